@@ -1,0 +1,282 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by executing the UNMODIFIED reference (/root/reference) under
+oracle/ref_harness.py in the build container.  Inputs are NOT stored: every fixture is a function of seeds through
+glamr_amd/utils/synth.py, which regenerates bit-identical inputs on the GPU box.
+
+    python -m oracle.make_golden            # all fixtures (~4 min on 8 cores)
+    python -m oracle.make_golden smpl nets  # a subset
+
+Fixture -> reference entry point:
+  smpl.npz      lib/models/smpl.py SMPL.forward / get_joints                     (sub-sampled vertices)
+  geom.npz      lib/utils/torch_transform.py, konia_transform.py, traj_utils.py  (function-level vectors)
+  nets.npz      MotionInfillerVAE.inference / TrajPredVAE.inference / MotionTrajJointModel.inference with supplied latents
+  grecon_<cfg>_T<T>_P<P>.npz   GlobalReconOptimizer.init_data, first-iteration losses + gradients, state after K Adam steps
+  full_glamr_dynamic_T300.npz  GlobalReconOptimizer.optimize end to end (500 iterations), BASELINE.json configs[1]
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+VERT_STRIDE = 53
+
+
+def seeded_inputs(kind, seed=0):
+    """Shared by the generator and the tests."""
+    rng = np.random.default_rng(777 + seed)
+    if kind == 'smpl':
+        B = 12
+        pose = rng.normal(size=(B, 72)).astype(np.float32) * 0.4
+        pose[0] = 0.0
+        pose[1, :3] = 1e-5          # near-zero angle branch
+        return dict(pose=pose, betas=rng.normal(size=(B, 10)).astype(np.float32),
+                    trans=rng.normal(size=(B, 3)).astype(np.float32), scale=rng.uniform(0.8, 1.2, size=B).astype(np.float32))
+    if kind == 'geom':
+        N = 64
+        aa = rng.normal(size=(N, 3)).astype(np.float32)
+        aa[0] = 0.0
+        aa[1] = [1e-4, 0, 0]
+        aa[2] = [3.1, 0.1, 0.0]
+        aa[3] = [0, 0, 3.14159]
+        return dict(aa=aa, aa2=rng.normal(size=(N, 3)).astype(np.float32), d6=rng.normal(size=(N, 6)).astype(np.float32),
+                    trans=rng.normal(size=(N, 3)).astype(np.float32), local=_local_traj(rng, N))
+    raise KeyError(kind)
+
+
+def _local_traj(rng, n):
+    loc = rng.normal(size=(n, 11)).astype(np.float32) * 0.1
+    loc[:, 3:9] += np.array([1, 0, 0, 0, 1, 0], dtype=np.float32)
+    loc[:, 9] += 1.0
+    return loc
+
+
+def net_inputs(T, seed=0):
+    rng = np.random.default_rng(4242 + seed)
+    t = np.arange(T)[:, None] / 30.0
+    pose = (0.3 * np.sin(2 * np.pi * rng.uniform(0.2, 0.8, size=(1, 69)) * t + rng.uniform(0, 6.28, size=(1, 69)))).astype(np.float32)
+    mask = np.ones(T, dtype=np.float64)
+    a = T // 3
+    mask[a:a + T // 5] = 0.0
+    pose[mask == 0] = 0.0
+    n_win = int(np.ceil((T - 10) / 30))
+    return dict(in_body_pose=pose[None], frame_mask=mask[None],
+                in_motion_latent=rng.normal(size=(n_win, 128)).astype(np.float32),
+                in_traj_latent=rng.normal(size=(1, 128)).astype(np.float32))
+
+
+def latents_for(in_dict, seed=0):
+    """Deterministic infiller / traj-predictor noise for every person of a synthetic sequence (replaces torch.randn_like at
+    lib/utils/dist.py:21-23; the reference accepts them through in_motion_latent / in_traj_latent)."""
+    out = {}
+    for idx, pd in in_dict['est'].items():
+        ex = pd['bboxes_dict']['exist']
+        vis = np.where(ex)[0]
+        n = vis[-1] + 1 - vis[0]
+        rng = np.random.default_rng(9000 + 31 * seed + idx)
+        out[idx] = dict(motion=rng.normal(size=(int(np.ceil((n - 10) / 30)), 128)).astype(np.float32),
+                        traj=rng.normal(size=(1, 128)).astype(np.float32))
+    return out
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+
+def gen_smpl():
+    from lib.models.smpl import SMPL, SMPL_MODEL_DIR
+    smpl = SMPL(SMPL_MODEL_DIR, pose_type='body26fk', create_transl=False)
+    x = {k: torch.tensor(v) for k, v in seeded_inputs('smpl').items()}
+    out = smpl(global_orient=x['pose'][:, :3], body_pose=x['pose'][:, 3:], betas=x['betas'], root_trans=x['trans'],
+               root_scale=x['scale'], return_full_pose=True)
+    out2 = smpl(global_orient=x['pose'][:, :3], body_pose=x['pose'][:, 3:], betas=x['betas'], return_full_pose=True)
+    out3 = smpl(global_orient=x['pose'][:, :3], body_pose=x['pose'][:, 3:], betas=x['betas'], root_trans=x['trans'], orig_joints=True)
+    fk = smpl.get_joints(global_orient=x['pose'][:, :3], body_pose=x['pose'][:, 3:], betas=x['betas'], root_trans=x['trans'])
+    np.savez_compressed(os.path.join(GOLD, 'smpl.npz'), joints=_np(out.joints), verts_sub=_np(out.vertices[:, ::VERT_STRIDE]),
+                        joints_noanchor=_np(out2.joints), verts_noanchor_sub=_np(out2.vertices[:, ::VERT_STRIDE]),
+                        joints_orig24=_np(out3.joints), fk_joints=_np(fk), joint_map=_np(smpl.joint_map))
+
+
+def gen_geom():
+    import lib.utils.torch_transform as tt
+    from lib.utils.geometry import perspective_projection
+    from traj_pred.utils import traj_utils as tu
+    x = {k: torch.tensor(v) for k, v in seeded_inputs('geom').items()}
+    q1, q2 = tt.angle_axis_to_quaternion(x['aa']), tt.angle_axis_to_quaternion(x['aa2'])
+    R = tt.angle_axis_to_rotation_matrix(x['aa'])
+    M = tt.make_transform(x['aa'], x['trans'], rot_type='axis_angle')
+    trans_g, q_g = tu.traj_local2global_heading(x['local'])
+    K = torch.tensor([[1000., 0, 960], [0, 1000., 540], [0, 0, 1]]).repeat(x['aa'].shape[0], 1, 1)
+    pts = x['trans'][:, None, :] * torch.tensor([1., 1., 0.2]) + torch.tensor([0., 0., 5.])
+    np.savez_compressed(
+        os.path.join(GOLD, 'geom.npz'),
+        aa_to_quat=_np(q1), aa_to_rotmat=_np(R), rotmat_to_quat=_np(tt.rotation_matrix_to_quaternion(R)),
+        quat_to_aa=_np(tt.quaternion_to_angle_axis(q1)), quat_mul=_np(tt.quat_mul(q1, q2)),
+        quat_angle_diff=_np(tt.quat_angle_diff(q1, q2)), quat_to_rotmat=_np(tt.quaternion_to_rotation_matrix(q1)),
+        sixd_to_rotmat=_np(tt.rot6d_to_rotmat(x['d6'])), aa_to_6d=_np(tt.angle_axis_to_rot6d(x['aa'])),
+        sixd_to_quat=_np(tt.rot6d_to_quat(x['d6'])), make_transform=_np(M), inverse_transform=_np(tt.inverse_transform(M)),
+        transform_trans=_np(tt.transform_trans(M, x['trans'].flip(0))), transform_rot=_np(tt.transform_rot(M, x['aa2'])),
+        heading=_np(tt.get_heading(q1)), heading_q=_np(tt.get_heading_q(q1)), l2g_trans=_np(trans_g), l2g_quat=_np(q_g),
+        g2l=_np(tu.traj_global2local_heading(trans_g, q_g)), project=_np(perspective_projection(pts, K)))
+
+
+def gen_nets():
+    from oracle import ref_harness as rh
+    model, _ = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
+    mt = model.mt_model
+    out = {}
+    for T in (120, 300):
+        b = {k: torch.tensor(v) for k, v in net_inputs(T).items()}
+        with torch.no_grad():
+            d = mt.inference(dict(b), sample_num=1)
+        out['T%d_body_pose' % T] = _np(d['infer_out_body_pose'])
+        out['T%d_local_traj' % T] = _np(d['infer_out_local_traj_tp'])
+        out['T%d_trans' % T] = _np(d['infer_out_trans'])
+        out['T%d_orient' % T] = _np(d['infer_out_orient'])
+    # one single-window infiller pass (T=40: one padded window, no autoregression) and the joint positions fed to the trajectory predictor
+    b = {k: torch.tensor(v) for k, v in net_inputs(40).items()}
+    with torch.no_grad():
+        d = mt.mfiller.inference({'in_body_pose': b['in_body_pose'], 'frame_mask': b['frame_mask'],
+                                  'in_motion_latent': b['in_motion_latent']}, sample_num=1, multi_step=True)
+        out['T40_body_pose'] = _np(d['infer_out_body_pose'])
+        out['T40_joint_pos'] = _np(mt.traj_predictor.get_joint_pos(d['infer_out_body_pose'][0, 0]))
+    np.savez_compressed(os.path.join(GOLD, 'nets.npz'), **out)
+
+
+def _flatten_state(data, keys_person, keys_top):
+    out = {}
+    for idx, pd in data['person_data'].items():
+        for k in keys_person:
+            if k in pd and pd[k] is not None:
+                out['p%d_%s' % (idx, k)] = _np(pd[k])
+    for k in keys_top:
+        if k in data:
+            out[k] = _np(data[k])
+    return out
+
+
+PERSON_KEYS_INIT = ['visible', 'visible_orig', 'exist_frames', 'vis_frames', 'invis_frames', 'fr_start', 'fr_end', 'exist_len',
+                    'smpl_pose', 'smpl_beta', 'smpl_orient_cam', 'root_trans_cam', 'kp_2d_score', 'kp_2d_aligned', 'cam_K',
+                    'smpl_pose_nofill', 'traj_local_pred', 'smpl_orient_world', 'root_trans_world', 'person2cam', 'kp_2d_pred']
+PERSON_KEYS_OPT = ['smpl_orient_world', 'root_trans_world', 'kp_2d_pred', 'traj_local_xy', 'traj_local_dxy', 'traj_local_heading',
+                   'traj_local_dheading', 'traj_local_z', 'traj_local_rot', 'world_dheading', 'smpl_orient_cam_in_world']
+TOP_KEYS = ['cam_pose', 'cam_pose_inv', 'cam_inv_rot_residual', 'cam_inv_trans_residual', 'fr_num_persons',
+            'cam_rot_6d', 'cam_trans', 'cam_rot_6d_fix', 'cam_trans_fix']
+
+
+def run_reference(model, cfg_specs, in_dict, latents, niters=None, grads_out=None):
+    """init_data + staged optimisation with the reference classes; `niters` caps every stage (None = full schedule)."""
+    # the reference only forwards latents when flag_opt_*_latent is set (global_recon_model.py:364-367); pass them by
+    # seeding the dict and enabling the flags around init_data, then disable so they are not optimised
+    model.flag_opt_motion_latent = model.flag_opt_traj_latent = True
+    mt = model.mt_model
+    keep = (mt.get_motion_latent, mt.get_traj_latent)
+    order = iter(sorted(latents.keys()))
+    state = {}
+
+    def motion_latent(seq_len):
+        state['idx'] = next(order)
+        return torch.tensor(latents[state['idx']]['motion'])
+
+    def traj_latent(seq_len):
+        return torch.tensor(latents[state['idx']]['traj'])
+
+    mt.get_motion_latent, mt.get_traj_latent = motion_latent, traj_latent
+    try:
+        data = model.init_data(in_dict)
+    finally:
+        mt.get_motion_latent, mt.get_traj_latent = keep
+        model.flag_opt_motion_latent = model.flag_opt_traj_latent = False
+    init_state = _flatten_state(data, PERSON_KEYS_INIT, TOP_KEYS)
+    for stage, spec in cfg_specs.items():
+        if grads_out is not None and stage not in grads_out:
+            params = model.get_parameter(data, spec['opt_variables'])
+            for p in params:
+                p.requires_grad_(True)
+                p.grad = None
+            model.forward(data, spec['opt_variables'], {'stage': stage})
+            loss, ld, lud = model.compute_loss(data, spec['loss_cfg'])
+            loss.backward()
+            g = {'loss_total': _np(loss)}
+            for name, v in lud.items():
+                g['loss_' + name] = _np(torch.as_tensor(v))
+            names = _param_names(model, data, spec['opt_variables'])
+            for nm, p in zip(names, params):
+                g['grad_' + nm] = _np(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            grads_out[stage] = g
+            for p in params:
+                p.requires_grad_(False)
+                p.grad = None
+        n = spec['opt_niters'] if niters is None else min(niters, spec['opt_niters'])
+        model.optimize_main(data, spec['opt_variables'], spec['opt_lr'], n, spec['loss_cfg'], {'stage': stage})
+    return data, init_state
+
+
+def _param_names(model, data, opt_variables):
+    """Names in the order get_parameter (global_recon_model.py:591-633) appends them."""
+    names = []
+    if 'cam' not in opt_variables:
+        names += ['cam_inv_rot_residual', 'cam_inv_trans_residual']
+    else:
+        names += ['cam_rot_6d_fix', 'cam_trans_fix'] if model.flag_fixed_cam else ['cam_rot_6d', 'cam_trans']
+    for idx in data['person_data'].keys():
+        for key in opt_variables:
+            if 'local' in key:
+                names.append('p%d_traj_%s' % (idx, key))
+        if 'world_dheading' in opt_variables:
+            names.append('p%d_world_dheading' % idx)
+    return names
+
+
+GRECON_CASES = [('glamr_dynamic', 120, 1, 25), ('glamr_static', 90, 1, 25), ('glamr_static_multi', 120, 2, 15),
+                ('glamr_dynamic_multi', 100, 2, 15), ('glamr_3dpw', 120, 1, 15), ('glamr_h36m', 100, 2, 10)]
+
+
+def gen_grecon(cases=GRECON_CASES):
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    for cfg_id, T, P, K in cases:
+        model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+        in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md)
+        grads = {}
+        data, init_state = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 3), niters=K, grads_out=grads)
+        out = {'init_' + k: v for k, v in init_state.items()}
+        out.update({'opt_' + k: v for k, v in _flatten_state(data, PERSON_KEYS_OPT, TOP_KEYS).items()})
+        for stage, g in grads.items():
+            out.update({'%s_%s' % (stage, k): v for k, v in g.items()})
+        out['niters'] = np.array(K)
+        np.savez_compressed(os.path.join(GOLD, 'grecon_%s_T%d_P%d.npz' % (cfg_id, T, P)), **out)
+        print('wrote', cfg_id, T, P)
+
+
+def gen_full():
+    import time
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    model, cfg = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
+    in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=md)
+    t0 = time.time()
+    data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 0))
+    dt = time.time() - t0
+    out = _flatten_state(data, PERSON_KEYS_OPT + ['smpl_pose', 'visible', 'vis_frames'], TOP_KEYS)
+    out['ref_seconds'] = np.array(dt)
+    out['ref_threads'] = np.array(torch.get_num_threads())
+    np.savez_compressed(os.path.join(GOLD, 'full_glamr_dynamic_T300.npz'), **out)
+    print('full reference optimize(): %.1f s on %d threads' % (dt, torch.get_num_threads()))
+
+
+def main(argv):
+    from oracle import ref_harness as rh
+    rh.setup()
+    os.makedirs(GOLD, exist_ok=True)
+    todo = argv or ['smpl', 'geom', 'nets', 'grecon', 'full']
+    for name in todo:
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'grecon': gen_grecon, 'full': gen_full}[name]()
+        print('done', name)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])
