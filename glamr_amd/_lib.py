@@ -1,0 +1,95 @@
+"""ctypes binding of libglamr_hip.so (include/glamr_hip.h).  There is NO fallback: if the library is missing or a call
+fails, a RuntimeError is raised -- the product path never computes on the CPU."""
+import ctypes
+import os
+from ctypes import c_int, c_int32, c_int64, c_size_t, c_uint32, c_float, c_void_p, c_char_p, POINTER, Structure
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libglamr_hip.so')
+NUM_LOSSES = 13
+
+
+class TensorDesc(Structure):
+    _fields_ = [('offset', c_int64), ('rows', c_int32), ('cols', c_int32)]
+
+
+class StageDesc(Structure):
+    _fields_ = [('var_mask', c_uint32), ('flags', c_uint32), ('loss_mask', c_uint32), ('monitor_mask', c_uint32),
+                ('first_frame_only_mask', c_uint32), ('niters', c_int32), ('lr', c_float), ('loss_weight', c_float * 16),
+                ('kp_min_conf', c_float), ('first_frame_weight', c_float * 16), ('rel_trans_weight', c_float)]
+
+
+class SceneBatch(Structure):
+    _fields_ = [('n_scenes', c_int32), ('max_persons', c_int32), ('max_len', c_int32), ('n_joints', c_int32),
+                ('n_persons', c_void_p), ('fr_start', c_void_p), ('fr_end', c_void_p),
+                ('vis', c_void_p), ('j_local', c_void_p), ('kp_2d', c_void_p), ('kp_score', c_void_p), ('cam_K', c_void_p),
+                ('traj_local_pred', c_void_p), ('orient_cam', c_void_p), ('base_orient', c_void_p), ('base_trans', c_void_p),
+                ('person2cam', c_void_p), ('rel_transform_cam', c_void_p),
+                ('cam_pose', c_void_p), ('params', c_void_p), ('losses', c_void_p),
+                ('orient_world', c_void_p), ('trans_world', c_void_p), ('kp_2d_pred', c_void_p), ('orient_cam_in_world', c_void_p)]
+
+
+class ParamLayout(Structure):
+    _fields_ = [(n, c_int32) for n in ('scene_stride', 'cam_rot6d', 'cam_trans', 'cam_inv_rot_res', 'cam_inv_trans_res',
+                                       'person_stride', 'person0', 'local_xy', 'local_dxy', 'local_heading', 'local_dheading',
+                                       'local_z', 'local_rot', 'world_dheading')]
+
+
+_SIGNATURES = {
+    'glamr_version': (c_int, []),
+    'glamr_last_error': (c_char_p, []),
+    'glamr_device_info': (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
+    'glamr_smpl_create': (c_int, [POINTER(c_void_p), c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    'glamr_smpl_destroy': (c_int, [c_void_p]),
+    'glamr_smpl_workspace_bytes': (c_size_t, [c_void_p, c_int]),
+    'glamr_smpl_forward': (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p]),
+    'glamr_smpl_fk': (c_int, [c_void_p, c_int] + [c_void_p] * 5),
+    'glamr_smpl_backward_root': (c_int, [c_void_p, c_int] + [c_void_p] * 10 + [c_int, c_void_p]),
+    'glamr_nets_create': (c_int, [POINTER(c_void_p), c_void_p, POINTER(TensorDesc), c_int, c_void_p, POINTER(TensorDesc), c_int, c_void_p, c_void_p]),
+    'glamr_nets_destroy': (c_int, [c_void_p]),
+    'glamr_nets_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
+    'glamr_nets_infer': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 7),
+    'glamr_grecon_param_layout': (c_int, [c_int, c_int, POINTER(ParamLayout)]),
+    'glamr_grecon_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'glamr_grecon_run_stage': (c_int, [POINTER(SceneBatch), POINTER(StageDesc), c_void_p, c_void_p, c_void_p]),
+}
+
+
+def exported_symbols():
+    """Names every entry point include/glamr_hip.h declares (checked against the header in tests/test_abi.py)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libglamr_hip.so is not built (%s missing): run `python -m glamr_amd.build` or '
+                               '`python -c "import __graft_entry__ as g; g.build()"`.  There is no CPU fallback.' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('libglamr_hip: %s (code %d)' % (lib().glamr_last_error().decode('utf-8', 'replace'), rc))
+
+
+def ptr(t):
+    """Device (or host) address of a contiguous torch tensor / numpy array, or None."""
+    if t is None:
+        return None
+    if hasattr(t, 'data_ptr'):
+        assert t.is_contiguous(), 'libglamr_hip needs contiguous tensors'
+        return c_void_p(t.data_ptr())
+    assert t.flags['C_CONTIGUOUS']
+    return c_void_p(t.ctypes.data)
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,54 @@
+"""Builds libglamr_hip.so (gfx950) in-tree with hipcc.  `python -m glamr_amd.build [--force]`."""
+import glob
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, 'csrc')
+LIB_PATH = os.path.join(PKG_DIR, 'libglamr_hip.so')
+HEADER = os.path.join(os.path.dirname(PKG_DIR), 'include', 'glamr_hip.h')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
+
+
+def _headers():
+    return glob.glob(os.path.join(CSRC, '*.hpp')) + [HEADER]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in _sources() + _headers())
+
+
+def build_library(force=False, verbose=False):
+    """Compiles every source under csrc/ into one shared object.  Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    objs = []
+    bdir = os.path.join(CSRC, 'build')
+    os.makedirs(bdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(p) for p in _headers())
+    for src in _sources():
+        obj = os.path.join(bdir, os.path.basename(src) + '.o')
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB_PATH]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build_library(force='--force' in sys.argv, verbose=True))

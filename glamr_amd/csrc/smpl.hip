@@ -1,0 +1,670 @@
+// SMPL forward kinematics + linear blend skinning for gfx950 (MI355X).
+//
+// Replaces lib/models/smpl.py:274-343 and the smplx.lbs it calls.  Pipeline per call:
+//   smpl_prep_kernel    per frame: Rodrigues (smplx variant), pose/shape feature row, kinematic chain (level-parallel),
+//                       skinning transforms A_j, posed chain joints
+//   smpl_lbs_kernel     f32-MFMA tiles: v_posed = [betas | R-I | 1] . [shapedirs | posedirs | v_template] (K=218, three
+//                       coordinate planes sharing the frame operand), T = W . A (K=24), verts = T . [v_posed; 1];
+//                       in-register regression of the extra joints, picked-vertex capture, optional vertex write-out
+//                       through an LDS transpose (coalesced 384-B rows)
+//   smpl_finish_kernel  reduces the per-tile regression partials, assembles the mapped joints, re-anchors them
+//   smpl_anchor_kernel  (only if vertices are requested with root_trans) verts = (verts - pivot) * scale + trans
+//
+// MFMA tile orientation: rows (A operand) = vertices of the tile, cols (B operand) = frames.  With
+// v_mfma_f32_32x32x2_f32, lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; the reduction index k is
+// consumed in two interleaved halves (lanes 0-31 walk k = 0..KH-1, lanes 32-63 walk k = KH..2KH-1) so every lane
+// reads CONTIGUOUS k and operands can be fetched 16 bytes at a time.  Accumulator register r of lane l is
+// element (row = (r & 3) + 8 (r >> 2) + 4 (l >> 5), col = l & 31).
+#include "common.hpp"
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+namespace glamr {
+
+constexpr int NJ = 24;            // chain joints
+constexpr int KH = 112;           // reduction entries per lane-half
+constexpr int KTOT = 2 * KH;      // 224 >= 10 + 207 + 1
+constexpr int KSTRIDE = 228;      // LDS row stride in floats: 228 mod 64 = 36 -> conflict-free ds_read_b128 over 16 rows
+constexpr int TILE_V = 32;
+constexpr int TILE_F = 32;
+constexpr int MAX_EXTRA = 9;
+constexpr int MAX_PICKED = 32;
+constexpr int OUT_STRIDE = 97;    // LDS transpose row stride (floats) for the vertex write-out
+constexpr int K_ONE = 217;        // feature index that carries the constant 1 (multiplies v_template)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace glamr
+
+struct glamr_smpl {
+  int V, Vpad, num_betas, n_extra, n_picked, n_out, n_tiles, n_levels;
+  int n_extra_used;
+  // device constants
+  float* dirs_tiled;      // [n_tiles][3][32][KSTRIDE]
+  float* w_tiled;         // [Vpad][24]
+  float* jx_used;         // [n_extra_used][Vpad]
+  float* j_template;      // [24][3]
+  float* j_shapedirs;     // [24][3][num_betas]
+  float* j_template_unshaped;  // [24][3]  (= j_template; kept separate for clarity of get_joints)
+  int32_t* parents;       // [24]
+  int32_t* level;         // [24]
+  int32_t* joint_map;     // [n_out]
+  int32_t* extra_slot;    // [MAX_EXTRA] -> slot in jx_used or -1
+  int32_t* pick_tile;     // [n_picked] tile index of each picked vertex
+  int32_t* pick_row;      // [n_picked] row inside the tile
+  int32_t* tile_pick_start;  // [n_tiles+1] CSR over picks sorted by tile
+  int32_t* tile_pick_ids;    // [n_picked] pick slot ids sorted by tile
+};
+
+namespace glamr {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------------
+
+// smplx batch_rodrigues: angle = || r + 1e-8 ||, R = I + sin K + (1 - cos) K^2 with K from r / angle.
+__device__ __forceinline__ void rodrigues_smplx(const float r[3], float R[9]) {
+  const float ax = r[0] + 1e-8f, ay = r[1] + 1e-8f, az = r[2] + 1e-8f;
+  const float angle = sqrtf(ax * ax + ay * ay + az * az);
+  const float inv = 1.0f / angle;
+  const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
+  const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+  // K = [[0,-z,y],[z,0,-x],[-y,x,0]],  K^2 = [[-(y^2+z^2), xy, xz],[xy, -(x^2+z^2), yz],[xz, yz, -(x^2+y^2)]]
+  R[0] = 1.0f + c1 * (-(y * y + z * z));
+  R[1] = s * (-z) + c1 * (x * y);
+  R[2] = s * (y) + c1 * (x * z);
+  R[3] = s * (z) + c1 * (x * y);
+  R[4] = 1.0f + c1 * (-(x * x + z * z));
+  R[5] = s * (-x) + c1 * (y * z);
+  R[6] = s * (-y) + c1 * (x * z);
+  R[7] = s * (x) + c1 * (y * z);
+  R[8] = 1.0f + c1 * (-(x * x + y * y));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// prep: one thread per (frame, joint); FRAMES_PER_BLOCK frames per 256-thread block
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PREP_FRAMES = 8;   // 8 * 24 = 192 active threads of 256
+
+struct PrepArgs {
+  int B, num_betas, n_levels, use_shape;
+  const float* pose;        // (B,72)
+  const float* betas;       // (B,num_betas) or null
+  const float* j_template;  // (24,3)
+  const float* j_shapedirs; // (24,3,num_betas)
+  const int32_t* parents;
+  const int32_t* level;
+  float* feat;              // (Bpad, KTOT) or null
+  float* askin;             // (Bpad, 12, 24) or null
+  float* chain_joints;      // (B, 24, 3)
+};
+
+__global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
+  __shared__ float sG[PREP_FRAMES][NJ][12];   // global transform of each joint: 3x3 rotation | translation
+  __shared__ float sJ[PREP_FRAMES][NJ][3];    // rest joints
+  const int tid = threadIdx.x;
+  const int fl = tid / NJ, j = tid % NJ;
+  const int b = blockIdx.x * PREP_FRAMES + fl;
+  const bool active = (fl < PREP_FRAMES) && (b < a.B);
+  float R[9];
+  float Jr[3] = {0.f, 0.f, 0.f};
+  if (active) {
+    float r[3] = {a.pose[(size_t)b * 72 + j * 3 + 0], a.pose[(size_t)b * 72 + j * 3 + 1], a.pose[(size_t)b * 72 + j * 3 + 2]};
+    rodrigues_smplx(r, R);
+    for (int c = 0; c < 3; ++c) {
+      float v = a.j_template[j * 3 + c];
+      if (a.use_shape)
+        for (int l = 0; l < a.num_betas; ++l) v = fmaf(a.j_shapedirs[(j * 3 + c) * a.num_betas + l], a.betas[(size_t)b * a.num_betas + l], v);
+      Jr[c] = v;
+      sJ[fl][j][c] = v;
+    }
+    if (a.feat) {
+      float* f = a.feat + (size_t)b * KTOT;
+      if (j > 0) {
+        for (int e = 0; e < 9; ++e) f[10 + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+      } else {
+        for (int l = 0; l < 10; ++l) f[l] = (l < a.num_betas) ? a.betas[(size_t)b * a.num_betas + l] : 0.0f;
+        f[K_ONE] = 1.0f;
+        for (int k = K_ONE + 1; k < KTOT; ++k) f[k] = 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  // kinematic chain, one tree level at a time (SMPL: 9 levels)
+  const int par = active ? a.parents[j] : -1;
+  const int lev = active ? a.level[j] : -1;
+  if (active && lev == 0) {
+    for (int e = 0; e < 9; ++e) sG[fl][j][(e / 3) * 4 + (e % 3)] = R[e];
+    for (int c = 0; c < 3; ++c) sG[fl][j][c * 4 + 3] = Jr[c];
+  }
+  __syncthreads();
+  for (int L = 1; L < a.n_levels; ++L) {
+    if (active && lev == L) {
+      const float* Gp = sG[fl][par];
+      float t[3] = {Jr[0] - sJ[fl][par][0], Jr[1] - sJ[fl][par][1], Jr[2] - sJ[fl][par][2]};
+      float G[12];
+      for (int r0 = 0; r0 < 3; ++r0) {
+        for (int c = 0; c < 3; ++c) G[r0 * 4 + c] = Gp[r0 * 4 + 0] * R[0 * 3 + c] + Gp[r0 * 4 + 1] * R[1 * 3 + c] + Gp[r0 * 4 + 2] * R[2 * 3 + c];
+        G[r0 * 4 + 3] = Gp[r0 * 4 + 0] * t[0] + Gp[r0 * 4 + 1] * t[1] + Gp[r0 * 4 + 2] * t[2] + Gp[r0 * 4 + 3];
+      }
+      for (int e = 0; e < 12; ++e) sG[fl][j][e] = G[e];
+    }
+    __syncthreads();
+  }
+  if (active) {
+    const float* G = sG[fl][j];
+    for (int c = 0; c < 3; ++c) a.chain_joints[((size_t)b * NJ + j) * 3 + c] = G[c * 4 + 3];
+    if (a.askin) {
+      // relative transform: A = [G_R | G_t - G_R J]
+      float* A = a.askin + (size_t)b * 12 * NJ;
+      for (int r0 = 0; r0 < 3; ++r0) {
+        for (int c = 0; c < 3; ++c) A[(r0 * 4 + c) * NJ + j] = G[r0 * 4 + c];
+        A[(r0 * 4 + 3) * NJ + j] = G[r0 * 4 + 3] - (G[r0 * 4 + 0] * Jr[0] + G[r0 * 4 + 1] * Jr[1] + G[r0 * 4 + 2] * Jr[2]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// main LBS kernel
+// ---------------------------------------------------------------------------------------------------------------------
+struct LbsArgs {
+  int B, V, n_tiles, n_ftiles, n_extra_used, n_picked;
+  const float* dirs_tiled;
+  const float* w_tiled;
+  const float* jx_used;
+  const int32_t* tile_pick_start;
+  const int32_t* tile_pick_ids;
+  const int32_t* pick_row;
+  const float* feat;        // (Bpad, KTOT)
+  const float* askin;       // (Bpad, 12, 24)
+  float* verts;             // (B, V, 3) or null
+  float* picked;            // (B, n_picked, 3)
+  float* partial;           // (n_tiles, Bpad, n_extra_used, 3)
+  int Bpad;
+};
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int NE>
+__global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sDirs = smem;                                   // [3][32][KSTRIDE]
+  float* sOut = smem + 3 * TILE_V * KSTRIDE;             // [4 waves][32 frames][OUT_STRIDE]  (only when verts != null)
+  const int tile = blockIdx.x;
+  const int v0 = tile * TILE_V;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+
+  // stage this tile's direction matrix (contiguous 3*32*KSTRIDE floats) into LDS
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.dirs_tiled + (size_t)tile * 3 * TILE_V * KSTRIDE);
+    f32x4* dst = reinterpret_cast<f32x4*>(sDirs);
+    for (int i = tid; i < 3 * TILE_V * KSTRIDE / 4; i += 256) dst[i] = src[i];
+  }
+  // skinning weights of my A-operand row (vertex v0 + col), my k-half: 12 values
+  float wreg[12];
+  {
+    const float* w = a.w_tiled + (size_t)(v0 + col) * NJ + half * 12;
+#pragma unroll
+    for (int m = 0; m < 12; ++m) wreg[m] = w[m];
+  }
+  // extra-joint regressor weights for the 16 accumulator rows this lane owns
+  float jx[NE > 0 ? NE : 1][16];
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) jx[e][r] = a.jx_used[(size_t)e * (a.n_tiles * TILE_V) + v0 + acc_row(r, half)];
+  __syncthreads();
+
+  const float* myDirs = sDirs + (size_t)col * KSTRIDE + half * KH;
+
+  for (int ft = wave; ft < a.n_ftiles; ft += 4) {
+    const int b = ft * TILE_F + col;            // Bpad is a multiple of 32: always a readable row
+    const float* frow = a.feat + (size_t)b * KTOT + half * KH;
+    f32x16 px = {0}, py = {0}, pz = {0};
+#pragma unroll 2
+    for (int m = 0; m < KH / 4; ++m) {
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(frow + 4 * m);
+      const f32x4 ax = *reinterpret_cast<const f32x4*>(myDirs + 0 * TILE_V * KSTRIDE + 4 * m);
+      const f32x4 ay = *reinterpret_cast<const f32x4*>(myDirs + 1 * TILE_V * KSTRIDE + 4 * m);
+      const f32x4 az = *reinterpret_cast<const f32x4*>(myDirs + 2 * TILE_V * KSTRIDE + 4 * m);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        px = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s], fb[s], px, 0, 0, 0);
+        py = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[s], fb[s], py, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_32x32x2f32(az[s], fb[s], pz, 0, 0, 0);
+      }
+    }
+    // skinning: out_r = T_r0 px + T_r1 py + T_r2 pz + T_r3,  T_e[v, b] = sum_j W[v, j] A_e[b, j]
+    const float* arow = a.askin + (size_t)b * 12 * NJ + half * 12;
+    f32x16 out[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      f32x16 T[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        T[c] = (f32x16){0};
+        const float* ae = arow + (r * 4 + c) * NJ;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ae), a1 = *reinterpret_cast<const f32x4*>(ae + 4),
+                    a2 = *reinterpret_cast<const f32x4*>(ae + 8);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[m], a0[m], T[c], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 + m], a1[m], T[c], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[8 + m], a2[m], T[c], 0, 0, 0);
+      }
+      out[r] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+    }
+    const bool frame_ok = b < a.B;
+    // extra-joint regression partial sums: sum over this tile's 32 vertices (16 rows here + 16 in the other half)
+    if (NE > 0) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float s = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) s = fmaf(jx[e][q], out[r][q], s);
+          s += __shfl_xor(s, 32);
+          if (half == 0) a.partial[(((size_t)tile * a.Bpad + b) * NE + e) * 3 + r] = s;
+        }
+      }
+    }
+    // picked vertices of this tile (rare: 21 picks over 216 tiles)
+    for (int p = a.tile_pick_start[tile]; p < a.tile_pick_start[tile + 1]; ++p) {
+      const int slot = a.tile_pick_ids[p];
+      const int row = a.pick_row[slot];
+      if (frame_ok) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (acc_row(q, half) == row) {
+            float* dst = a.picked + ((size_t)b * a.n_picked + slot) * 3;
+            dst[0] = out[0][q];
+            dst[1] = out[1][q];
+            dst[2] = out[2][q];
+          }
+      }
+    }
+    // vertex write-out through an LDS transpose: [frame][vertex row][xyz] so each frame's 96 floats are contiguous
+    if (a.verts) {
+      float* so = sOut + (size_t)wave * TILE_F * OUT_STRIDE;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = acc_row(q, half);
+        so[col * OUT_STRIDE + row * 3 + 0] = out[0][q];
+        so[col * OUT_STRIDE + row * 3 + 1] = out[1][q];
+        so[col * OUT_STRIDE + row * 3 + 2] = out[2][q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int nvalid = min(TILE_V, a.V - v0) * 3;
+      for (int idx = lane; idx < TILE_F * 96; idx += 64) {
+        const int f = idx / 96, c = idx - f * 96;
+        const int bb = ft * TILE_F + f;
+        if (bb < a.B && c < nvalid) a.verts[((size_t)bb * a.V + v0) * 3 + c] = so[f * OUT_STRIDE + c];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// finish: assemble mapped joints, re-anchor
+// ---------------------------------------------------------------------------------------------------------------------
+struct FinishArgs {
+  int B, Bpad, n_tiles, n_extra_used, n_picked, n_out, orig_joints;
+  const float* chain_joints;   // (B,24,3)
+  const float* picked;         // (B,n_picked,3)
+  const float* partial;        // (n_tiles,Bpad,n_extra_used,3)
+  const int32_t* joint_map;
+  const int32_t* extra_slot;
+  const float* root_trans;     // (B,3) or null
+  const float* root_scale;     // (B) or null
+  float* joints;               // (B,n_out,3)
+  float* pivot;                // (B,3) un-anchored position of joint 0 (for the vertex pass)
+};
+
+__global__ __launch_bounds__(64) void smpl_finish_kernel(FinishArgs a) {
+  __shared__ float sExtra[MAX_EXTRA * 3];
+  __shared__ float sPivot[3];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nred = a.n_extra_used * 3;
+  // deterministic reduction over tiles: lane l sums tiles l, l+64, ... then a shuffle tree
+  for (int q = 0; q < nred; ++q) {
+    float s = 0.f;
+    for (int t = lane; t < a.n_tiles; t += 64) s += a.partial[((size_t)t * a.Bpad + b) * nred + q];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) sExtra[q] = s;
+  }
+  __syncthreads();
+  const int n_out = a.orig_joints ? NJ : a.n_out;
+  float val[3] = {0.f, 0.f, 0.f};
+  if (lane < n_out) {
+    const int src = a.orig_joints ? lane : a.joint_map[lane];
+    for (int c = 0; c < 3; ++c) {
+      if (src < NJ) val[c] = a.chain_joints[((size_t)b * NJ + src) * 3 + c];
+      else if (src < NJ + a.n_picked) val[c] = a.picked[((size_t)b * a.n_picked + (src - NJ)) * 3 + c];
+      else val[c] = sExtra[a.extra_slot[src - NJ - a.n_picked] * 3 + c];
+    }
+    if (lane == 0) for (int c = 0; c < 3; ++c) sPivot[c] = val[c];
+  }
+  __syncthreads();
+  if (lane < n_out) {
+    if (a.root_trans) {
+      const float sc = a.root_scale ? a.root_scale[b] : 1.0f;
+      for (int c = 0; c < 3; ++c) val[c] = (val[c] - sPivot[c]) * sc + a.root_trans[(size_t)b * 3 + c];
+    }
+    for (int c = 0; c < 3; ++c) a.joints[((size_t)b * n_out + lane) * 3 + c] = val[c];
+  }
+  if (lane < 3 && a.pivot) a.pivot[(size_t)b * 3 + lane] = sPivot[lane];
+}
+
+__global__ __launch_bounds__(256) void smpl_anchor_kernel(int B, int V, const float* pivot, const float* root_trans,
+                                                          const float* root_scale, float* verts) {
+  const int b = blockIdx.y;
+  const float sc = root_scale ? root_scale[b] : 1.0f;
+  const float p[3] = {pivot[b * 3], pivot[b * 3 + 1], pivot[b * 3 + 2]};
+  const float t[3] = {root_trans[b * 3], root_trans[b * 3 + 1], root_trans[b * 3 + 2]};
+  float* row = verts + (size_t)b * V * 3;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < V * 3; i += gridDim.x * 256) {
+    const int c = i % 3;
+    row[i] = (row[i] - p[c]) * sc + t[c];
+  }
+}
+
+// FK-only re-anchoring (get_joints): joints = (joints - joints[0]) * scale + root_trans
+__global__ void smpl_fk_anchor_kernel(int B, const float* root_trans, const float* root_scale, float* joints) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  __shared__ float p[3];
+  float v[3];
+  for (int c = 0; c < 3; ++c) v[c] = joints[((size_t)b * NJ + j) * 3 + c];
+  if (j == 0) for (int c = 0; c < 3; ++c) p[c] = v[c];
+  __syncthreads();
+  const float sc = root_scale ? root_scale[b] : 1.0f;
+  for (int c = 0; c < 3; ++c) joints[((size_t)b * NJ + j) * 3 + c] = (v[c] - p[c]) * sc + root_trans[(size_t)b * 3 + c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward w.r.t. root orientation / translation / scale through the rigid identity
+//   y = s R (x_local - pivot_local) + t   =>   dL/dR = [sum g (y - t)^T] R / 1,   dL/dt = sum g,   dL/ds = sum g.(y - t) / s
+// followed by the backward of the smplx Rodrigues formula.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  int B, V, n_out;
+  const float* pose; const float* root_trans; const float* root_scale;
+  const float* verts; const float* joints; const float* g_verts; const float* g_joints;
+  float* g_orient; float* g_trans; float* g_scale;
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void smpl_backward_root_kernel(BwdArgs a) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bool anchored = a.root_trans != nullptr;
+  float t[3] = {0.f, 0.f, 0.f};
+  if (anchored) for (int c = 0; c < 3; ++c) t[c] = a.root_trans[(size_t)b * 3 + c];
+  // when not anchored the rigid motion is about the (shaped) root joint, which the outputs do not carry: unsupported here
+  float M[9] = {0}, gs[3] = {0}, gdot = 0.f;
+  auto accum = [&](const float* y, const float* g) {
+    const float d[3] = {y[0] - t[0], y[1] - t[1], y[2] - t[2]};
+    for (int i = 0; i < 3; ++i) {
+      gs[i] += g[i];
+      gdot += g[i] * d[i];
+      for (int k = 0; k < 3; ++k) M[i * 3 + k] += g[i] * d[k];
+    }
+  };
+  if (a.g_verts)
+    for (int v = tid; v < a.V; v += 256) accum(a.verts + ((size_t)b * a.V + v) * 3, a.g_verts + ((size_t)b * a.V + v) * 3);
+  if (a.g_joints)
+    for (int j = tid; j < a.n_out; j += 256) accum(a.joints + ((size_t)b * a.n_out + j) * 3, a.g_joints + ((size_t)b * a.n_out + j) * 3);
+  for (int e = 0; e < 9; ++e) M[e] = block_sum_256(M[e], red);
+  for (int e = 0; e < 3; ++e) gs[e] = block_sum_256(gs[e], red);
+  gdot = block_sum_256(gdot, red);
+  if (tid != 0) return;
+  const float sc = a.root_scale ? a.root_scale[b] : 1.0f;
+  if (a.g_trans) for (int c = 0; c < 3; ++c) a.g_trans[(size_t)b * 3 + c] = gs[c];
+  if (a.g_scale) a.g_scale[b] = gdot / sc;
+  // dL/dR = M R   (since (x_local - pivot) = R^T (y - t) / s  and  dy/dR = s (x_local - pivot)^T)
+  const float r[3] = {a.pose[(size_t)b * 72], a.pose[(size_t)b * 72 + 1], a.pose[(size_t)b * 72 + 2]};
+  float R[9];
+  rodrigues_smplx(r, R);
+  float gR[9];
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k) gR[i * 3 + k] = M[i * 3 + 0] * R[0 * 3 + k] + M[i * 3 + 1] * R[1 * 3 + k] + M[i * 3 + 2] * R[2 * 3 + k];
+  // backward of rodrigues_smplx
+  const float ax = r[0] + 1e-8f, ay = r[1] + 1e-8f, az = r[2] + 1e-8f;
+  const float angle = sqrtf(ax * ax + ay * ay + az * az), inv = 1.0f / angle;
+  const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
+  const float s = sinf(angle), c = cosf(angle), c1 = 1.0f - c;
+  // R = I + s K + c1 K2
+  const float K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
+  float g_s = 0.f, g_c1 = 0.f;
+  for (int e = 0; e < 9; ++e) { g_s += gR[e] * K[e]; g_c1 += gR[e] * K2[e]; }
+  // d/dx, d/dy, d/dz of (s K + c1 K2)
+  float gx = s * (gR[7] - gR[5]) + c1 * (y * (gR[1] + gR[3]) + z * (gR[2] + gR[6]) - 2.f * x * (gR[4] + gR[8]));
+  float gy = s * (gR[2] - gR[6]) + c1 * (x * (gR[1] + gR[3]) + z * (gR[5] + gR[7]) - 2.f * y * (gR[0] + gR[8]));
+  float gz = s * (gR[3] - gR[1]) + c1 * (x * (gR[2] + gR[6]) + y * (gR[5] + gR[7]) - 2.f * z * (gR[0] + gR[4]));
+  const float g_angle = g_s * c + g_c1 * s;          // d s/d angle = cos, d c1/d angle = sin
+  // x = r0 / angle etc.; angle = || r + eps ||
+  const float g_angle_tot = g_angle - (gx * r[0] + gy * r[1] + gz * r[2]) * inv * inv;
+  a.g_orient[(size_t)b * 3 + 0] = gx * inv + g_angle_tot * ax * inv;
+  a.g_orient[(size_t)b * 3 + 1] = gy * inv + g_angle_tot * ay * inv;
+  a.g_orient[(size_t)b * 3 + 2] = gz * inv + g_angle_tot * az * inv;
+}
+
+}  // namespace glamr
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+using namespace glamr;
+
+extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const float* v_template, const float* shapedirs,
+                                 const float* posedirs, const float* J_regressor, const float* lbs_weights,
+                                 const float* J_regressor_extra, int n_extra, const int32_t* parents,
+                                 const int32_t* extra_vertex_ids, int n_picked, const int32_t* joint_map, int n_out) {
+  GLAMR_REQUIRE(out && v_template && shapedirs && posedirs && J_regressor && lbs_weights && parents && joint_map, "null argument");
+  GLAMR_REQUIRE(V > 0 && num_betas > 0 && num_betas <= 10, "unsupported V=%d num_betas=%d (<=10)", V, num_betas);
+  GLAMR_REQUIRE(n_extra >= 0 && n_extra <= MAX_EXTRA && n_picked >= 0 && n_picked <= MAX_PICKED && n_out > 0 && n_out <= 64,
+                "unsupported n_extra=%d n_picked=%d n_out=%d", n_extra, n_picked, n_out);
+  glamr_smpl* h = new (std::nothrow) glamr_smpl();
+  if (!h) return fail(GLAMR_E_NOMEM, "out of host memory");
+  std::memset(h, 0, sizeof(*h));
+  h->V = V; h->num_betas = num_betas; h->n_extra = n_extra; h->n_picked = n_picked; h->n_out = n_out;
+  h->n_tiles = (V + TILE_V - 1) / TILE_V;
+  h->Vpad = h->n_tiles * TILE_V;
+
+  // tree levels
+  std::vector<int32_t> level(NJ, 0);
+  int n_levels = 1;
+  for (int j = 0; j < NJ; ++j) {
+    if (parents[j] >= 0) {
+      GLAMR_REQUIRE(parents[j] < j, "parents must be topologically ordered");
+      level[j] = level[parents[j]] + 1;
+    }
+    n_levels = std::max(n_levels, level[j] + 1);
+  }
+  h->n_levels = n_levels;
+
+  // which extra-regressed joints does the joint map reference?
+  std::vector<int32_t> extra_slot(MAX_EXTRA, -1);
+  int n_used = 0;
+  for (int i = 0; i < n_out; ++i) {
+    const int src = joint_map[i];
+    GLAMR_REQUIRE(src >= 0 && src < NJ + n_picked + n_extra, "joint_map[%d]=%d out of range", i, src);
+    if (src >= NJ + n_picked && extra_slot[src - NJ - n_picked] < 0) extra_slot[src - NJ - n_picked] = n_used++;
+  }
+  h->n_extra_used = n_used;
+  GLAMR_REQUIRE(n_used == 0 || J_regressor_extra, "joint_map references extra joints but J_regressor_extra is null");
+
+  // direction matrix, tiled: [tile][plane][row][KSTRIDE]; k: 0..9 shapedirs, 10..216 posedirs, 217 v_template
+  std::vector<float> dirs((size_t)h->n_tiles * 3 * TILE_V * KSTRIDE, 0.0f);
+  for (int v = 0; v < V; ++v) {
+    const int tile = v / TILE_V, row = v % TILE_V;
+    for (int r = 0; r < 3; ++r) {
+      float* d = &dirs[(((size_t)tile * 3 + r) * TILE_V + row) * KSTRIDE];
+      for (int l = 0; l < num_betas; ++l) d[l] = shapedirs[((size_t)v * 3 + r) * num_betas + l];
+      for (int k = 0; k < 207; ++k) d[10 + k] = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + r];
+      d[K_ONE] = v_template[(size_t)v * 3 + r];
+    }
+  }
+  std::vector<float> w((size_t)h->Vpad * NJ, 0.0f);
+  for (int v = 0; v < V; ++v) for (int j = 0; j < NJ; ++j) w[(size_t)v * NJ + j] = lbs_weights[(size_t)v * NJ + j];
+  std::vector<float> jx((size_t)std::max(1, n_used) * h->Vpad, 0.0f);
+  for (int e = 0; e < n_extra; ++e)
+    if (extra_slot[e] >= 0)
+      for (int v = 0; v < V; ++v) jx[(size_t)extra_slot[e] * h->Vpad + v] = J_regressor_extra[(size_t)e * V + v];
+  // rest joints and their shape derivatives (J = J_regressor (v_template + shapedirs beta) is linear in beta)
+  std::vector<float> jt(NJ * 3), js((size_t)NJ * 3 * num_betas);
+  for (int j = 0; j < NJ; ++j)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0.0;
+      for (int v = 0; v < V; ++v) s += (double)J_regressor[(size_t)j * V + v] * v_template[(size_t)v * 3 + c];
+      jt[j * 3 + c] = (float)s;
+      for (int l = 0; l < num_betas; ++l) {
+        double q = 0.0;
+        for (int v = 0; v < V; ++v) q += (double)J_regressor[(size_t)j * V + v] * shapedirs[((size_t)v * 3 + c) * num_betas + l];
+        js[((size_t)j * 3 + c) * num_betas + l] = (float)q;
+      }
+    }
+  // picked vertices sorted by tile (CSR)
+  std::vector<int32_t> pick_row(std::max(1, n_picked)), tstart(h->n_tiles + 1, 0), tids(std::max(1, n_picked));
+  for (int p = 0; p < n_picked; ++p) {
+    GLAMR_REQUIRE(extra_vertex_ids[p] >= 0 && extra_vertex_ids[p] < V, "extra_vertex_ids[%d] out of range", p);
+    pick_row[p] = extra_vertex_ids[p] % TILE_V;
+    tstart[extra_vertex_ids[p] / TILE_V + 1]++;
+  }
+  for (int t = 0; t < h->n_tiles; ++t) tstart[t + 1] += tstart[t];
+  {
+    std::vector<int32_t> cur(tstart.begin(), tstart.end() - 1);
+    for (int p = 0; p < n_picked; ++p) tids[cur[extra_vertex_ids[p] / TILE_V]++] = p;
+  }
+
+  int rc;
+  if ((rc = upload(&h->dirs_tiled, dirs.data(), dirs.size()))) return rc;
+  if ((rc = upload(&h->w_tiled, w.data(), w.size()))) return rc;
+  if ((rc = upload(&h->jx_used, jx.data(), jx.size()))) return rc;
+  if ((rc = upload(&h->j_template, jt.data(), jt.size()))) return rc;
+  if ((rc = upload(&h->j_shapedirs, js.data(), js.size()))) return rc;
+  if ((rc = upload(&h->parents, parents, (size_t)NJ))) return rc;
+  if ((rc = upload(&h->level, level.data(), level.size()))) return rc;
+  if ((rc = upload(&h->joint_map, joint_map, (size_t)n_out))) return rc;
+  if ((rc = upload(&h->extra_slot, extra_slot.data(), extra_slot.size()))) return rc;
+  if ((rc = upload(&h->pick_row, pick_row.data(), pick_row.size()))) return rc;
+  if ((rc = upload(&h->tile_pick_start, tstart.data(), tstart.size()))) return rc;
+  if ((rc = upload(&h->tile_pick_ids, tids.data(), tids.size()))) return rc;
+  *out = h;
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_smpl_destroy(glamr_smpl* h) {
+  if (!h) return GLAMR_OK;
+  void* ptrs[] = {h->dirs_tiled, h->w_tiled, h->jx_used, h->j_template, h->j_shapedirs, h->parents, h->level, h->joint_map,
+                  h->extra_slot, h->pick_row, h->tile_pick_start, h->tile_pick_ids};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete h;
+  return GLAMR_OK;
+}
+
+namespace {
+struct SmplWs { float *feat, *askin, *chain, *picked, *partial, *pivot; size_t total; int Bpad; };
+SmplWs smpl_ws_layout(const glamr_smpl* h, int B, char* base) {
+  SmplWs w{};
+  w.Bpad = (B + TILE_F - 1) / TILE_F * TILE_F;
+  size_t off = 0;
+  auto take = [&](size_t nfloats) { float* p = reinterpret_cast<float*>(base + off); off = align_up(off + nfloats * sizeof(float), 256); return p; };
+  w.feat = take((size_t)w.Bpad * KTOT);
+  w.askin = take((size_t)w.Bpad * 12 * NJ);
+  w.chain = take((size_t)w.Bpad * NJ * 3);
+  w.picked = take((size_t)w.Bpad * std::max(1, h->n_picked) * 3);
+  w.partial = take((size_t)h->n_tiles * w.Bpad * std::max(1, h->n_extra_used) * 3);
+  w.pivot = take((size_t)w.Bpad * 3);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t glamr_smpl_workspace_bytes(const glamr_smpl* h, int B) {
+  if (!h || B <= 0) return 0;
+  return smpl_ws_layout(h, B, nullptr).total;
+}
+
+extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const float* betas, const float* root_trans,
+                                  const float* root_scale, float* verts, float* joints, int flags, void* workspace, void* stream_) {
+  GLAMR_REQUIRE(h && pose && betas && joints && workspace, "null argument");
+  GLAMR_REQUIRE(B > 0, "B must be positive");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SmplWs w = smpl_ws_layout(h, B, static_cast<char*>(workspace));
+  // rows [B, Bpad) of feat/askin are read by the padded MFMA tiles: keep them finite
+  if (w.Bpad > B) {
+    GLAMR_HIP_CHECK(hipMemsetAsync(w.feat + (size_t)B * KTOT, 0, (size_t)(w.Bpad - B) * KTOT * sizeof(float), stream));
+    GLAMR_HIP_CHECK(hipMemsetAsync(w.askin + (size_t)B * 12 * NJ, 0, (size_t)(w.Bpad - B) * 12 * NJ * sizeof(float), stream));
+  }
+  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, w.askin, w.chain};
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
+  LbsArgs la{B, h->V, h->n_tiles, w.Bpad / TILE_F, h->n_extra_used, h->n_picked, h->dirs_tiled, h->w_tiled, h->jx_used,
+             h->tile_pick_start, h->tile_pick_ids, h->pick_row, w.feat, w.askin, verts, w.picked, w.partial, w.Bpad};
+  const size_t lds = (size_t)(3 * TILE_V * KSTRIDE + (verts ? 4 * TILE_F * OUT_STRIDE : 0)) * sizeof(float);
+  auto launch = [&](auto kern) -> int {
+    GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(h->n_tiles), dim3(256), lds, stream, la);
+    return GLAMR_OK;
+  };
+  int rc = GLAMR_OK;
+  switch (h->n_extra_used) {
+    case 0: rc = launch(smpl_lbs_kernel<0>); break;
+    case 1: rc = launch(smpl_lbs_kernel<1>); break;
+    case 2: rc = launch(smpl_lbs_kernel<2>); break;
+    case 3: rc = launch(smpl_lbs_kernel<3>); break;
+    case 4: rc = launch(smpl_lbs_kernel<4>); break;
+    default: return fail(GLAMR_E_UNSUPPORTED, "joint_map references %d extra-regressed joints (max 4 supported)", h->n_extra_used);
+  }
+  if (rc) return rc;
+  FinishArgs fa{B, w.Bpad, h->n_tiles, h->n_extra_used, h->n_picked, h->n_out, (flags & GLAMR_SMPL_ORIG_JOINTS) ? 1 : 0,
+                w.chain, w.picked, w.partial, h->joint_map, h->extra_slot, root_trans, root_scale, joints, w.pivot};
+  hipLaunchKernelGGL(smpl_finish_kernel, dim3(B), dim3(64), 0, stream, fa);
+  if (verts && root_trans)
+    hipLaunchKernelGGL(smpl_anchor_kernel, dim3(8, B), dim3(256), 0, stream, B, h->V, w.pivot, root_trans, root_scale, verts);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_smpl_fk(glamr_smpl* h, int B, const float* pose, const float* root_trans, const float* root_scale,
+                             float* joints, void* stream_) {
+  GLAMR_REQUIRE(h && pose && joints, "null argument");
+  GLAMR_REQUIRE(B > 0, "B must be positive");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PrepArgs pa{B, h->num_betas, h->n_levels, 0, pose, nullptr, h->j_template, h->j_shapedirs, h->parents, h->level, nullptr, nullptr, joints};
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
+  if (root_trans) hipLaunchKernelGGL(smpl_fk_anchor_kernel, dim3(B), dim3(NJ), 0, stream, B, root_trans, root_scale, joints);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_smpl_backward_root(glamr_smpl* h, int B, const float* pose, const float* root_trans, const float* root_scale,
+                                        const float* verts, const float* joints, const float* g_verts, const float* g_joints,
+                                        float* g_orient, float* g_trans, float* g_scale, int flags, void* stream_) {
+  GLAMR_REQUIRE(h && pose && g_orient, "null argument");
+  GLAMR_REQUIRE(root_trans, "backward_root needs the re-anchored forward (root_trans != NULL): without it the rotation pivot "
+                            "(the shaped root joint) is not recoverable from the outputs");
+  GLAMR_REQUIRE((!g_verts || verts) && (!g_joints || joints), "gradient given without the matching forward output");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  BwdArgs ba{B, h->V, (flags & GLAMR_SMPL_ORIG_JOINTS) ? NJ : h->n_out, pose, root_trans, root_scale, verts, joints, g_verts, g_joints,
+             g_orient, g_trans, g_scale};
+  hipLaunchKernelGGL(smpl_backward_root_kernel, dim3(B), dim3(256), 0, stream, ba);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}

@@ -1,0 +1,201 @@
+/* libglamr_hip.so -- C ABI of the MI355X-native GLAMR global-reconstruction hot path.
+ *
+ * The reference (NVlabs/GLAMR) has no FFI layer: its hot path is Python calling PyTorch.  The entry points
+ * below are what a binding for that path binds instead; each names the reference interface it replaces (paths relative to
+ * the reference tree).  Conventions:
+ *   - every function returns 0 on success or a negative GLAMR_E_* code; glamr_last_error() gives the thread-local message;
+ *     nothing throws across the ABI and nothing calls exit();
+ *   - pointers marked `dev` are device (HBM) addresses owned by the caller (the PyTorch caching allocator in the Python
+ *     host); pointers marked `host` are host addresses read during the call only;
+ *   - all work is enqueued on the caller's stream (`hipStream_t` passed as void*), no hidden synchronisation unless the
+ *     function says so; handles are re-entrant per handle, one process per GPU;
+ *   - fp32 everywhere; quaternions (w,x,y,z); matrices row-major.
+ */
+#ifndef GLAMR_HIP_H
+#define GLAMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLAMR_OK 0
+#define GLAMR_E_INVALID (-1)   /* bad argument */
+#define GLAMR_E_HIP (-2)       /* HIP runtime error (message has the hipError string) */
+#define GLAMR_E_NOMEM (-3)
+#define GLAMR_E_UNSUPPORTED (-4)
+
+int glamr_version(void);                 /* 100*major + minor */
+const char* glamr_last_error(void);      /* thread-local, valid until the next failing call on this thread */
+int glamr_device_info(int* cu_count, int* gfx_major_minor, size_t* hbm_bytes);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * SMPL body model -- replaces lib/models/smpl.py:274-343 (`SMPL.__init__/forward/get_joints`) and the third-party
+ * smplx.lbs.lbs / batch_rodrigues / batch_rigid_transform / vertices2joints it calls (lib/models/smpl.py:7-8,295,299).
+ * ------------------------------------------------------------------------------------------------------------------- */
+typedef struct glamr_smpl glamr_smpl;
+
+/* Uploads and re-tiles the model constants.  All arrays `host`, fp32 / int32:
+ *   v_template (V,3)  shapedirs (V,3,num_betas)  posedirs (207, V*3) [smplx layout: pose-feature major]
+ *   J_regressor (24,V)  lbs_weights (V,24)  J_regressor_extra (n_extra,V)  parents (24; parents[0] = -1)
+ *   extra_vertex_ids (n_picked)  -- vertices smplx appends as joints 24..24+n_picked-1
+ *   joint_map (n_out) -- indices into [24 chain | n_picked vertices | n_extra regressed]  (smpl.py:284-287,300-301) */
+int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const float* v_template, const float* shapedirs,
+                      const float* posedirs, const float* J_regressor, const float* lbs_weights,
+                      const float* J_regressor_extra, int n_extra, const int32_t* parents,
+                      const int32_t* extra_vertex_ids, int n_picked, const int32_t* joint_map, int n_out);
+int glamr_smpl_destroy(glamr_smpl* h);
+/* Bytes of device scratch glamr_smpl_forward needs for a batch of B frames (caller allocates, any 256-B aligned buffer). */
+size_t glamr_smpl_workspace_bytes(const glamr_smpl* h, int B);
+
+#define GLAMR_SMPL_ORIG_JOINTS 1   /* joints = the 24 chain joints (smpl.py:296-297), n_out is ignored */
+
+/* SMPL.forward (smpl.py:289-316).  dev in: pose (B,72) = [global_orient | body_pose] axis-angle, betas (B,num_betas),
+ * root_trans (B,3) or NULL (no re-anchoring), root_scale (B) or NULL (=1).  dev out: verts (B,V,3) or NULL (skips the
+ * vertex write-out entirely), joints (B,n_out,3).  workspace: glamr_smpl_workspace_bytes(h,B) bytes. */
+int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const float* betas, const float* root_trans,
+                       const float* root_scale, float* verts, float* joints, int flags, void* workspace, void* stream);
+
+/* SMPL.get_joints (smpl.py:318-343): forward kinematics of the 24 chain joints from the UNSHAPED template.
+ * dev in: pose (B,72); root_trans/root_scale as above.  dev out: joints (B,24,3). */
+int glamr_smpl_fk(glamr_smpl* h, int B, const float* pose, const float* root_trans, const float* root_scale,
+                  float* joints, void* stream);
+
+/* Backward of glamr_smpl_forward w.r.t. global_orient, root_trans and root_scale only (the quantities the optimiser
+ * differentiates, global_recon_model.py:517-524 with get_parameter :591-633).  Uses the rigid identity
+ * out = s * R(global_orient) * (x_local - pivot_local) + t  (SURVEY.md App. B step 8), so only the forward OUTPUTS are needed.
+ * dev in: pose (B,72), root_trans, root_scale (may be NULL), verts/joints = forward outputs, g_verts (B,V,3) or NULL,
+ * g_joints (B,n_out,3) or NULL.  dev out: g_orient (B,3), g_trans (B,3) or NULL, g_scale (B) or NULL. */
+int glamr_smpl_backward_root(glamr_smpl* h, int B, const float* pose, const float* root_trans, const float* root_scale,
+                             const float* verts, const float* joints, const float* g_verts, const float* g_joints,
+                             float* g_orient, float* g_trans, float* g_scale, int flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Motion priors -- replace MotionInfillerVAE.inference (motion_infiller/models/motion_infiller_vae.py:618-667),
+ * TrajPredVAE.inference (traj_pred/models/traj_pred_vae.py:524-548) and MotionTrajJointModel.inference
+ * (motion_infiller/models/motion_traj_joint_model.py:141-145).  Declared in round 1, see glamr_nets.h section below.
+ * ------------------------------------------------------------------------------------------------------------------- */
+typedef struct glamr_nets glamr_nets;
+
+/* Weights are handed over as ONE packed fp32 host blob plus a table of (offset, rows, cols) per tensor, in the order of
+ * the checkpoint layout (glamr_amd/models/layouts.py == state_dict order of the reference modules). */
+typedef struct glamr_tensor_desc { int64_t offset; int32_t rows; int32_t cols; } glamr_tensor_desc;
+
+int glamr_nets_create(glamr_nets** out, const float* infiller_blob, const glamr_tensor_desc* infiller_desc, int n_infiller,
+                      const float* trajpred_blob, const glamr_tensor_desc* trajpred_desc, int n_trajpred,
+                      const float* fk_rest_joints /* host (24,3): J_regressor @ v_template */, const int32_t* parents);
+int glamr_nets_destroy(glamr_nets* h);
+size_t glamr_nets_workspace_bytes(const glamr_nets* h, int n_seq, int max_len);
+
+/* Batched infiller + trajectory predictor over n_seq independent sequences (one "person" each).
+ * dev in : body_pose (n_seq, max_len, 69) zero outside each sequence's [0,len) and on invisible frames
+ *          (global_recon_model.py:146-147,357); visible (n_seq, max_len) 1/0; lens (n_seq) int32 host;
+ *          motion_eps (n_seq, n_win_max, 128), traj_eps (n_seq, 128) -- the Gaussian draws of lib/utils/dist.py:21-23.
+ * dev out: out_pose (n_seq, max_len, 69)   = infer_out_body_pose
+ *          out_local_traj (n_seq, max_len, 11) = infer_out_local_traj_tp (time-major in the reference)
+ *          out_trans (n_seq, max_len, 3), out_orient (n_seq, max_len, 3) = infer_out_trans / infer_out_orient. */
+int glamr_nets_infer(glamr_nets* h, int n_seq, int max_len, const int32_t* lens, const float* body_pose,
+                     const float* visible, const float* motion_eps, int n_win_max, const float* traj_eps,
+                     float* out_pose, float* out_local_traj, float* out_trans, float* out_orient,
+                     void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Fused global optimiser -- replaces GlobalReconOptimizer.forward/compute_loss/optimize_main
+ * (global_recon/models/global_recon_model.py:394-570) and the residuals of global_recon/models/loss_func.py.
+ * One launch runs ALL iterations of one stage for a batch of scenes; each scene (a sequence with P persons sharing a
+ * camera) is owned by one workgroup, so iterations need no grid-wide synchronisation.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* optimisation variables (opt_variables in global_recon/cfg/ *.yml; get_parameter :591-633) */
+#define GLAMR_VAR_CAM (1u << 0)
+#define GLAMR_VAR_LOCAL_XY (1u << 1)
+#define GLAMR_VAR_LOCAL_HEADING (1u << 2)
+#define GLAMR_VAR_WORLD_DHEADING (1u << 3)
+#define GLAMR_VAR_LOCAL_DXY (1u << 4)
+#define GLAMR_VAR_LOCAL_ROT (1u << 5)
+#define GLAMR_VAR_LOCAL_Z (1u << 6)
+#define GLAMR_VAR_LOCAL_DHEADING (1u << 7)
+
+/* model flags (grecon_model_specs) */
+#define GLAMR_FLAG_FIXED_CAM (1u << 0)             /* flag_fixed_cam */
+#define GLAMR_FLAG_CAM_FROM_PERSON (1u << 1)       /* flag_opt_cam_from_person_pose */
+#define GLAMR_FLAG_HAS_WORLD_DHEADING (1u << 2)    /* a previous stage created pose_dict['world_dheading'] (:624-627) */
+
+/* loss ids (loss_func_dict, loss_func.py:314-340) -- order of glamr_stage_desc.loss_weight[] */
+enum {
+  GLAMR_LOSS_KP_2D = 0, GLAMR_LOSS_KP_2D_DIST, GLAMR_LOSS_REL_TRANSFORM, GLAMR_LOSS_CAM_TRAJ_ROT,
+  GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS, GLAMR_LOSS_LOCAL_DXY_REG, GLAMR_LOSS_LOCAL_DHEADING_REG_NEW, GLAMR_LOSS_LOCAL_ROT_REG,
+  GLAMR_LOSS_LOCAL_Z_REG, GLAMR_LOSS_CAM_INV_TRANS_RES_REG, GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS,
+  GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS, GLAMR_LOSS_CAM_UP_REG, GLAMR_NUM_LOSSES
+};
+
+typedef struct glamr_stage_desc {
+  uint32_t var_mask;                     /* GLAMR_VAR_* */
+  uint32_t flags;                        /* GLAMR_FLAG_* */
+  uint32_t loss_mask;                    /* bit i set: loss i is in the stage's loss_cfg */
+  uint32_t monitor_mask;                 /* bit i set: monitor_only (reported, not optimised; compute_loss :540-542) */
+  uint32_t first_frame_only_mask;        /* per-loss `first_frame_only` */
+  int32_t niters;                        /* opt_niters */
+  float lr;                              /* opt_lr; Adam betas (0.9, 0.999), eps 1e-8 (:642) */
+  float loss_weight[16];
+  float kp_min_conf;                     /* kp_2d / kp_2d_dist `min_conf` */
+  float first_frame_weight[16];          /* per-loss `first_frame_weight` (rel_transform default 10, others 1) */
+  float rel_trans_weight;                /* rel_transform `trans_weight` */
+} glamr_stage_desc;
+
+/* Geometry of the packed scene batch.  All per-frame arrays are padded to max_len frames; person p of scene s lives at
+ * slot s*max_persons + p. */
+typedef struct glamr_scene_batch {
+  int32_t n_scenes, max_persons, max_len, n_joints;   /* n_joints = 26 */
+  /* host, int32 */
+  const int32_t* n_persons;              /* (n_scenes) */
+  /* dev, int32 per person slot */
+  const int32_t* fr_start;               /* first existing frame  (exist_frames = [fr_start, fr_end), :92-95) */
+  const int32_t* fr_end;
+  /* dev, fp32 constants (never written) */
+  const float* vis;                      /* (slots, max_len) 1 = vis_frames (post filter_pose) */
+  const float* j_local;                  /* (slots, max_len, n_joints, 3): joints for zero root orient, pivot-relative   */
+  const float* kp_2d;                    /* (slots, max_len, n_joints, 2) kp_2d_aligned */
+  const float* kp_score;                 /* (slots, max_len, n_joints)   kp_2d_score */
+  const float* cam_K;                    /* (slots, max_len, 4) fx fy cx cy  -- general 3x3 not needed by any caller */
+  const float* traj_local_pred;          /* (slots, max_len, 11) rows [0, exist_len) */
+  const float* orient_cam;               /* (slots, max_len, 3) smpl_orient_cam (HybrIK, interpolated) */
+  const float* base_orient;              /* (slots, max_len, 3) smpl_orient_world_base outside exist_frames */
+  const float* base_trans;               /* (slots, max_len, 3) root_trans_world_base outside exist_frames */
+  const float* person2cam;               /* (slots, max_len, 12) 3x4 */
+  const float* rel_transform_cam;        /* (n_scenes, max_persons, max_persons, max_len, 12) or NULL */
+  /* dev, fp32 state (read and written) */
+  float* cam_pose;                       /* (n_scenes, max_len, 12) world->camera 3x4; in: current, out: final */
+  float* params;                         /* packed optimisation variables, layout from glamr_grecon_param_layout() */
+  float* losses;                         /* (n_scenes, GLAMR_NUM_LOSSES) unweighted values of the LAST iteration */
+  /* dev outputs of the last forward pass */
+  float* orient_world;                   /* (slots, max_len, 3) */
+  float* trans_world;                    /* (slots, max_len, 3) */
+  float* kp_2d_pred;                     /* (slots, max_len, n_joints, 2) */
+  float* orient_cam_in_world;            /* (slots, max_len, 3) */
+} glamr_scene_batch;
+
+/* Offsets (in floats) of each variable block inside one scene's parameter vector; see glamr_grecon_param_layout(). */
+typedef struct glamr_param_layout {
+  int32_t scene_stride;                  /* floats per scene */
+  int32_t cam_rot6d, cam_trans;          /* (max_len,6) (max_len,3); fixed camera uses row 0 only */
+  int32_t cam_inv_rot_res, cam_inv_trans_res;   /* (max_len,6) (max_len,3) */
+  int32_t person_stride, person0;        /* person p block at person0 + p*person_stride */
+  int32_t local_xy, local_dxy, local_heading, local_dheading, local_z, local_rot, world_dheading;  /* within a person block */
+} glamr_param_layout;
+
+int glamr_grecon_param_layout(int max_persons, int max_len, glamr_param_layout* out);
+size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len);
+
+/* Runs stage->niters Adam iterations (fresh zero moments, :635-644) on every scene of the batch.  With niters == 0 it
+ * performs one forward pass + loss evaluation without touching the parameters (forward(data, [], {'stage':'init'}) :246).
+ * If `grads_out` (dev, n_scenes*scene_stride) is non-NULL the gradient of the LAST evaluated iteration is stored there. */
+int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out,
+                           void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLAMR_HIP_H */
