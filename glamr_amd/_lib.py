@@ -20,13 +20,11 @@ class StageDesc(Structure):
 
 
 class SceneBatch(Structure):
-    _fields_ = [('n_scenes', c_int32), ('max_persons', c_int32), ('max_len', c_int32), ('n_joints', c_int32),
-                ('n_persons', c_void_p), ('fr_start', c_void_p), ('fr_end', c_void_p),
-                ('vis', c_void_p), ('j_local', c_void_p), ('kp_2d', c_void_p), ('kp_score', c_void_p), ('cam_K', c_void_p),
-                ('traj_local_pred', c_void_p), ('orient_cam', c_void_p), ('base_orient', c_void_p), ('base_trans', c_void_p),
-                ('person2cam', c_void_p), ('rel_transform_cam', c_void_p),
-                ('cam_pose', c_void_p), ('params', c_void_p), ('losses', c_void_p),
-                ('orient_world', c_void_p), ('trans_world', c_void_p), ('kp_2d_pred', c_void_p), ('orient_cam_in_world', c_void_p)]
+    _fields_ = [('n_scenes', c_int32), ('max_persons', c_int32), ('max_len', c_int32), ('n_joints', c_int32)] + \
+               [(n, c_void_p) for n in ('n_persons', 'seq_len', 'fr_start', 'fr_end', 'vis', 'j_local', 'kp_2d', 'kp_score', 'cam_K',
+                                        'traj_local_pred', 'orient_cam', 'base_orient', 'base_trans', 'person2cam', 'dheading_mask',
+                                        'rel_transform_cam', 'cam_pose', 'params', 'losses', 'orient_world', 'trans_world',
+                                        'kp_2d_pred', 'orient_cam_in_world')]
 
 
 class ParamLayout(Structure):
@@ -66,6 +64,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libglamr_hip.so is not built (%s missing): run `python -m glamr_amd.build` or '
                                '`python -c "import __graft_entry__ as g; g.build()"`.  There is no CPU fallback.' % LIB_PATH)
+        # torch ships its own libamdhip64; it must be mapped first so this library binds to the SAME HIP runtime instance
+        # (two runtimes in one process cannot both own the device)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)

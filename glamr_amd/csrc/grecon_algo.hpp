@@ -1,0 +1,946 @@
+// One scene of GLAMR's global optimisation: forward residuals, hand-written reverse pass and Adam, for all iterations of a stage.
+//
+// Replaces GlobalReconOptimizer.forward / get_pred_trajectory_base / compute_loss / optimize_main
+// (global_recon/models/global_recon_model.py:394-570) and the residuals in global_recon/models/loss_func.py for every branch
+// the shipped configs reach.  The SMPL call inside the loop is replaced by the rigid
+// identity  joints = R_smplx(orient_world) * j_local + trans_world  with j_local cached once per sequence (App. B step 8).
+//
+// The algorithm is written against a tiny "block runtime" RT (thread id, barrier, block reduction, block prefix sum) so the
+// same source is instantiated by the gfx950 kernel (grecon.hip: one workgroup per scene, threads over frames) and by the
+// single-threaded host runtime the CPU test-suite uses to check gradients without a GPU (tests/hostsim).  Every loop over
+// frames is `for (t = rt.tid(); t < T; t += rt.nthreads())`; phases are separated by rt.sync().
+//
+// Per-frame dataflow (person p, existing frames e in [0,n), video frames t in [0,T)):
+//   A  L[e] = prior[e] + deltas;  dtheta[e] = atan2s(L.sin, L.cos)                    -> scan  theta = cumsum(dtheta)
+//   B  d[e] = Rot2D(theta[e-1]) L[e].xy                                             -> scan  xy = cumsum(d)
+//   C  q = hq(theta) * R2q(6d->R(L.rot)) * base;  orient_base = q2aa(q);  world_dheading;  d6 = aa2R_k(orient_world)[:, :2]
+//   D  camera (own 6D/trans parameters | averaged from persons + residuals | constant)
+//   E  cam-frame orientation, joints, projection, all residuals and their per-frame gradients (neighbours read, own written)
+//   G  camera gradients -> camera parameters (Adam) or back into the persons' transforms
+//   H  reverse of C;  suffix scans of g_xy and g_theta reverse B and A;  Adam on every trajectory variable.
+#pragma once
+#include "rotmath.hpp"
+#include "../../include/glamr_hip.h"
+
+namespace glamr {
+namespace grecon {
+
+constexpr int NJ = 26;
+constexpr float FPS = 30.0f;
+
+struct PersonConst {
+  int fr_start, fr_end;               // exist_frames = [fr_start, fr_end)
+  const float* vis;                   // [T]
+  int* vis_rank;                      // [T] index among visible frames, -1 if invisible (filled by setup_tables)
+  const float* j_local;               // [T][NJ][3]
+  const float* kp_2d;                 // [T][NJ][2]
+  const float* kp_score;              // [T][NJ]
+  const float* cam_K;                 // [T][9]
+  const float* prior;                 // [T][11] traj_local_pred, rows [0,n)
+  const float* orient_cam;            // [T][3]
+  const float* base_orient;           // [T][3]
+  const float* base_trans;            // [T][3]
+  const float* person2cam;            // [T][12]
+  const float* dheading_mask;         // [T] (row e, e >= 1) or null = all zero
+};
+
+struct PersonState {
+  float* p;                           // parameter block of this person (glamr_param_layout offsets)
+  float* m; float* v; float* g;       // Adam moments, gradient (same layout)
+  float* theta; float* xy;            // [T], [T][2] scan buffers
+  float* d6;                          // [T][6]
+  float* orient_world; float* trans_world;  // [T][3] outputs
+  float* g_ow; float* g_tw;           // [T][3]
+  float* g_theta; float* g_xy;        // [T], [T][2]
+  float* kp_2d_pred; float* orient_cam_in_world;   // outputs
+  float* kp_wsum;                     // [NJ] sum over visible frames of thresholded score^2
+};
+
+struct Scene {
+  int P, T;
+  const glamr_param_layout* lay;
+  const glamr_stage_desc* st;
+  PersonConst pc[8];
+  PersonState ps[8];
+  const float* rel_cam;               // [P][P][T][12] or null
+  int* pair_first;                    // [8][8] first co-visible frame or -1 (setup_tables)
+  int* fill_src;                      // [T] frame whose averaged camera a frame without persons inherits (:493-498)
+  int* n_vis_persons;                 // [T] fr_num_persons
+  float* cam_pose;                    // [T][12]  in/out
+  float* cam_inv;                     // [T][12]  scratch
+  float* g_cam; float* g_caminv;      // [T][12]
+  float* g_avg;                       // [T][12] (cam-from-person)
+  float* cp; float* cm; float* cv; float* cg;   // scene-level parameter block (camera), moments, gradient
+  float* losses;                      // [GLAMR_NUM_LOSSES]
+  int store_grad;
+  int rel_stride_p, rel_stride_t;     // padded person count / frame count of rel_cam
+};
+
+// ---- small helpers ---------------------------------------------------------------------------------------------------
+
+GLAMR_HD float gmof(float x, float sigma2) { return sigma2 * x * x / (sigma2 + x * x); }
+GLAMR_HD float gmof_d(float x, float sigma2) { const float d = sigma2 + x * x; return 2.0f * sigma2 * sigma2 * x / (d * d); }
+
+struct AdamCoef { float lr_t; float bc2_sqrt; };   // lr / (1 - beta1^t),  sqrt(1 - beta2^t)
+
+// torch.optim.Adam single-tensor update (betas 0.9/0.999, eps 1e-8, no weight decay)
+GLAMR_HD void adam(float& p, float& m, float& v, float g, const AdamCoef& c) {
+  m = m + (g - m) * (1.0f - 0.9f);
+  v = v * 0.999f + (1.0f - 0.999f) * g * g;
+  const float denom = sqrtf(v) / c.bc2_sqrt + 1e-8f;
+  p = p - c.lr_t * (m / denom);
+}
+
+GLAMR_HD void invert34(const float M[12], float O[12]) {       // [R|t] -> [R^T | -R^T t]   (inverse_transform)
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) O[i * 4 + j] = M[j * 4 + i];
+    O[i * 4 + 3] = -(M[0 * 4 + 3] * M[0 * 4 + i] + M[1 * 4 + 3] * M[1 * 4 + i] + M[2 * 4 + 3] * M[2 * 4 + i]);
+  }
+}
+// O = invert(M):  gM += d(O)/d(M)^T gO
+GLAMR_HD void invert34_bwd(const float M[12], const float gO[12], float gM[12]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) gM[j * 4 + i] += gO[i * 4 + j];
+  for (int i = 0; i < 3; ++i) {            // O_i3 = -sum_k t_k R_ki
+    const float g = gO[i * 4 + 3];
+    for (int k = 0; k < 3; ++k) {
+      gM[k * 4 + 3] += -g * M[k * 4 + i];
+      gM[k * 4 + i] += -g * M[k * 4 + 3];
+    }
+  }
+}
+GLAMR_HD void get_R(const float M[12], float R[9]) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i * 3 + j] = M[i * 4 + j]; }
+// C = A B for 3x4 rigid transforms (implicit last row 0 0 0 1)
+GLAMR_HD void mul34(const float A[12], const float B[12], float C[12]) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) C[i * 4 + j] = A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j] + A[i * 4 + 2] * B[2 * 4 + j];
+    C[i * 4 + 3] += A[i * 4 + 3];
+  }
+}
+GLAMR_HD void mul34_bwd(const float A[12], const float B[12], const float gC[12], float* gA, float* gB) {
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k) {
+      if (gA) { float s = 0.f; for (int j = 0; j < 4; ++j) s += gC[i * 4 + j] * B[k * 4 + j]; gA[i * 4 + k] += s; }
+    }
+  if (gA) for (int i = 0; i < 3; ++i) gA[i * 4 + 3] += gC[i * 4 + 3];
+  if (gB)
+    for (int k = 0; k < 3; ++k)
+      for (int j = 0; j < 4; ++j) { float s = 0.f; for (int i = 0; i < 3; ++i) s += A[i * 4 + k] * gC[i * 4 + j]; gB[k * 4 + j] += s; }
+}
+
+// person trajectory row L[e] from the prior and the optimisation deltas (get_pred_trajectory_base :394-419)
+struct LocalRow { float dx, dy, z, r6[6], h; };   // h = heading angle after adding the delta; (cos h, sin h) replaces cols 9,10
+template <class S>
+GLAMR_HD LocalRow local_row(const S& sc, int p, int e) {
+  const PersonConst& c = sc.pc[p];
+  const float* pr = c.prior + (size_t)e * 11;
+  const float* P = sc.ps[p].p;
+  const glamr_param_layout& l = *sc.lay;
+  LocalRow L;
+  if (e == 0) {
+    L.dx = pr[0] + P[l.local_xy + 0];
+    L.dy = pr[1] + P[l.local_xy + 1];
+    L.h = rm::atan2s(pr[10], pr[9]) + P[l.local_heading];
+  } else {
+    L.dx = pr[0] + P[l.local_dxy + e * 2 + 0];
+    L.dy = pr[1] + P[l.local_dxy + e * 2 + 1];
+    L.h = rm::atan2s(pr[10], pr[9]) + (c.dheading_mask ? P[l.local_dheading + e] * c.dheading_mask[e] : 0.0f);
+  }
+  L.z = pr[2] + P[l.local_z + e];
+  for (int k = 0; k < 6; ++k) L.r6[k] = pr[3 + k] + P[l.local_rot + e * 6 + k];
+  return L;
+}
+
+// orientation chain of frame e: q = hq(theta) (x) R2q(6d->R(r6)) (x) base ; aa = q2aa(q)
+struct OrientFwd { float hq[4], lq[4], q1[4], q[4], aa[3]; float R6[9]; };
+GLAMR_HD void orient_base_fwd(float theta, const float r6[6], OrientFwd& o) {
+  const float base[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+  rm::heading_quat(theta, o.hq);
+  rm::rot6d_to_rotmat(r6, o.R6);
+  rm::rotmat_to_quat(o.R6, o.lq);
+  rm::quat_mul(o.hq, o.lq, o.q1);
+  rm::quat_mul(o.q1, base, o.q);
+  rm::quat_to_aa(o.q, o.aa);
+}
+GLAMR_HD void orient_base_bwd(float theta, const float r6[6], const OrientFwd& o, const float gaa[3], float& gtheta, float gr6[6]) {
+  const float base[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+  float gq[4] = {0, 0, 0, 0}, gq1[4] = {0, 0, 0, 0}, ghq[4] = {0, 0, 0, 0}, glq[4] = {0, 0, 0, 0}, gR[9] = {0};
+  rm::quat_to_aa_bwd(o.q, gaa, gq);
+  rm::quat_mul_bwd(o.q1, base, gq, gq1, nullptr);
+  rm::quat_mul_bwd(o.hq, o.lq, gq1, ghq, glq);
+  gtheta += rm::heading_quat_bwd(theta, ghq);
+  rm::rotmat_to_quat_bwd(o.R6, glq, gR);
+  rm::rot6d_to_rotmat_bwd(r6, gR, gr6);
+}
+
+// world heading offset: ow = q2aa( aa2q((0,0,w)) (x) aa2q(ob) )   (:459-465)
+struct WorldFwd { float wq[4], bq[4], q[4]; };
+GLAMR_HD void world_dheading_fwd(float w, const float ob[3], WorldFwd& f, float ow[3]) {
+  rm::heading_quat(w, f.wq);
+  rm::aa_to_quat(ob, f.bq);
+  rm::quat_mul(f.wq, f.bq, f.q);
+  rm::quat_to_aa(f.q, ow);
+}
+GLAMR_HD void world_dheading_bwd(float w, const float ob[3], const WorldFwd& f, const float gow[3], float& gw, float gob[3]) {
+  float gq[4] = {0, 0, 0, 0}, gwq[4] = {0, 0, 0, 0}, gbq[4] = {0, 0, 0, 0};
+  rm::quat_to_aa_bwd(f.q, gow, gq);
+  rm::quat_mul_bwd(f.wq, f.bq, gq, gwq, gbq);
+  gw += rm::heading_quat_bwd(w, gwq);
+  rm::aa_to_quat_bwd(ob, gbq, gob);
+}
+
+
+// ---- layout of the parameter vector and of the per-scene workspace ------------------------------------------------------
+
+GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) {
+  const int T = max_len;
+  l.cam_rot6d = 0;
+  l.cam_trans = l.cam_rot6d + 6 * T;
+  l.cam_inv_rot_res = l.cam_trans + 3 * T;
+  l.cam_inv_trans_res = l.cam_inv_rot_res + 6 * T;
+  l.person0 = l.cam_inv_trans_res + 3 * T;
+  l.local_xy = 0;
+  l.local_heading = 2;
+  l.local_dxy = 4;
+  l.local_dheading = l.local_dxy + 2 * T;
+  l.local_z = l.local_dheading + T;
+  l.local_rot = l.local_z + T;
+  l.world_dheading = l.local_rot + 6 * T;
+  l.person_stride = l.world_dheading + T;
+  l.scene_stride = l.person0 + max_persons * l.person_stride;
+}
+
+GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
+  glamr_param_layout l;
+  param_layout(max_persons, max_len, l);
+  const size_t T = (size_t)max_len;
+  size_t n = 3 * (size_t)l.person0 + 4 * 12 * T + 2 * T + 64;                       // cm cv cg | cam_inv g_cam g_caminv g_avg | fill_src n_vis | pair_first
+  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 6 + 3 + 3 + 1 + 2 + 1) * T + 32);   // m v g | theta xy d6 g_ow g_tw g_theta g_xy vis_rank | kp_wsum
+  return n;
+}
+
+// Binds scene `si` of the batch to pointers (no computation).  `ws` = this scene's workspace slice.
+GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layout& l, const glamr_stage_desc* st, int si,
+                             int n_persons, int seq_len, float* ws, float* grads_out, Scene& sc) {
+  const size_t TM = (size_t)b.max_len;
+  sc.P = n_persons; sc.T = seq_len; sc.lay = &l; sc.st = st;
+  sc.rel_cam = b.rel_transform_cam ? b.rel_transform_cam + (size_t)si * b.max_persons * b.max_persons * TM * 12 : nullptr;
+  sc.cam_pose = b.cam_pose + (size_t)si * TM * 12;
+  sc.cp = b.params + (size_t)si * l.scene_stride;
+  sc.losses = b.losses + (size_t)si * GLAMR_NUM_LOSSES;
+  sc.store_grad = grads_out != nullptr;
+  float* w = ws;
+  auto take = [&](size_t n) { float* r = w; w += n; return r; };
+  sc.cm = take(l.person0); sc.cv = take(l.person0);
+  float* cg_ws = take(l.person0);
+  sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : cg_ws;
+  sc.cam_inv = take(12 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
+  sc.fill_src = reinterpret_cast<int*>(take(TM)); sc.n_vis_persons = reinterpret_cast<int*>(take(TM));
+  sc.pair_first = reinterpret_cast<int*>(take(64));
+  for (int p = 0; p < b.max_persons; ++p) {
+    const size_t slot = (size_t)si * b.max_persons + p;
+    PersonConst& c = sc.pc[p];
+    PersonState& s = sc.ps[p];
+    s.p = sc.cp + l.person0 + (size_t)p * l.person_stride;
+    s.m = take(l.person_stride); s.v = take(l.person_stride);
+    float* g_ws = take(l.person_stride);
+    s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
+    s.theta = take(TM); s.xy = take(2 * TM); s.d6 = take(6 * TM); s.g_ow = take(3 * TM); s.g_tw = take(3 * TM);
+    s.g_theta = take(TM); s.g_xy = take(2 * TM);
+    c.vis_rank = reinterpret_cast<int*>(take(TM));
+    s.kp_wsum = take(32);
+    c.fr_start = b.fr_start[slot]; c.fr_end = b.fr_end[slot];
+    c.vis = b.vis + slot * TM;
+    c.j_local = b.j_local + slot * TM * NJ * 3;
+    c.kp_2d = b.kp_2d + slot * TM * NJ * 2;
+    c.kp_score = b.kp_score + slot * TM * NJ;
+    c.cam_K = b.cam_K + slot * TM * 9;
+    c.prior = b.traj_local_pred + slot * TM * 11;
+    c.orient_cam = b.orient_cam + slot * TM * 3;
+    c.base_orient = b.base_orient + slot * TM * 3;
+    c.base_trans = b.base_trans + slot * TM * 3;
+    c.person2cam = b.person2cam + slot * TM * 12;
+    c.dheading_mask = b.dheading_mask ? b.dheading_mask + slot * TM : nullptr;
+    s.orient_world = b.orient_world + slot * TM * 3;
+    s.trans_world = b.trans_world + slot * TM * 3;
+    s.kp_2d_pred = b.kp_2d_pred + slot * TM * NJ * 2;
+    s.orient_cam_in_world = b.orient_cam_in_world + slot * TM * 3;
+  }
+  // rel_transform_cam is indexed with the padded person count
+  sc.rel_stride_p = b.max_persons;
+  sc.rel_stride_t = (int)TM;
+}
+
+// Integer tables derived from the visibility masks; once per stage.
+template <class RT>
+GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
+  const int T = sc.T, P = sc.P;
+  for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    int n = 0;
+    for (int p = 0; p < P; ++p) n += sc.pc[p].vis[t] != 0.f ? 1 : 0;
+    sc.n_vis_persons[t] = n;
+  }
+  for (int p = 0; p < P; ++p)
+    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      int r = -1;
+      if (sc.pc[p].vis[t] != 0.f) { r = 0; for (int u = 0; u < t; ++u) r += sc.pc[p].vis[u] != 0.f ? 1 : 0; }
+      sc.pc[p].vis_rank[t] = r;
+    }
+  for (int i = rt.tid(); i < P * P; i += rt.nthreads()) {
+    const int a = i / P, b = i % P;
+    int first = -1;
+    for (int t = 0; t < T && first < 0; ++t) if (sc.pc[a].vis[t] != 0.f && sc.pc[b].vis[t] != 0.f) first = t;
+    sc.pair_first[a * 8 + b] = first;
+  }
+  rt.sync();
+  for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    int src = t;
+    while (src >= 0 && sc.n_vis_persons[src] == 0) --src;
+    if (src < 0) { src = 0; while (src < T - 1 && sc.n_vis_persons[src] == 0) ++src; }
+    sc.fill_src[t] = src;
+  }
+  rt.sync();
+}
+
+// ---- the per-scene driver --------------------------------------------------------------------------------------------
+
+template <class RT>
+GLAMR_HD void run_scene(RT& rt, Scene& sc) {
+  const glamr_stage_desc& st = *sc.st;
+  const glamr_param_layout& l = *sc.lay;
+  const int T = sc.T, P = sc.P;
+  const bool var_cam = st.var_mask & GLAMR_VAR_CAM;
+  const bool fixed_cam = st.flags & GLAMR_FLAG_FIXED_CAM;
+  const bool cam_from_person = !var_cam && (st.flags & GLAMR_FLAG_CAM_FROM_PERSON);
+  const bool has_wd = (st.flags & GLAMR_FLAG_HAS_WORLD_DHEADING) || (st.var_mask & GLAMR_VAR_WORLD_DHEADING);
+  auto on = [&](int id) { return (st.loss_mask >> id) & 1u; };
+  auto active = [&](int id) { return ((st.loss_mask >> id) & 1u) && !((st.monitor_mask >> id) & 1u); };
+  auto ffo = [&](int id) { return (st.first_frame_only_mask >> id) & 1u; };
+
+  setup_tables(rt, sc);
+  // ---- stage setup: normalisers, Adam state, camera parameters from the current camera (get_parameter :596-606) ----------
+  float n_vis_total = 0.f, n_exist = 0.f, n_exist_m1 = 0.f;
+  for (int p = 0; p < P; ++p) {
+    float c = 0.f;
+    for (int t = rt.tid(); t < T; t += rt.nthreads()) c += sc.pc[p].vis[t];
+    n_vis_total += rt.reduce_sum(c);
+    const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+    n_exist += (float)n;
+    n_exist_m1 += (float)(n - 1);
+  }
+  for (int i = rt.tid(); i < l.person0; i += rt.nthreads()) { sc.cm[i] = 0.f; sc.cv[i] = 0.f; sc.cg[i] = 0.f; }
+  for (int p = 0; p < P; ++p)
+    for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) { sc.ps[p].m[i] = 0.f; sc.ps[p].v[i] = 0.f; sc.ps[p].g[i] = 0.f; }
+  if (var_cam) {
+    const int rows = fixed_cam ? 1 : T;
+    for (int t = rt.tid(); t < rows; t += rt.nthreads()) {
+      const float* M = sc.cam_pose + (size_t)t * 12;
+      for (int r = 0; r < 3; ++r) {
+        sc.cp[l.cam_rot6d + t * 6 + r] = M[r * 4 + 0];
+        sc.cp[l.cam_rot6d + t * 6 + 3 + r] = M[r * 4 + 1];
+        sc.cp[l.cam_trans + t * 3 + r] = M[r * 4 + 3];
+      }
+    }
+  }
+  // per-joint sum over visible frames of thresholded score^2 (first_frame_only broadcasting of kp_2d, loss_func.py:27-33)
+  for (int p = 0; p < P; ++p)
+    for (int j = 0; j < NJ; ++j) {
+      float c = 0.f;
+      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+        const float sj = sc.pc[p].kp_score[(size_t)t * NJ + j];
+        if (sc.pc[p].vis[t] != 0.f && sj >= st.kp_min_conf) c += sj * sj;
+      }
+      c = rt.reduce_sum(c);
+      if (rt.tid() == 0) sc.ps[p].kp_wsum[j] = c;
+    }
+  rt.sync();
+
+  const int niters = st.niters;
+  double b1p = 1.0, b2p = 1.0;
+  const int n_eval = niters > 0 ? niters : 1;
+  for (int it = 0; it < n_eval; ++it) {
+    const bool last = (it == n_eval - 1);
+    const bool update = niters > 0;
+    b1p *= 0.9; b2p *= 0.999;
+    AdamCoef ac;
+    ac.lr_t = (float)((double)st.lr / (1.0 - b1p));
+    ac.bc2_sqrt = (float)sqrt(1.0 - b2p);
+    float lsum[GLAMR_NUM_LOSSES];
+    for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) lsum[i] = 0.f;
+    float kp_dist_cnt = 0.f;
+
+    // ---- A: heading increments ---------------------------------------------------------------------------------------
+    for (int p = 0; p < P; ++p) {
+      const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+      for (int e = rt.tid(); e < n; e += rt.nthreads()) {
+        const LocalRow L = local_row(sc, p, e);
+        sc.ps[p].theta[e] = rm::atan2s(sinf(L.h), cosf(L.h));
+      }
+    }
+    rt.sync();
+    for (int p = 0; p < P; ++p) rt.scan(sc.ps[p].theta, sc.pc[p].fr_end - sc.pc[p].fr_start, 1, false);
+    // ---- B: planar displacement in world axes -------------------------------------------------------------------------
+    for (int p = 0; p < P; ++p) {
+      const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+      for (int e = rt.tid(); e < n; e += rt.nthreads()) {
+        const LocalRow L = local_row(sc, p, e);
+        float dx = L.dx, dy = L.dy;
+        if (e > 0) {
+          const float th = sc.ps[p].theta[e - 1];
+          const float c = cosf(th), s = sinf(th);
+          dx = L.dx * c - L.dy * s;
+          dy = L.dx * s + L.dy * c;
+        }
+        sc.ps[p].xy[e * 2 + 0] = dx;
+        sc.ps[p].xy[e * 2 + 1] = dy;
+      }
+    }
+    rt.sync();
+    for (int p = 0; p < P; ++p) {
+      rt.scan(sc.ps[p].xy, sc.pc[p].fr_end - sc.pc[p].fr_start, 2, false);
+      rt.scan(sc.ps[p].xy + 1, sc.pc[p].fr_end - sc.pc[p].fr_start, 2, false);
+    }
+    // ---- C: world orientation / translation ---------------------------------------------------------------------------
+    for (int p = 0; p < P; ++p) {
+      const PersonConst& c = sc.pc[p];
+      PersonState& s = sc.ps[p];
+      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+        float ob[3], tb[3];
+        if (t >= c.fr_start && t < c.fr_end) {
+          const int e = t - c.fr_start;
+          const LocalRow L = local_row(sc, p, e);
+          OrientFwd o;
+          orient_base_fwd(s.theta[e], L.r6, o);
+          for (int k = 0; k < 3; ++k) ob[k] = o.aa[k];
+          tb[0] = s.xy[e * 2 + 0]; tb[1] = s.xy[e * 2 + 1]; tb[2] = L.z;
+        } else {
+          for (int k = 0; k < 3; ++k) { ob[k] = c.base_orient[t * 3 + k]; tb[k] = c.base_trans[t * 3 + k]; }
+        }
+        float ow[3] = {ob[0], ob[1], ob[2]};
+        if (has_wd) { WorldFwd wf; world_dheading_fwd(s.p[l.world_dheading + t], ob, wf, ow); }
+        float Rk[9];
+        rm::aa_to_rotmat_k(ow, Rk);
+        for (int k = 0; k < 3; ++k) {
+          s.orient_world[t * 3 + k] = ow[k];
+          s.trans_world[t * 3 + k] = tb[k];
+          s.g_ow[t * 3 + k] = 0.f;
+          s.g_tw[t * 3 + k] = 0.f;
+          s.d6[t * 6 + k] = Rk[k * 3 + 0];
+          s.d6[t * 6 + 3 + k] = Rk[k * 3 + 1];
+        }
+      }
+    }
+    rt.sync();
+    // ---- D: camera ------------------------------------------------------------------------------------------------------
+    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      float M[12], Mi[12];
+      if (var_cam) {
+        const int row = fixed_cam ? 0 : t;
+        float R[9];
+        rm::rot6d_to_rotmat(sc.cp + l.cam_rot6d + row * 6, R);
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sc.cp[l.cam_trans + row * 3 + i]; }
+        invert34(M, Mi);
+      } else if (cam_from_person) {
+        const int src = sc.fill_src[t];
+        float avg[12];
+        for (int k = 0; k < 12; ++k) avg[k] = 0.f;
+        for (int p = 0; p < P; ++p) {
+          if (sc.pc[p].vis[src] == 0.f) continue;
+          float Tw[12], Rk[9], C[12];
+          rm::aa_to_rotmat_k(sc.ps[p].orient_world + src * 3, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].trans_world[src * 3 + i]; }
+          mul34(Tw, sc.pc[p].person2cam + (size_t)src * 12, C);
+          for (int k = 0; k < 12; ++k) avg[k] += C[k];
+        }
+        const float inv_n = 1.0f / (float)sc.n_vis_persons[src];
+        for (int k = 0; k < 12; ++k) avg[k] = avg[k] * inv_n;   // sum(...) / num_persons  (:492)
+        float r6[6];
+        for (int r = 0; r < 3; ++r) { r6[r] = avg[r * 4 + 0]; r6[3 + r] = avg[r * 4 + 1]; }
+        if (sc.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) r6[k] += sc.cp[l.cam_inv_rot_res + t * 6 + k];
+        float R[9];
+        rm::rot6d_to_rotmat(r6, R);
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sc.cp[l.cam_inv_trans_res + t * 3 + i]; }
+        invert34(Mi, M);
+      } else {
+        for (int k = 0; k < 12; ++k) M[k] = sc.cam_pose[(size_t)t * 12 + k];
+        invert34(M, Mi);
+      }
+      for (int k = 0; k < 12; ++k) {
+        sc.cam_pose[(size_t)t * 12 + k] = M[k];
+        sc.cam_inv[(size_t)t * 12 + k] = Mi[k];
+      }
+    }
+    rt.sync();
+    // ---- E: residuals and per-frame gradients -----------------------------------------------------------------------------
+    const float w_kp = active(GLAMR_LOSS_KP_2D) ? st.loss_weight[GLAMR_LOSS_KP_2D] / n_vis_total : 0.f;
+    const float n_ctr = ffo(GLAMR_LOSS_CAM_TRAJ_ROT) ? (float)P : n_vis_total;
+    const float w_ctr = active(GLAMR_LOSS_CAM_TRAJ_ROT) ? st.loss_weight[GLAMR_LOSS_CAM_TRAJ_ROT] / n_ctr : 0.f;
+    const float n_trs = (float)(P * (T - 1));
+    const float w_trs = active(GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS) ? st.loss_weight[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] / n_trs : 0.f;
+    const float w_crs = active(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS) ? st.loss_weight[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] / (float)(T - 1) : 0.f;
+    const float w_cos = active(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS) ? st.loss_weight[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] / (float)(T - 1) : 0.f;
+    const float n_up = ffo(GLAMR_LOSS_CAM_UP_REG) ? 1.0f : (float)T;
+    const float w_up = active(GLAMR_LOSS_CAM_UP_REG) ? st.loss_weight[GLAMR_LOSS_CAM_UP_REG] / n_up : 0.f;
+    const float n_rel = (float)(P * (P - 1) * T);
+    const float w_rel = (active(GLAMR_LOSS_REL_TRANSFORM) && P > 1) ? st.loss_weight[GLAMR_LOSS_REL_TRANSFORM] / n_rel : 0.f;
+    const float min_conf = st.kp_min_conf;
+
+    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      float gC[12], gCi[12];
+      for (int k = 0; k < 12; ++k) { gC[k] = 0.f; gCi[k] = 0.f; }
+      const float* M = sc.cam_pose + (size_t)t * 12;
+      const float* Mi = sc.cam_inv + (size_t)t * 12;
+      float Rc[9];
+      get_R(M, Rc);
+      for (int p = 0; p < P; ++p) {
+        const PersonConst& c = sc.pc[p];
+        PersonState& s = sc.ps[p];
+        const float* ow = s.orient_world + t * 3;
+        const float* tw = s.trans_world + t * 3;
+        float g_ow[3] = {0, 0, 0}, g_tw[3] = {0, 0, 0};
+        float gRk[9];
+        for (int k = 0; k < 9; ++k) gRk[k] = 0.f;
+        float Rk[9];
+        rm::aa_to_rotmat_k(ow, Rk);
+        const bool visible = c.vis[t] != 0.f;
+        // orientation seen from the camera: transform_rot(cam_pose, orient_world)  (:512)
+        float Mk[9], ociw[3];
+        rm::mat3_mul(Rc, Rk, Mk);
+        rm::rotmat_to_aa(Mk, ociw);
+        if (last) for (int k = 0; k < 3; ++k) s.orient_cam_in_world[t * 3 + k] = ociw[k];
+        if (on(GLAMR_LOSS_CAM_TRAJ_ROT) && visible && (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) || c.vis_rank[t] == 0)) {
+          float Ra[9], Rb[9];
+          rm::aa_to_rotmat_k(ociw, Ra);
+          rm::aa_to_rotmat_k(c.orient_cam + t * 3, Rb);
+          const float fw = (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) && c.vis_rank[t] == 0) ? st.first_frame_weight[GLAMR_LOSS_CAM_TRAJ_ROT] : 1.0f;
+          float gRa[9];
+          for (int k = 0; k < 9; ++k) gRa[k] = 0.f;
+          for (int r = 0; r < 3; ++r)
+            for (int col = 0; col < 2; ++col) {
+              const float d = (Rb[r * 3 + col] - Ra[r * 3 + col]) * fw;
+              lsum[GLAMR_LOSS_CAM_TRAJ_ROT] += d * d;
+              gRa[r * 3 + col] = -2.0f * d * fw * w_ctr;
+            }
+          if (w_ctr != 0.f) {
+            float g_oc[3] = {0, 0, 0}, gMk[9];
+            for (int k = 0; k < 9; ++k) gMk[k] = 0.f;
+            rm::aa_to_rotmat_k_bwd(ociw, gRa, g_oc);
+            rm::rotmat_to_aa_bwd(Mk, g_oc, gMk);
+            float gRc[9];
+            for (int k = 0; k < 9; ++k) gRc[k] = 0.f;
+            rm::mat3_mul_bwd(Rc, Rk, gMk, gRc, gRk);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gC[i * 4 + j] += gRc[i * 3 + j];
+          }
+        }
+        // joints, projection, 2-D keypoint residual  (:517-528, loss_func.py:15-57)
+        const bool kp_first = ffo(GLAMR_LOSS_KP_2D);
+        const bool need_kp = last || (w_kp != 0.f && visible && (!kp_first || c.vis_rank[t] == 0));
+        if (need_kp) {
+          float Rs[9];
+          rm::aa_to_rotmat_s(ow, Rs);
+          float gRs[9];
+          for (int k = 0; k < 9; ++k) gRs[k] = 0.f;
+          const float* K = c.cam_K + (size_t)t * 9;
+          const float rank_w = (c.vis_rank[t] >= 0 && c.vis_rank[t] < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
+          const bool kp_frame = visible && (!kp_first || c.vis_rank[t] == 0);
+          for (int j = 0; j < NJ; ++j) {
+            const float* jl = c.j_local + ((size_t)t * NJ + j) * 3;
+            float J[3], X[3];
+            rm::mat3_vec(Rs, jl, J);
+            for (int k = 0; k < 3; ++k) J[k] += tw[k];
+            rm::mat3_vec(Rc, J, X);
+            for (int k = 0; k < 3; ++k) X[k] += M[k * 4 + 3];
+            const float hx = K[0] * X[0] + K[1] * X[1] + K[2] * X[2];
+            const float hy = K[3] * X[0] + K[4] * X[1] + K[5] * X[2];
+            const float hz = K[6] * X[0] + K[7] * X[1] + K[8] * X[2] + 1e-8f;
+            const float u = hx / hz, v = hy / hz;
+            if (last) { s.kp_2d_pred[((size_t)t * NJ + j) * 2 + 0] = u; s.kp_2d_pred[((size_t)t * NJ + j) * 2 + 1] = v; }
+            const float du = u - c.kp_2d[((size_t)t * NJ + j) * 2 + 0], dv = v - c.kp_2d[((size_t)t * NJ + j) * 2 + 1];
+            const float sc_raw = c.kp_score[(size_t)t * NJ + j];
+            if (last && on(GLAMR_LOSS_KP_2D_DIST) && sc_raw > min_conf && (!ffo(GLAMR_LOSS_KP_2D_DIST) || t == 0)) {
+              lsum[GLAMR_LOSS_KP_2D_DIST] += sqrtf(du * du + dv * dv);
+              kp_dist_cnt += 1.0f;
+            }
+            if (!kp_frame || !on(GLAMR_LOSS_KP_2D)) continue;
+            // weight of this residual: score^2 (thresholded); with first_frame_only the first visible frame's residual is
+            // multiplied by the sum of score^2 over ALL visible frames (broadcast quirk)
+            float wj;
+            if (kp_first) wj = s.kp_wsum[j] * rank_w;
+            else { const float scj = sc_raw < min_conf ? 0.f : sc_raw; wj = scj * scj * rank_w; }
+            lsum[GLAMR_LOSS_KP_2D] += (gmof(du, 1e4f) + gmof(dv, 1e4f)) * wj;
+            if (w_kp == 0.f || wj == 0.f) continue;
+            const float gu = gmof_d(du, 1e4f) * wj * w_kp, gv = gmof_d(dv, 1e4f) * wj * w_kp;
+            // u = hx / hz, v = hy / hz
+            const float ghx = gu / hz, ghy = gv / hz, ghz = -(gu * u + gv * v) / hz;
+            float gX[3];
+            for (int k = 0; k < 3; ++k) gX[k] = K[k] * ghx + K[3 + k] * ghy + K[6 + k] * ghz;
+            for (int i = 0; i < 3; ++i) {
+              for (int k = 0; k < 3; ++k) gC[i * 4 + k] += gX[i] * J[k];
+              gC[i * 4 + 3] += gX[i];
+            }
+            float gJ[3];
+            rm::mat3T_vec(Rc, gX, gJ);
+            for (int i = 0; i < 3; ++i) {
+              g_tw[i] += gJ[i];
+              for (int k = 0; k < 3; ++k) gRs[i * 3 + k] += gJ[i] * jl[k];
+            }
+          }
+          if (w_kp != 0.f && kp_frame) rm::aa_to_rotmat_s_bwd(ow, gRs, g_ow);
+        }
+        // smoothness of the world orientation in 6D  (loss_func.py:117-132)
+        if (on(GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS)) {
+          const float* d0 = s.d6 + t * 6;
+          float gd6[6] = {0, 0, 0, 0, 0, 0};
+          if (t + 1 < T) for (int k = 0; k < 6; ++k) { const float v = (s.d6[(t + 1) * 6 + k] - d0[k]) * FPS; lsum[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] += v * v; gd6[k] -= 2.0f * FPS * v * w_trs; }
+          if (t > 0) for (int k = 0; k < 6; ++k) { const float v = (d0[k] - s.d6[(t - 1) * 6 + k]) * FPS; gd6[k] += 2.0f * FPS * v * w_trs; }
+          for (int r = 0; r < 3; ++r) { gRk[r * 3 + 0] += gd6[r]; gRk[r * 3 + 1] += gd6[3 + r]; }
+        }
+        // relative transform between persons on co-visible frames  (loss_func.py:248-271)
+        if (on(GLAMR_LOSS_REL_TRANSFORM) && P > 1 && visible) {
+          float Ti[12];
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Ti[i * 4 + j] = Rk[i * 3 + j]; Ti[i * 4 + 3] = tw[i]; }
+          float Tiinv[12];
+          invert34(Ti, Tiinv);
+          float gTi[12];
+          for (int k = 0; k < 12; ++k) gTi[k] = 0.f;
+          for (int o = 0; o < P; ++o) {
+            if (o == p || sc.pc[o].vis[t] == 0.f) continue;
+            float To[12], Ro[9];
+            rm::aa_to_rotmat_k(sc.ps[o].orient_world + t * 3, Ro);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = sc.ps[o].trans_world[t * 3 + i]; }
+            float Toinv[12];
+            invert34(To, Toinv);
+            // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
+            for (int dir = 0; dir < 2; ++dir) {
+              const int a = dir == 0 ? p : o, b = dir == 0 ? o : p;
+              const float* target = sc.rel_cam + (((size_t)a * sc.rel_stride_p + b) * sc.rel_stride_t + t) * 12;
+              const float fw = (sc.pair_first[a * 8 + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
+              float rel[12];
+              if (dir == 0) mul34(Tiinv, To, rel); else mul34(Toinv, Ti, rel);
+              float grel[12];
+              for (int k = 0; k < 12; ++k) grel[k] = 0.f;
+              for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 2; ++j) {
+                  const float d = (target[i * 4 + j] - rel[i * 4 + j]) * fw;
+                  if (dir == 0) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d;
+                  grel[i * 4 + j] = -2.0f * d * fw * w_rel;
+                }
+                const float d = (target[i * 4 + 3] - rel[i * 4 + 3]) * fw;
+                if (dir == 0) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d * st.rel_trans_weight;
+                grel[i * 4 + 3] = -2.0f * d * fw * w_rel * st.rel_trans_weight;
+              }
+              if (w_rel == 0.f) continue;
+              if (dir == 0) {
+                float gInv[12];
+                for (int k = 0; k < 12; ++k) gInv[k] = 0.f;
+                mul34_bwd(Tiinv, To, grel, gInv, nullptr);
+                invert34_bwd(Ti, gInv, gTi);
+              } else {
+                mul34_bwd(Toinv, Ti, grel, nullptr, gTi);
+              }
+            }
+          }
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) gRk[i * 3 + j] += gTi[i * 4 + j]; g_tw[i] += gTi[i * 4 + 3]; }
+        }
+        rm::aa_to_rotmat_k_bwd(ow, gRk, g_ow);
+        for (int k = 0; k < 3; ++k) { s.g_ow[t * 3 + k] += g_ow[k]; s.g_tw[t * 3 + k] += g_tw[k]; }
+      }
+      // camera-only terms on the camera-to-world transform  (loss_func.py:76-114)
+      if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) {
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 2; ++j) {
+            if (t + 1 < T) { const float v = (Mi[i * 4 + j] - sc.cam_inv[(size_t)(t + 1) * 12 + i * 4 + j]) * FPS; lsum[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] += v * v; gCi[i * 4 + j] += 2.0f * FPS * v * w_crs; }
+            if (t > 0) { const float v = (sc.cam_inv[(size_t)(t - 1) * 12 + i * 4 + j] - Mi[i * 4 + j]) * FPS; gCi[i * 4 + j] -= 2.0f * FPS * v * w_crs; }
+          }
+      }
+      if (on(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS)) {
+        for (int i = 0; i < 3; ++i) {
+          if (t + 1 < T) { const float v = (sc.cam_inv[(size_t)(t + 1) * 12 + i * 4 + 3] - Mi[i * 4 + 3]) * FPS; lsum[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] += v * v; gCi[i * 4 + 3] -= 2.0f * FPS * v * w_cos; }
+          if (t > 0) { const float v = (Mi[i * 4 + 3] - sc.cam_inv[(size_t)(t - 1) * 12 + i * 4 + 3]) * FPS; gCi[i * 4 + 3] += 2.0f * FPS * v * w_cos; }
+        }
+      }
+      if (on(GLAMR_LOSS_CAM_UP_REG) && (!ffo(GLAMR_LOSS_CAM_UP_REG) || t == 0)) {
+        const float fw = t < 10 ? st.first_frame_weight[GLAMR_LOSS_CAM_UP_REG] : 1.0f;
+        lsum[GLAMR_LOSS_CAM_UP_REG] += Mi[2 * 4 + 1] * fw;
+        gCi[2 * 4 + 1] += fw * w_up;
+      }
+      for (int k = 0; k < 12; ++k) { sc.g_cam[(size_t)t * 12 + k] = gC[k]; sc.g_caminv[(size_t)t * 12 + k] = gCi[k]; }
+    }
+    rt.sync();
+    // ---- G: camera gradients ------------------------------------------------------------------------------------------------
+    if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
+      for (int t = rt.tid(); t < T; t += rt.nthreads())
+        for (int k = 0; k < 3; ++k) { const float r = sc.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
+    if (update && var_cam) {
+      float gfix[9];
+      for (int k = 0; k < 9; ++k) gfix[k] = 0.f;
+      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+        const int row = fixed_cam ? 0 : t;
+        float gM[12];
+        for (int k = 0; k < 12; ++k) gM[k] = sc.g_cam[(size_t)t * 12 + k];
+        invert34_bwd(sc.cam_pose + (size_t)t * 12, sc.g_caminv + (size_t)t * 12, gM);
+        float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
+        get_R(gM, gR);
+        rm::rot6d_to_rotmat_bwd(sc.cp + l.cam_rot6d + row * 6, gR, g6);
+        if (fixed_cam) {
+          for (int k = 0; k < 6; ++k) gfix[k] += g6[k];
+          for (int k = 0; k < 3; ++k) gfix[6 + k] += gM[k * 4 + 3];
+        } else {
+          for (int k = 0; k < 6; ++k) {
+            const int i = l.cam_rot6d + t * 6 + k;
+            if (sc.store_grad) sc.cg[i] = g6[k];
+            adam(sc.cp[i], sc.cm[i], sc.cv[i], g6[k], ac);
+          }
+          for (int k = 0; k < 3; ++k) {
+            const int i = l.cam_trans + t * 3 + k;
+            if (sc.store_grad) sc.cg[i] = gM[k * 4 + 3];
+            adam(sc.cp[i], sc.cm[i], sc.cv[i], gM[k * 4 + 3], ac);
+          }
+        }
+      }
+      if (fixed_cam) {
+        for (int k = 0; k < 9; ++k) gfix[k] = rt.reduce_sum(gfix[k]);
+        if (rt.tid() == 0) {
+          for (int k = 0; k < 6; ++k) { const int i = l.cam_rot6d + k; if (sc.store_grad) sc.cg[i] = gfix[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[k], ac); }
+          for (int k = 0; k < 3; ++k) { const int i = l.cam_trans + k; if (sc.store_grad) sc.cg[i] = gfix[6 + k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[6 + k], ac); }
+        }
+      }
+    } else if (update && cam_from_person) {
+      // gradient of the averaged camera-to-world transform of every frame, then folded onto its source frame
+      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+        float gMi[12];
+        for (int k = 0; k < 12; ++k) gMi[k] = sc.g_caminv[(size_t)t * 12 + k];
+        invert34_bwd(sc.cam_inv + (size_t)t * 12, sc.g_cam + (size_t)t * 12, gMi);     // cam_pose = invert(cam_inv)
+        // cam_inv = [6d->R(r6) | avg_t + res]; r6 = avg cols (+ res on empty frames)
+        const int src = sc.fill_src[t];
+        float avg6[6];
+        {
+          // recompute r6 of this frame
+          float avg[12];
+          for (int k = 0; k < 12; ++k) avg[k] = 0.f;
+          for (int p = 0; p < P; ++p) {
+            if (sc.pc[p].vis[src] == 0.f) continue;
+            float Tw[12], Rk[9], C[12];
+            rm::aa_to_rotmat_k(sc.ps[p].orient_world + src * 3, Rk);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].trans_world[src * 3 + i]; }
+            mul34(Tw, sc.pc[p].person2cam + (size_t)src * 12, C);
+            for (int k = 0; k < 12; ++k) avg[k] += C[k];
+          }
+          const float inv_n = 1.0f / (float)sc.n_vis_persons[src];
+          for (int r = 0; r < 3; ++r) { avg6[r] = avg[r * 4 + 0] * inv_n; avg6[3 + r] = avg[r * 4 + 1] * inv_n; }
+          if (sc.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) avg6[k] += sc.cp[l.cam_inv_rot_res + t * 6 + k];
+        }
+        float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
+        get_R(gMi, gR);
+        rm::rot6d_to_rotmat_bwd(avg6, gR, g6);
+        float* ga = sc.g_avg + (size_t)t * 12;
+        for (int r = 0; r < 3; ++r) { ga[r * 4 + 0] = g6[r]; ga[r * 4 + 1] = g6[3 + r]; ga[r * 4 + 2] = 0.f; ga[r * 4 + 3] = gMi[r * 4 + 3]; }
+        // residual parameters
+        float g_tres[3] = {gMi[3], gMi[7], gMi[11]};
+        if (active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
+          const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
+          for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sc.cp[l.cam_inv_trans_res + t * 3 + k] * wreg;
+        }
+        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k; if (sc.store_grad) sc.cg[i] = g_tres[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], g_tres[k], ac); }
+        if (sc.n_vis_persons[t] == 0)
+          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k; if (sc.store_grad) sc.cg[i] = g6[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], g6[k], ac); }
+      }
+      rt.sync();
+      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+        if (sc.n_vis_persons[t] == 0) continue;                 // only frames with persons are sources
+        float ga[12];
+        for (int k = 0; k < 12; ++k) ga[k] = 0.f;
+        // frames filled from t: t itself, the run of empty frames after it, and (for the first source) the leading run
+        for (int u = 0; u < T; ++u) {
+          if (sc.fill_src[u] != t) continue;
+          for (int k = 0; k < 12; ++k) ga[k] += sc.g_avg[(size_t)u * 12 + k];
+        }
+        const float inv_n = 1.0f / (float)sc.n_vis_persons[t];
+        for (int k = 0; k < 12; ++k) ga[k] *= inv_n;
+        for (int p = 0; p < P; ++p) {
+          if (sc.pc[p].vis[t] == 0.f) continue;
+          float Tw[12], Rk[9], gTw[12];
+          for (int k = 0; k < 12; ++k) gTw[k] = 0.f;
+          rm::aa_to_rotmat_k(sc.ps[p].orient_world + t * 3, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].trans_world[t * 3 + i]; }
+          mul34_bwd(Tw, sc.pc[p].person2cam + (size_t)t * 12, ga, gTw, nullptr);
+          float gRk[9], g_ow[3] = {0, 0, 0};
+          get_R(gTw, gRk);
+          rm::aa_to_rotmat_k_bwd(sc.ps[p].orient_world + t * 3, gRk, g_ow);
+          for (int k = 0; k < 3; ++k) { sc.ps[p].g_ow[t * 3 + k] += g_ow[k]; sc.ps[p].g_tw[t * 3 + k] += gTw[k * 4 + 3]; }
+        }
+      }
+      rt.sync();
+    } else if (update && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
+      // camera neither optimised nor derived from the persons: the residual only feels its own regulariser
+      const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
+      for (int t = rt.tid(); t < T; t += rt.nthreads())
+        for (int k = 0; k < 3; ++k) {
+          const int i = l.cam_inv_trans_res + t * 3 + k;
+          const float g = 2.0f * FPS * FPS * sc.cp[i] * wreg;
+          if (sc.store_grad) sc.cg[i] = g;
+          adam(sc.cp[i], sc.cm[i], sc.cv[i], g, ac);
+        }
+    }
+    // ---- H: reverse of the orientation chain; direct parameter gradients ----------------------------------------------------
+    const float w_rot = active(GLAMR_LOSS_LOCAL_ROT_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_ROT_REG] / n_exist : 0.f;
+    const float w_z = active(GLAMR_LOSS_LOCAL_Z_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_Z_REG] / n_exist : 0.f;
+    const float w_dxy = active(GLAMR_LOSS_LOCAL_DXY_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_DXY_REG] / n_exist_m1 : 0.f;
+    const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
+    for (int p = 0; p < P; ++p) {
+      const PersonConst& c = sc.pc[p];
+      PersonState& s = sc.ps[p];
+      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+        const bool ex = t >= c.fr_start && t < c.fr_end;
+        const int e = t - c.fr_start;
+        float ob[3];
+        LocalRow L;
+        OrientFwd o;
+        if (ex) {
+          L = local_row(sc, p, e);
+          orient_base_fwd(s.theta[e], L.r6, o);
+          for (int k = 0; k < 3; ++k) ob[k] = o.aa[k];
+        } else {
+          for (int k = 0; k < 3; ++k) ob[k] = c.base_orient[t * 3 + k];
+        }
+        float g_ob[3] = {s.g_ow[t * 3 + 0], s.g_ow[t * 3 + 1], s.g_ow[t * 3 + 2]};
+        if (has_wd) {
+          WorldFwd wf;
+          float ow[3], gw = 0.f;
+          world_dheading_fwd(s.p[l.world_dheading + t], ob, wf, ow);
+          float g_in[3] = {g_ob[0], g_ob[1], g_ob[2]};
+          g_ob[0] = g_ob[1] = g_ob[2] = 0.f;
+          world_dheading_bwd(s.p[l.world_dheading + t], ob, wf, g_in, gw, g_ob);
+          if (update && (st.var_mask & GLAMR_VAR_WORLD_DHEADING)) {
+            const int i = l.world_dheading + t;
+            if (sc.store_grad) s.g[i] = gw;
+            adam(s.p[i], s.m[i], s.v[i], gw, ac);
+          }
+        }
+        if (!ex) continue;
+        float gth = 0.f, gr6[6] = {0, 0, 0, 0, 0, 0};
+        orient_base_bwd(s.theta[e], L.r6, o, g_ob, gth, gr6);
+        s.g_theta[e] = gth;
+        s.g_xy[e * 2 + 0] = s.g_tw[t * 3 + 0];
+        s.g_xy[e * 2 + 1] = s.g_tw[t * 3 + 1];
+        // local_rot / local_z: gradient is final here (+ regularisers loss_func.py:189-237)
+        for (int k = 0; k < 6; ++k) {
+          const int i = l.local_rot + e * 6 + k;
+          const float r = s.p[i] * FPS;
+          if (on(GLAMR_LOSS_LOCAL_ROT_REG)) lsum[GLAMR_LOSS_LOCAL_ROT_REG] += r * r;
+          const float g = gr6[k] + 2.0f * FPS * r * w_rot;
+          if (update && (st.var_mask & GLAMR_VAR_LOCAL_ROT)) { if (sc.store_grad) s.g[i] = g; adam(s.p[i], s.m[i], s.v[i], g, ac); }
+        }
+        {
+          const int i = l.local_z + e;
+          const float r = s.p[i] * FPS;
+          if (on(GLAMR_LOSS_LOCAL_Z_REG)) lsum[GLAMR_LOSS_LOCAL_Z_REG] += r * r;
+          const float g = s.g_tw[t * 3 + 2] + 2.0f * FPS * r * w_z;
+          if (update && (st.var_mask & GLAMR_VAR_LOCAL_Z)) { if (sc.store_grad) s.g[i] = g; adam(s.p[i], s.m[i], s.v[i], g, ac); }
+        }
+      }
+    }
+    rt.sync();
+    if (update) {
+      for (int p = 0; p < P; ++p) {
+        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+        rt.scan(sc.ps[p].g_xy, n, 2, true);
+        rt.scan(sc.ps[p].g_xy + 1, n, 2, true);
+      }
+      // ---- I: reverse of B ----------------------------------------------------------------------------------------------
+      for (int p = 0; p < P; ++p) {
+        PersonState& s = sc.ps[p];
+        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+        for (int e = rt.tid(); e < n; e += rt.nthreads()) {
+          // contribution of d[e+1] = Rot(theta[e]) L[e+1].xy to g_theta[e]
+          if (e + 1 < n) {
+            const LocalRow Ln = local_row(sc, p, e + 1);
+            const float th = s.theta[e], cs = cosf(th), sn = sinf(th);
+            const float gdx = s.g_xy[(e + 1) * 2 + 0], gdy = s.g_xy[(e + 1) * 2 + 1];
+            s.g_theta[e] += gdx * (-Ln.dx * sn - Ln.dy * cs) + gdy * (Ln.dx * cs - Ln.dy * sn);
+          }
+        }
+      }
+      rt.sync();
+      for (int p = 0; p < P; ++p) {
+        PersonState& s = sc.ps[p];
+        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+        for (int e = rt.tid(); e < n; e += rt.nthreads()) {
+          float gx = s.g_xy[e * 2 + 0], gy = s.g_xy[e * 2 + 1];
+          if (e > 0) {
+            const float th = s.theta[e - 1], cs = cosf(th), sn = sinf(th);
+            const float a = gx * cs + gy * sn, b = -gx * sn + gy * cs;
+            gx = a; gy = b;
+          }
+          if (e == 0) {
+            if (st.var_mask & GLAMR_VAR_LOCAL_XY) {
+              const float g[2] = {gx, gy};
+              for (int k = 0; k < 2; ++k) { const int i = l.local_xy + k; if (sc.store_grad) s.g[i] = g[k]; adam(s.p[i], s.m[i], s.v[i], g[k], ac); }
+            }
+          } else {
+            const float g[2] = {gx, gy};
+            for (int k = 0; k < 2; ++k) {
+              const int i = l.local_dxy + e * 2 + k;
+              const float r = s.p[i] * FPS;
+              if (on(GLAMR_LOSS_LOCAL_DXY_REG)) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r;
+              const float gt = g[k] + 2.0f * FPS * r * w_dxy;
+              if (st.var_mask & GLAMR_VAR_LOCAL_DXY) { if (sc.store_grad) s.g[i] = gt; adam(s.p[i], s.m[i], s.v[i], gt, ac); }
+            }
+          }
+        }
+        rt.sync();
+        rt.scan(s.g_theta, n, 1, true);
+        // ---- J: reverse of A ----------------------------------------------------------------------------------------------
+        for (int e = rt.tid(); e < n; e += rt.nthreads()) {
+          const float gh = s.g_theta[e];
+          if (e == 0) {
+            if (st.var_mask & GLAMR_VAR_LOCAL_HEADING) { const int i = l.local_heading; if (sc.store_grad) s.g[i] = gh; adam(s.p[i], s.m[i], s.v[i], gh, ac); }
+          } else {
+            const int i = l.local_dheading + e;
+            const float v = s.p[i];
+            if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
+            if (!(st.var_mask & GLAMR_VAR_LOCAL_DHEADING)) continue;
+            const float g = (sc.pc[p].dheading_mask ? gh * sc.pc[p].dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cosf(v) - 1.0f) * (-sinf(v)) + sinf(v) * cosf(v)) * w_dh;
+            if (sc.store_grad) s.g[i] = g;
+            adam(s.p[i], s.m[i], s.v[i], g, ac);
+          }
+        }
+      }
+    }
+    // regulariser values that do not depend on being optimised (reported every evaluation)
+    if (last) {
+      for (int p = 0; p < P && !update; ++p) {
+        PersonState& s = sc.ps[p];
+        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+        for (int e = rt.tid() + 1; e < n; e += rt.nthreads()) {
+          if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[l.local_dxy + e * 2 + k] * FPS; lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
+          if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float v = s.p[l.local_dheading + e]; const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
+        }
+      }
+      // block-reduce and normalise the reported (unweighted) loss values
+      float tot[GLAMR_NUM_LOSSES];
+      for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) tot[i] = rt.reduce_sum(lsum[i]);
+      const float cnt = rt.reduce_sum(kp_dist_cnt);
+      if (rt.tid() == 0) {
+        float* o = sc.losses;
+        o[GLAMR_LOSS_KP_2D] = tot[GLAMR_LOSS_KP_2D] / n_vis_total;
+        o[GLAMR_LOSS_KP_2D_DIST] = tot[GLAMR_LOSS_KP_2D_DIST] / cnt;
+        o[GLAMR_LOSS_REL_TRANSFORM] = P > 1 ? tot[GLAMR_LOSS_REL_TRANSFORM] / n_rel : 0.f;
+        o[GLAMR_LOSS_CAM_TRAJ_ROT] = tot[GLAMR_LOSS_CAM_TRAJ_ROT] / n_ctr;
+        o[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] = tot[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] / n_trs;
+        o[GLAMR_LOSS_LOCAL_DXY_REG] = tot[GLAMR_LOSS_LOCAL_DXY_REG] / n_exist_m1;
+        o[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] = tot[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1;
+        o[GLAMR_LOSS_LOCAL_ROT_REG] = tot[GLAMR_LOSS_LOCAL_ROT_REG] / n_exist;
+        o[GLAMR_LOSS_LOCAL_Z_REG] = tot[GLAMR_LOSS_LOCAL_Z_REG] / n_exist;
+        o[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] = tot[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
+        o[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] = tot[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] / (float)(T - 1);
+        o[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] = tot[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] / (float)(T - 1);
+        o[GLAMR_LOSS_CAM_UP_REG] = tot[GLAMR_LOSS_CAM_UP_REG] / n_up;
+      }
+    }
+    rt.sync();
+  }
+}
+
+}  // namespace grecon
+}  // namespace glamr

@@ -149,27 +149,28 @@ typedef struct glamr_stage_desc {
  * slot s*max_persons + p. */
 typedef struct glamr_scene_batch {
   int32_t n_scenes, max_persons, max_len, n_joints;   /* n_joints = 26 */
-  /* host, int32 */
-  const int32_t* n_persons;              /* (n_scenes) */
-  /* dev, int32 per person slot */
-  const int32_t* fr_start;               /* first existing frame  (exist_frames = [fr_start, fr_end), :92-95) */
-  const int32_t* fr_end;
+  /* dev, int32 */
+  const int32_t* n_persons;              /* (n_scenes) persons actually present in each scene (<= max_persons <= 8) */
+  const int32_t* seq_len;                /* (n_scenes) frames actually present in each scene (<= max_len) */
+  const int32_t* fr_start;               /* (slots) first existing frame  (exist_frames = [fr_start, fr_end), :92-95) */
+  const int32_t* fr_end;                 /* (slots) */
   /* dev, fp32 constants (never written) */
-  const float* vis;                      /* (slots, max_len) 1 = vis_frames (post filter_pose) */
-  const float* j_local;                  /* (slots, max_len, n_joints, 3): joints for zero root orient, pivot-relative   */
+  const float* vis;                      /* (slots, max_len) 1 = vis_frames (post filter_pose), 0 otherwise */
+  const float* j_local;                  /* (slots, max_len, n_joints, 3) joints for zero root orient / trans (pivot-relative) */
   const float* kp_2d;                    /* (slots, max_len, n_joints, 2) kp_2d_aligned */
   const float* kp_score;                 /* (slots, max_len, n_joints)   kp_2d_score */
-  const float* cam_K;                    /* (slots, max_len, 4) fx fy cx cy  -- general 3x3 not needed by any caller */
+  const float* cam_K;                    /* (slots, max_len, 9) */
   const float* traj_local_pred;          /* (slots, max_len, 11) rows [0, exist_len) */
   const float* orient_cam;               /* (slots, max_len, 3) smpl_orient_cam (HybrIK, interpolated) */
-  const float* base_orient;              /* (slots, max_len, 3) smpl_orient_world_base outside exist_frames */
-  const float* base_trans;               /* (slots, max_len, 3) root_trans_world_base outside exist_frames */
+  const float* base_orient;              /* (slots, max_len, 3) smpl_orient_world_base (used outside exist_frames) */
+  const float* base_trans;               /* (slots, max_len, 3) root_trans_world_base   (used outside exist_frames) */
   const float* person2cam;               /* (slots, max_len, 12) 3x4 */
+  const float* dheading_mask;            /* (slots, max_len) row e >= 1 multiplies traj_local_dheading[e-1] (:400-402); NULL = 0 */
   const float* rel_transform_cam;        /* (n_scenes, max_persons, max_persons, max_len, 12) or NULL */
   /* dev, fp32 state (read and written) */
-  float* cam_pose;                       /* (n_scenes, max_len, 12) world->camera 3x4; in: current, out: final */
-  float* params;                         /* packed optimisation variables, layout from glamr_grecon_param_layout() */
-  float* losses;                         /* (n_scenes, GLAMR_NUM_LOSSES) unweighted values of the LAST iteration */
+  float* cam_pose;                       /* (n_scenes, max_len, 12) world->camera 3x4; in: current, out: last evaluated */
+  float* params;                         /* (n_scenes, scene_stride) optimisation variables, see glamr_grecon_param_layout() */
+  float* losses;                         /* (n_scenes, GLAMR_NUM_LOSSES) unweighted values of the LAST evaluation */
   /* dev outputs of the last forward pass */
   float* orient_world;                   /* (slots, max_len, 3) */
   float* trans_world;                    /* (slots, max_len, 3) */
@@ -177,7 +178,9 @@ typedef struct glamr_scene_batch {
   float* orient_cam_in_world;            /* (slots, max_len, 3) */
 } glamr_scene_batch;
 
-/* Offsets (in floats) of each variable block inside one scene's parameter vector; see glamr_grecon_param_layout(). */
+/* Offsets (in floats) of each variable block inside one scene's parameter vector; see glamr_grecon_param_layout().
+ * Per-frame person variables are stored by existing-frame row e (row 0 of local_dxy / local_dheading is unused: the reference's
+ * (n-1)-row tensors start at e = 1); world_dheading and the camera blocks are stored by video frame t. */
 typedef struct glamr_param_layout {
   int32_t scene_stride;                  /* floats per scene */
   int32_t cam_rot6d, cam_trans;          /* (max_len,6) (max_len,3); fixed camera uses row 0 only */

@@ -1,0 +1,35 @@
+// TEST INFRASTRUCTURE: instantiates the per-scene optimiser algorithm (glamr_amd/csrc/grecon_algo.hpp) with a single-threaded
+// host runtime so the CPU test-suite can check its gradients and control flow against the oracle without a GPU.
+// Same argument structs as the C ABI, but every pointer is a HOST pointer.  Never loaded by the product.
+#include "../../glamr_amd/csrc/grecon_algo.hpp"
+#include <vector>
+using namespace glamr::grecon;
+
+struct HostRT {
+  int tid() const { return 0; }
+  int nthreads() const { return 1; }
+  void sync() const {}
+  float reduce_sum(float v) const { return v; }
+  void scan(float* a, int n, int stride, bool reverse) const {
+    if (!reverse) { for (int i = 1; i < n; ++i) a[(size_t)i * stride] += a[(size_t)(i - 1) * stride]; }
+    else { for (int i = n - 2; i >= 0; --i) a[(size_t)i * stride] += a[(size_t)(i + 1) * stride]; }
+  }
+};
+
+extern "C" int hostsim_grecon_param_layout(int max_persons, int max_len, glamr_param_layout* out) {
+  param_layout(max_persons, max_len, *out);
+  return 0;
+}
+
+extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_stage_desc* st, float* grads_out) {
+  glamr_param_layout l;
+  param_layout(b->max_persons, b->max_len, l);
+  std::vector<float> ws(scene_workspace_floats(b->max_persons, b->max_len));
+  HostRT rt;
+  for (int si = 0; si < b->n_scenes; ++si) {
+    Scene sc;
+    assemble_scene(*b, l, st, si, b->n_persons[si], b->seq_len[si], ws.data(), grads_out, sc);
+    run_scene(rt, sc);
+  }
+  return 0;
+}

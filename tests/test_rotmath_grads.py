@@ -1,0 +1,89 @@
+"""Hand-written reverse-mode derivatives (glamr_amd/csrc/rotmath.hpp) vs torch autograd of the oracle formulation, on the host."""
+import ctypes
+import numpy as np
+import pytest
+import torch
+
+from oracle.port import transforms as tf
+from oracle.smplx_lbs import batch_rodrigues
+from tests import hostsim
+
+
+def _call(lib, name, x, gout, nout):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    gout = np.ascontiguousarray(gout, dtype=np.float32)
+    out = np.zeros((x.shape[0], nout), dtype=np.float32)
+    gx = np.zeros_like(x)
+    fn = getattr(lib, name)
+    fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
+    fn(x.shape[0], x.ctypes.data, gout.ctypes.data, out.ctypes.data, gx.ctypes.data)
+    return out, gx
+
+
+def _rand_rot(n, rng):
+    aa = torch.tensor(rng.normal(size=(n, 3)), dtype=torch.float32)
+    aa[: n // 4] *= 2.5            # large angles: exercise every rotmat_to_quat branch
+    return tf.aa_to_rotmat(aa).reshape(n, 9)
+
+
+CASES = {
+    't_rot6d_to_rotmat': (6, 9, lambda x: tf.sixd_to_rotmat(x).reshape(-1, 9), 'd6'),
+    't_rotmat_to_quat': (9, 4, lambda x: tf.rotmat_to_quat(x.view(-1, 3, 3)), 'rot'),
+    't_quat_to_aa': (4, 3, tf.quat_to_aa, 'quat'),
+    't_aa_to_quat': (3, 4, tf.aa_to_quat, 'aa'),
+    't_aa_to_rotmat_k': (3, 9, lambda x: tf.aa_to_rotmat(x).reshape(-1, 9), 'aa'),
+    't_aa_to_rotmat_s': (3, 9, lambda x: batch_rodrigues(x).reshape(-1, 9), 'aa_s'),
+    't_rotmat_to_aa': (9, 3, lambda x: tf.rotmat_to_aa(x.view(-1, 3, 3)), 'rot'),
+    't_quat_mul': (8, 4, lambda x: tf.quat_mul(x[:, :4], x[:, 4:]), 'quat2'),
+    't_atan2s': (2, 1, lambda x: tf.safe_atan2(x[:, 0], x[:, 1]).unsqueeze(-1), 'xy'),
+    't_normalize3': (3, 3, tf.unit, 'vec'),
+}
+
+
+def _inputs(kind, rng, n=400):
+    if kind == 'd6':
+        x = rng.normal(size=(n, 6))
+        x[0] = [1, 0, 0, 0, 1, 0]
+    elif kind == 'rot':
+        x = _rand_rot(n, rng).numpy() + rng.normal(size=(n, 9)) * 1e-3      # slightly off-manifold like the reference's products
+    elif kind == 'quat':
+        x = rng.normal(size=(n, 4))
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        x[0] = [1, 0, 0, 0]
+        x[1] = [-0.3, 0.2, 0.1, 0.9]
+    elif kind == 'aa':
+        x = rng.normal(size=(n, 3))
+        x[0] = 0.0
+        x[1] = [1e-4, -2e-4, 1e-4]        # Taylor branch of the kornia converter
+        x[2] = [3.0, 0.5, -0.2]
+    elif kind == 'aa_s':                  # smplx Rodrigues has no small-angle branch: 1 - cos(1e-4) is rounding noise in fp32
+        x = rng.normal(size=(n, 3))
+        x[0] = 0.0
+        x[1] = [1e-2, -2e-2, 1e-2]
+    elif kind == 'quat2':
+        x = rng.normal(size=(n, 8))
+    elif kind == 'xy':
+        x = rng.normal(size=(n, 2))
+        x[0] = [1e-8, 1e-7]
+        x[1] = [0.0, -1.0]
+    else:
+        x = rng.normal(size=(n, 3))
+        x[0] = 0.0
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_forward_and_backward_match_autograd(name):
+    lib = hostsim.build('rotmath_shim')
+    nin, nout, fn, kind = CASES[name]
+    rng = np.random.default_rng(hash(name) % 1000)
+    x = _inputs(kind, rng)
+    gout = rng.normal(size=(x.shape[0], nout)).astype(np.float32)
+    out, gx = _call(lib, name, x, gout, nout)
+    xt = torch.tensor(x, requires_grad=True)
+    ref = fn(xt)
+    ref.backward(torch.tensor(gout))
+    np.testing.assert_allclose(out, ref.detach().numpy(), rtol=2e-5, atol=2e-6, err_msg=name + ' forward')
+    g_ref = xt.grad.numpy()
+    scale = np.maximum(1.0, np.abs(g_ref).max(axis=1, keepdims=True))
+    assert np.abs((gx - g_ref) / scale).max() < 2e-4, name + ' backward'
