@@ -1,0 +1,127 @@
+// gfx950 kernel + C ABI of the fused global optimiser (algorithm: grecon_algo.hpp).
+//
+// Launch geometry: ONE workgroup per scene (a sequence with its persons and camera), threads over frames.  A scene's whole
+// optimisation state is ~0.1-0.2 MB and stays L2-resident; iterations are separated by workgroup barriers only, so a stage of
+// 500 iterations is a single launch with no grid-wide synchronisation and no host round trip.  Many scenes run concurrently,
+// one per CU (blockIdx -> scene; with >= 256 scenes every CU is busy; XCD placement is irrelevant because scenes never
+// communicate).
+#include "common.hpp"
+#include "grecon_algo.hpp"
+
+namespace glamr {
+namespace grecon {
+
+constexpr int MAX_THREADS = 512;
+
+struct DeviceRT {
+  float* red;   // LDS: [16] wave partials + [1] carry
+  __device__ __forceinline__ int tid() const { return threadIdx.x; }
+  __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ float reduce_sum(float v) const {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    return s;
+  }
+  // in-place inclusive prefix (or suffix) sum over a[i*stride], i in [0,n); ends with a barrier
+  __device__ void scan(float* a, int n, int stride, bool reverse) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    float carry = 0.f;
+    for (int base = 0; base < n; base += blockDim.x) {
+      const int i = base + threadIdx.x;
+      const size_t idx = (size_t)(reverse ? (n - 1 - i) : i) * stride;
+      float x = (i < n) ? a[idx] : 0.f;
+      for (int off = 1; off < 64; off <<= 1) {
+        const float y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+      }
+      __syncthreads();
+      if (lane == 63) red[wave] = x;
+      __syncthreads();
+      float pre = carry;
+      for (int w = 0; w < wave; ++w) pre += red[w];
+      float tot = 0.f;
+      for (int w = 0; w < nw; ++w) tot += red[w];
+      if (i < n) a[idx] = x + pre;
+      carry += tot;
+    }
+    __syncthreads();
+  }
+};
+
+struct KernelArgs {
+  glamr_scene_batch b;
+  glamr_stage_desc st;
+  glamr_param_layout lay;
+  float* workspace;
+  size_t ws_floats_per_scene;
+  float* grads_out;
+};
+
+__global__ __launch_bounds__(MAX_THREADS) void grecon_stage_kernel(KernelArgs a) {
+  __shared__ float red[32];
+  __shared__ Scene sc;
+  __shared__ glamr_stage_desc s_st;        // the scene keeps POINTERS to these: they must live in LDS, not in a thread's private copy
+  __shared__ glamr_param_layout s_lay;
+  const int si = blockIdx.x;
+  if (threadIdx.x == 0) {
+    s_st = a.st;
+    s_lay = a.lay;
+    assemble_scene(a.b, s_lay, &s_st, si, a.b.n_persons[si], a.b.seq_len[si], a.workspace + (size_t)si * a.ws_floats_per_scene, a.grads_out, sc);
+  }
+  __syncthreads();
+  DeviceRT rt{red};
+  run_scene(rt, sc);
+}
+
+}  // namespace grecon
+}  // namespace glamr
+
+using namespace glamr;
+using namespace glamr::grecon;
+
+extern "C" int glamr_grecon_param_layout(int max_persons, int max_len, glamr_param_layout* out) {
+  GLAMR_REQUIRE(out && max_persons >= 1 && max_persons <= 8 && max_len >= 2, "bad arguments (1 <= max_persons <= 8, max_len >= 2)");
+  param_layout(max_persons, max_len, *out);
+  return GLAMR_OK;
+}
+
+extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len) {
+  if (n_scenes <= 0 || max_persons < 1 || max_persons > 8 || max_len < 2) return 0;
+  return (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, max_len), 64) * sizeof(float);
+}
+
+extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out,
+                                      void* workspace, void* stream_) {
+  GLAMR_REQUIRE(batch && stage && workspace, "null argument");
+  GLAMR_REQUIRE(batch->n_scenes > 0 && batch->max_persons >= 1 && batch->max_persons <= 8 && batch->max_len >= 2,
+                "bad batch geometry: n_scenes=%d max_persons=%d max_len=%d", batch->n_scenes, batch->max_persons, batch->max_len);
+  GLAMR_REQUIRE(batch->n_joints == NJ, "n_joints must be %d", NJ);
+  GLAMR_REQUIRE(batch->n_persons && batch->seq_len && batch->fr_start && batch->fr_end && batch->vis && batch->j_local && batch->kp_2d &&
+                    batch->kp_score && batch->cam_K && batch->traj_local_pred && batch->orient_cam && batch->base_orient &&
+                    batch->base_trans && batch->person2cam && batch->cam_pose && batch->params && batch->losses && batch->orient_world &&
+                    batch->trans_world && batch->kp_2d_pred && batch->orient_cam_in_world,
+                "a required array of glamr_scene_batch is NULL");
+  GLAMR_REQUIRE(batch->max_persons == 1 || batch->rel_transform_cam || !((stage->loss_mask >> GLAMR_LOSS_REL_TRANSFORM) & 1u),
+                "rel_transform loss needs rel_transform_cam for multi-person scenes");
+  GLAMR_REQUIRE(stage->niters >= 0, "niters must be >= 0");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  KernelArgs ka;
+  ka.b = *batch;
+  ka.st = *stage;
+  param_layout(batch->max_persons, batch->max_len, ka.lay);
+  ka.workspace = static_cast<float*>(workspace);
+  ka.ws_floats_per_scene = align_up(scene_workspace_floats(batch->max_persons, batch->max_len), 64);
+  ka.grads_out = grads_out;
+  int threads = (batch->max_len + 63) / 64 * 64;
+  if (threads > MAX_THREADS) threads = MAX_THREADS;
+  hipLaunchKernelGGL(grecon_stage_kernel, dim3(batch->n_scenes), dim3(threads), 0, stream, ka);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}

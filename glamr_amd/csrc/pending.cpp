@@ -8,6 +8,3 @@ extern "C" int glamr_nets_destroy(glamr_nets*) { return GLAMR_OK; }
 extern "C" size_t glamr_nets_workspace_bytes(const glamr_nets*, int, int) { return 0; }
 extern "C" int glamr_nets_infer(glamr_nets*, int, int, const int32_t*, const float*, const float*, const float*, int, const float*, float*,
                                 float*, float*, float*, void*, void*) { PENDING(glamr_nets_infer); }
-extern "C" int glamr_grecon_param_layout(int, int, glamr_param_layout*) { PENDING(glamr_grecon_param_layout); }
-extern "C" size_t glamr_grecon_workspace_bytes(int, int, int) { return 0; }
-extern "C" int glamr_grecon_run_stage(const glamr_scene_batch*, const glamr_stage_desc*, float*, void*, void*) { PENDING(glamr_grecon_run_stage); }

@@ -1,0 +1,145 @@
+"""Shared driver of the fused-optimiser parity tests: runs a reference-fixture case through a `runner` (host runtime of
+tests/hostsim on the CPU, or the real libglamr_hip.so on an MI355X) and checks losses, gradients and the K-step state."""
+import ctypes
+import numpy as np
+import torch
+
+from oracle import make_golden as mg
+from oracle.port import build
+from glamr_amd import _lib
+from glamr_amd.global_recon import packing
+from glamr_amd.global_recon.configs import get_config
+from glamr_amd.utils import synth
+
+
+def j_local_from_oracle(smpl, data):
+    out = {}
+    for idx, pd in data['person_data'].items():
+        T = pd['smpl_pose'].shape[0]
+        z = torch.zeros(T, 3)
+        with torch.no_grad():
+            out[idx] = smpl(global_orient=z, body_pose=pd['smpl_pose'], betas=pd['smpl_beta'], root_trans=z).joints
+    return out
+
+
+def hostsim_runner():
+    from tests import hostsim
+    lib = hostsim.build('grecon_host')
+    fn = lib.hostsim_grecon_run_stage
+    fn.argtypes = [ctypes.POINTER(_lib.SceneBatch), ctypes.POINTER(_lib.StageDesc), ctypes.c_void_p]
+
+    def run(packed, sd, want_grads):
+        sb = packed.struct()
+        grads = torch.zeros_like(packed.t['params']) if want_grads else None
+        assert fn(ctypes.byref(sb), ctypes.byref(sd), ctypes.c_void_p(grads.data_ptr()) if want_grads else None) == 0
+        return grads
+    return run, torch.device('cpu')
+
+
+def device_runner():
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+
+    def run(packed, sd, want_grads):
+        sb = packed.struct()
+        grads = torch.zeros_like(packed.t['params']) if want_grads else None
+        ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=dev)
+        _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), _lib.ptr(grads), _lib.ptr(ws), _lib.current_stream()))
+        torch.cuda.synchronize()
+        return grads.cpu() if want_grads else None
+    return run, dev
+
+
+def grads_by_name(packed, grads, data, model_specs, opt_variables, si=0):
+    l, T = packed.layout, packed.T
+    g = grads[si]
+    out = {}
+    Ts = int(data['seq_len'])
+    if 'cam' in opt_variables:
+        if model_specs.get('flag_fixed_cam', False):
+            out['cam_rot_6d_fix'] = g[l['cam_rot6d']:l['cam_rot6d'] + 6].view(1, 6)
+            out['cam_trans_fix'] = g[l['cam_trans']:l['cam_trans'] + 3].view(1, 3)
+        else:
+            out['cam_rot_6d'] = g[l['cam_rot6d']:l['cam_rot6d'] + 6 * T].view(T, 6)[:Ts]
+            out['cam_trans'] = g[l['cam_trans']:l['cam_trans'] + 3 * T].view(T, 3)[:Ts]
+    else:
+        empty = torch.where(data['fr_num_persons'] == 0)[0]
+        out['cam_inv_rot_residual'] = g[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].view(T, 6)[empty]
+        out['cam_inv_trans_residual'] = g[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].view(T, 3)[:Ts]
+    for pi, idx in enumerate(packed.person_ids[si]):
+        pd = data['person_data'][idx]
+        n = int(pd['fr_end']) - int(pd['fr_start'])
+        pp = g[l['person0'] + pi * l['person_stride']:l['person0'] + (pi + 1) * l['person_stride']]
+        names = {'local_xy': pp[l['local_xy']:l['local_xy'] + 2], 'local_heading': pp[l['local_heading']:l['local_heading'] + 1],
+                 'local_dxy': pp[l['local_dxy']:l['local_dxy'] + 2 * T].view(T, 2)[1:n], 'local_dheading': pp[l['local_dheading']:l['local_dheading'] + T][1:n],
+                 'local_z': pp[l['local_z']:l['local_z'] + T][:n], 'local_rot': pp[l['local_rot']:l['local_rot'] + 6 * T].view(T, 6)[:n]}
+        for key in opt_variables:
+            if 'local' in key:
+                out['p%d_traj_%s' % (idx, key)] = names[key]
+        if 'world_dheading' in opt_variables:
+            out['p%d_world_dheading' % idx] = pp[l['world_dheading']:l['world_dheading'] + T][:Ts].unsqueeze(-1)
+    return out
+
+
+def check_case(runner, asset_root, golden, cfg_id, T, P, K):
+    run, dev = runner
+    g = golden('grecon_%s_T%d_P%d' % (cfg_id, T, P))
+    cfg = get_config(cfg_id)
+    specs = cfg['grecon_model_specs']
+    md = synth.make_smpl_model()
+    in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md)
+    ora = build.load_optimizer(asset_root, cfg)
+    data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 3))
+    jl = j_local_from_oracle(ora.smpl, data)
+    first = True
+    has_wd = False
+    for stage, spec in cfg['opt_stage_specs'].items():
+        packed = packing.PackedScenes([data], [jl], dev)
+        if first:
+            # forward-only evaluation reproduces forward(data, [], {'stage': 'init'}) (global_recon_model.py:246)
+            sd0 = packing.stage_desc(spec, specs, has_wd, niters=0)
+            sd0.var_mask = 0
+            sd0.flags &= ~packing.FLAG_CAM_FROM_PERSON      # stage 'init' keeps the initial camera (:473)
+            run(packed, sd0, False)
+            for pi in range(P):
+                ref = g['init_p%d_kp_2d_pred' % pi]
+                err = np.abs(packed.t['kp_2d_pred'][pi, :T].cpu().numpy() - ref).max()
+                assert err < 2e-2, 'initial projection %g px' % err
+            # first-iteration losses and gradients vs autograd of the reference
+            packed1 = packing.PackedScenes([data], [jl], dev)
+            sd1 = packing.stage_desc(spec, specs, has_wd, niters=1)
+            grads = run(packed1, sd1, True)
+            named = grads_by_name(packed1, grads, data, specs, spec['opt_variables'])
+            gmax = max([float(np.abs(g['%s_grad_%s' % (stage, n)]).max()) for n in named if g['%s_grad_%s' % (stage, n)].size] + [0.0])
+            for name, val in named.items():
+                ref = g['%s_grad_%s' % (stage, name)]
+                assert tuple(val.shape) == ref.shape, name
+                if ref.size == 0:
+                    continue
+                # cancellation noise scales with the largest gradient of the stage (gauge directions such as the 3dpw person
+                # heading have true gradient 0 and a reference value that is itself rounding noise)
+                tol = 3e-4 * max(1.0, float(np.abs(ref).max())) + 2e-5 * gmax
+                err = np.abs(val.numpy() - ref).max()
+                assert err < tol, 'gradient %s: abs err %.2e > %.2e' % (name, err, tol)
+            for lname, lid in packing.LOSS_IDS.items():
+                key = '%s_loss_%s' % (stage, lname)
+                if key in g:
+                    ref = float(g[key])
+                    got = float(packed1.t['losses'][0, lid].cpu())
+                    assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), 'loss %s: %g vs %g' % (lname, got, ref)
+            first = False
+        sd = packing.stage_desc(spec, specs, has_wd, niters=min(K, spec['opt_niters']))
+        run(packed, sd, False)
+        packed.unpack_into([data], spec, specs)
+        has_wd = has_wd or 'world_dheading' in spec['opt_variables']
+    # free-running state after K steps per stage (tolerances as in tests/test_oracle_golden.py: Adam amplifies rounding noise
+    # along directions the loss does not see)
+    for pi in range(P):
+        pd = data['person_data'][pi]
+        vis = g['init_p%d_vis_frames' % pi] & g['init_p0_vis_frames']
+        err = np.abs(pd['kp_2d_pred'].numpy() - g['opt_p%d_kp_2d_pred' % pi])[vis].max()
+        assert err < 0.5, 'kp_2d_pred after optimisation: %g px' % err
+        if cfg_id != 'glamr_3dpw':
+            for key, tol in (('smpl_orient_world', 1e-2), ('root_trans_world', 1e-2)):
+                err = np.abs(pd[key].numpy() - g['opt_p%d_%s' % (pi, key)]).max()
+                assert err < tol, '%s: %g' % (key, err)

@@ -1,0 +1,13 @@
+"""MI355X parity of the fused optimiser kernel (glamr_grecon_run_stage through the C ABI) against fixtures produced by the
+UNMODIFIED reference: first-iteration losses and gradients, and the state after K Adam steps, for all six shipped configs."""
+import pytest
+
+from oracle import make_golden as mg
+from tests import grecon_common as gc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES)
+def test_fused_optimiser_kernel_vs_reference_fixture(asset_root, golden, cfg_id, T, P, K):
+    gc.check_case(gc.device_runner(), asset_root, golden, cfg_id, T, P, K)
