@@ -46,7 +46,7 @@ _SIGNATURES = {
     'glamr_nets_create': (c_int, [POINTER(c_void_p), c_void_p, POINTER(TensorDesc), c_int, c_void_p, POINTER(TensorDesc), c_int, c_void_p, c_void_p]),
     'glamr_nets_destroy': (c_int, [c_void_p]),
     'glamr_nets_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
-    'glamr_nets_infer': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 7),
+    'glamr_nets_infer': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     'glamr_grecon_param_layout': (c_int, [c_int, c_int, POINTER(ParamLayout)]),
     'glamr_grecon_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'glamr_grecon_run_stage': (c_int, [POINTER(SceneBatch), POINTER(StageDesc), c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,207 @@
+// Building-block kernels of the two motion priors on gfx950: f32-MFMA linear layers with fused epilogues, masked multi-head
+// attention for <= 64 tokens, residual + LayerNorm, and a register-resident LSTM recurrence.
+//
+// All activations are fp32 row-major [rows][ld] with ld a multiple of 4 (16-byte rows) so tiles move as dwordx4.
+#pragma once
+#include "common.hpp"
+
+namespace glamr {
+namespace nn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GT_M = 64, GT_N = 64, GT_K = 32, GT_LD = 36;   // LDS row stride 36 floats: conflict-free ds_read_b128 over 16 rows
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1 };
+
+// Y[M,N] = act(X[M,K] W[N,K]^T + bias[N] + (rowbias ? rowbias[row / rows_per_group][N] : 0)) + (R ? R[M,N] : 0)
+//   X: ldx >= K (K multiple of 32, zero padded), W: [Npad][K] with Npad a multiple of 64 (zero rows), Y/R: ldy.
+// Tile 64x64 per 256-thread workgroup, each wave owns a 32x32 accumulator (v_mfma_f32_32x32x2_f32); both operands are staged
+// through LDS in 32-deep K chunks; lanes 0-31 / 32-63 consume the low / high 16 k of a chunk so every lane reads contiguous k.
+struct GemmArgs {
+  const float* X; const float* W; const float* bias; const float* rowbias; const float* R; float* Y;
+  int M, N, K, ldx, ldy, ldr, rows_per_group, ldrb, act;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[GT_M * GT_LD];
+  __shared__ __attribute__((aligned(16))) float sB[GT_N * GT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int col = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
+  f32x16 acc = {0};
+  // staging map: 512 float4 per operand tile, two per thread
+  const int r0 = tid >> 3, c4 = (tid & 7) * 4;          // rows r0 and r0 + 32, k offset c4
+  for (int k0 = 0; k0 < a.K; k0 += GT_K) {
+    f32x4 va[2], vb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = r0 + q * 32;
+      const int gm = min(m0 + r, a.M - 1);
+      va[q] = *reinterpret_cast<const f32x4*>(a.X + (size_t)gm * a.ldx + k0 + c4);
+      vb[q] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + r) * a.K + k0 + c4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<f32x4*>(sA + (r0 + q * 32) * GT_LD + c4) = va[q];
+      *reinterpret_cast<f32x4*>(sB + (r0 + q * 32) * GT_LD + c4) = vb[q];
+    }
+    __syncthreads();
+    const float* pa = sA + (wm * 32 + col) * GT_LD + half * 16;
+    const float* pb = sB + (wn * 32 + col) * GT_LD + half * 16;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(pa + s4 * 4);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(pb + s4 * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], w[s], acc, 0, 0, 0);
+    }
+  }
+  // epilogue: lane owns column n0 + wn*32 + col, rows (r & 3) + 8 (r >> 2) + 4 half
+  const int n = n0 + wn * 32 + col;
+  if (n >= a.N) return;
+  const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m >= a.M) continue;
+    float v = acc[r] + b;
+    if (a.rowbias) v += a.rowbias[(size_t)(m / a.rows_per_group) * a.ldrb + n];
+    if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+    if (a.R) v += a.R[(size_t)m * a.ldr + n];
+    a.Y[(size_t)m * a.ldy + n] = v;
+  }
+}
+
+// Y[row] = LayerNorm(X[row] (+ R[row])) * gamma + beta over D = 256 columns, eps = 1e-5; one wave per row.
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* X, const float* R, const float* gamma, const float* beta, float* Y,
+                                                            int rows, int ld) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)row * ld + lane * 4);
+  if (R) { const f32x4 r = *reinterpret_cast<const f32x4*>(R + (size_t)row * ld + lane * 4); v += r; }
+  float s = v[0] + v[1] + v[2] + v[3];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s * (1.0f / 256.0f);
+  const f32x4 d = v - mean;
+  float q = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4), be = *reinterpret_cast<const f32x4*>(beta + lane * 4);
+  *reinterpret_cast<f32x4*>(Y + (size_t)row * ld + lane * 4) = d * rstd * g + be;
+}
+
+// Multi-head attention for short sequences: 8 heads x 32 dims, Lq, Lk <= 64.  One 64-thread workgroup per (sequence, head);
+// thread i owns query i.  Q rows at Q[(b*Lq + i)*ldq + h*32], K/V rows at K[(b*Lk + j)*ldk + h*32].
+// key_mask[b*Lk + j] != 0 -> key j is ignored (PyTorch key_padding_mask).  A fully masked row yields zeros.
+__global__ __launch_bounds__(64) void attention_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
+                                                       float* O, int ldo, int Lq, int Lk, int q_shared) {
+  __shared__ float sK[64][33], sV[64][33];
+  const int b = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
+  for (int idx = i; idx < Lk * 32; idx += 64) {
+    const int j = idx >> 5, d = idx & 31;
+    sK[j][d] = K[(size_t)(b * Lk + j) * ldk + h * 32 + d];
+    sV[j][d] = V[(size_t)(b * Lk + j) * ldk + h * 32 + d];
+  }
+  __syncthreads();
+  if (i >= Lq) return;
+  float q[32];
+  const float* qp = Q + (size_t)((q_shared ? 0 : b * Lq) + i) * ldq + h * 32;
+  const float scale = 0.17677669529663687f;        // 1 / sqrt(32)
+#pragma unroll
+  for (int d = 0; d < 32; ++d) q[d] = qp[d] * scale;
+  float mx = -INFINITY;
+  float sc[64];
+  for (int j = 0; j < Lk; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) s = fmaf(q[d], sK[j][d], s);
+    if (key_mask && key_mask[(size_t)b * Lk + j]) s = -INFINITY;
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float o[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) o[d] = 0.f;
+  float den = 0.f;
+  if (mx > -INFINITY) {
+    for (int j = 0; j < Lk; ++j) {
+      const float p = expf(sc[j] - mx);
+      den += p;
+#pragma unroll
+      for (int d = 0; d < 32; ++d) o[d] = fmaf(p, sV[j][d], o[d]);
+    }
+  }
+  const float inv = den > 0.f ? 1.0f / den : 0.f;
+  float* op = O + (size_t)(b * Lq + i) * ldo + h * 32;
+#pragma unroll
+  for (int d = 0; d < 32; ++d) op[d] = o[d] * inv;
+}
+
+// LSTM recurrence (nn.LSTMCell semantics, gate order i f g o, hidden 128).  The input projections
+// G[t] = W_ih x_t + b_ih + b_hh are precomputed by a GEMM; this kernel adds W_hh h_{t-1} and applies the cell.
+// One 512-thread workgroup per (sequence, direction): thread r keeps row r of W_hh (128 floats) in registers.
+struct LstmArgs {
+  const float* G;        // [n_seq][max_len][1024]: cols [0,512) forward gates, [512,1024) backward gates
+  const float* Whh_f;    // [512][128]
+  const float* Whh_b;
+  const int* lens;       // [n_seq]
+  float* H;              // [n_seq][max_len][256]: cols [0,128) forward h_t, [128,256) backward h_t
+  int max_len;
+};
+
+__global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
+  __shared__ __attribute__((aligned(16))) float sh[128];
+  __shared__ float sg[512];
+  const int b = blockIdx.x, dir = blockIdx.y, r = threadIdx.x;
+  const int n = a.lens[b];
+  const float* Wrow = (dir ? a.Whh_b : a.Whh_f) + (size_t)r * 128;
+  float w[128];
+#pragma unroll
+  for (int k = 0; k < 128; k += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Wrow + k);
+    w[k] = v[0]; w[k + 1] = v[1]; w[k + 2] = v[2]; w[k + 3] = v[3];
+  }
+  float c = 0.f;
+  if (r < 128) sh[r] = 0.f;
+  __syncthreads();
+  const float* Gb = a.G + (size_t)b * a.max_len * 1024 + dir * 512 + r;
+  float* Hb = a.H + (size_t)b * a.max_len * 256 + dir * 128;
+  for (int s = 0; s < n; ++s) {
+    const int t = dir ? (n - 1 - s) : s;
+    float acc = Gb[(size_t)t * 1024];
+#pragma unroll
+    for (int k = 0; k < 128; k += 4) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(sh + k);
+      acc = fmaf(w[k], hv[0], acc); acc = fmaf(w[k + 1], hv[1], acc); acc = fmaf(w[k + 2], hv[2], acc); acc = fmaf(w[k + 3], hv[3], acc);
+    }
+    sg[r] = acc;
+    __syncthreads();
+    if (r < 128) {
+      const float ig = 1.0f / (1.0f + expf(-sg[r]));
+      const float fg = 1.0f / (1.0f + expf(-sg[128 + r]));
+      const float gg = tanhf(sg[256 + r]);
+      const float og = 1.0f / (1.0f + expf(-sg[384 + r]));
+      c = fg * c + ig * gg;
+      const float hnew = og * tanhf(c);
+      sh[r] = hnew;
+      Hb[(size_t)t * 256 + r] = hnew;
+    }
+    __syncthreads();
+  }
+}
+
+inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
+                       int act = ACT_NONE, const float* R = nullptr, int ldr = 0, const float* rowbias = nullptr, int rows_per_group = 1, int ldrb = 0) {
+  if (M <= 0) return GLAMR_OK;
+  if (K % GT_K != 0 || ldx % 4 != 0) return fail(GLAMR_E_INVALID, "gemm: K=%d must be a multiple of %d and ldx=%d of 4", K, GT_K, ldx);
+  GemmArgs a{X, W, bias, rowbias, R, Y, M, N, K, ldx, ldy, ldr, rows_per_group, ldrb, act};
+  hipLaunchKernelGGL(gemm_kernel, dim3((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M), dim3(256), 0, st, a);
+  return GLAMR_OK;
+}
+
+}  // namespace nn
+}  // namespace glamr

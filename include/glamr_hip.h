@@ -75,7 +75,7 @@ int glamr_smpl_backward_root(glamr_smpl* h, int B, const float* pose, const floa
 /* ---------------------------------------------------------------------------------------------------------------------
  * Motion priors -- replace MotionInfillerVAE.inference (motion_infiller/models/motion_infiller_vae.py:618-667),
  * TrajPredVAE.inference (traj_pred/models/traj_pred_vae.py:524-548) and MotionTrajJointModel.inference
- * (motion_infiller/models/motion_traj_joint_model.py:141-145).  Declared in round 1, see glamr_nets.h section below.
+ * (motion_infiller/models/motion_traj_joint_model.py:141-145).
  * ------------------------------------------------------------------------------------------------------------------- */
 typedef struct glamr_nets glamr_nets;
 
@@ -96,10 +96,12 @@ size_t glamr_nets_workspace_bytes(const glamr_nets* h, int n_seq, int max_len);
  * dev out: out_pose (n_seq, max_len, 69)   = infer_out_body_pose
  *          out_local_traj (n_seq, max_len, 11) = infer_out_local_traj_tp (time-major in the reference)
  *          out_trans (n_seq, max_len, 3), out_orient (n_seq, max_len, 3) = infer_out_trans / infer_out_orient. */
+#define GLAMR_NETS_INFILL 1   /* run the motion infiller (MotionInfillerVAE.inference, multi_step) */
+#define GLAMR_NETS_TRAJ 2     /* run the trajectory predictor on the (infilled) body pose (TrajPredVAE.inference) */
 int glamr_nets_infer(glamr_nets* h, int n_seq, int max_len, const int32_t* lens, const float* body_pose,
                      const float* visible, const float* motion_eps, int n_win_max, const float* traj_eps,
                      float* out_pose, float* out_local_traj, float* out_trans, float* out_orient,
-                     void* workspace, void* stream);
+                     int flags, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Fused global optimiser -- replaces GlobalReconOptimizer.forward/compute_loss/optimize_main
