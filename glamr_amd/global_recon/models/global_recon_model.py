@@ -1,0 +1,335 @@
+"""GlobalReconOptimizer on MI355X -- drop-in for global_recon/models/global_recon_model.py:23-659.
+
+    model = GlobalReconOptimizer(cfg, device, log)        # cfg: reference-style Config object or the dict of configs.get_config()
+    out = model.optimize(in_dict)                         # same input/output dictionaries as the reference (:572-589)
+    outs = model.optimize_batch([in_dict, ...])           # extension: many independent sequences in one pass
+
+Division of labour:
+  * host (this file, numpy): the HybrIK wire format -> per-person arrays with the reference's frame/visibility bookkeeping
+    (:88-148, bit-exact indices), scipy interpolation over gaps, `filter_pose` (a sequential data-dependent loop, :250-271), and
+    the one-off camera / heading initialisation (:166-183, :273-317).
+  * device (HIP kernels behind libglamr_hip.so): motion infilling + trajectory prediction for ALL persons of ALL sequences in one
+    batched call, SMPL skinning for the cached root-relative joints, and every optimisation stage as ONE kernel launch that runs all
+    Adam iterations of all scenes (glamr_grecon_run_stage).
+There is no CPU path for the device part: a missing library or a non-HIP device raises.
+"""
+import time
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+from ... import _lib
+from ...lib.models.smpl import SMPL, SMPL_MODEL_DIR
+from ...lib.utils import np_transform as nt
+from ...models.prior_models import MotionTrajJointModel
+from ...models.priors import num_windows, NZ
+from .. import packing
+from ..configs import get_config
+
+# (body26fk index, smpl index) pairs with identical joint names (lib/utils/joints.py:48-73,619-641 through :82-85): the 14
+# keypoints of HybrIK's 24 SMPL joints that GLAMR trusts; the other 12 body26fk joints keep score 0.
+SMPL_TO_BODY26FK = np.array([[8, 8], [5, 5], [2, 2], [21, 17], [23, 19], [25, 21], [7, 7], [4, 4], [1, 1],
+                             [20, 16], [22, 18], [24, 20], [6, 12], [0, 0]])
+
+
+def _cfg_parts(cfg):
+    if isinstance(cfg, str):
+        cfg = get_config(cfg)
+    if isinstance(cfg, dict):
+        return cfg['grecon_model_specs'], cfg['opt_stage_specs'], cfg.get('id', 'glamr')
+    return cfg.grecon_model_specs, cfg.opt_stage_specs, getattr(cfg, 'id', 'glamr')
+
+
+class GlobalReconOptimizer:
+
+    def __init__(self, cfg, device=torch.device('cuda'), log=None, smpl=None, mt_model=None, results_root='results'):
+        self.cfg = cfg
+        self.specs, self.opt_stage_specs, self.cfg_id = _cfg_parts(cfg)
+        self.device = torch.device(device)
+        self.log = log
+        if self.device.type != 'cuda':
+            raise RuntimeError('glamr_amd.GlobalReconOptimizer runs on an MI355X (device %r given); there is no CPU fallback' % (device,))
+        _lib.lib()                                                     # fail early and loudly if the HIP library is missing
+        g = self.specs.get
+        if g('est_type', 'hybrik') != 'hybrik' or not g('flag_infer_motion_traj', False) or not g('flag_pred_traj', True) \
+                or not g('flag_opt_traj', True) or not g('flag_infill_motion', True):
+            raise NotImplementedError('only est_type=hybrik with motion infilling + trajectory prediction + trajectory optimisation '
+                                      '(every shipped config) is supported')
+        for flag in ('flag_opt_motion_latent', 'flag_opt_traj_latent', 'flag_opt_vis_local_rot', 'flag_opt_person2cam_rot',
+                     'flag_opt_person2cam_trans', 'flag_make_invis_with_keypoint', 'flag_traj_from_cam', 'flag_use_pen_loss', 'absolute_heading'):
+            if g(flag, False):
+                raise NotImplementedError('%s is not supported by the MI355X path' % flag)
+        if g('heading_type', 'scalar') != 'scalar' or not g('flag_cam_inv_trans_res_all', True) or not g('flag_opt_cam', True):
+            raise NotImplementedError('unsupported grecon_model_specs')
+        self.flag_filter_pose = g('flag_filter_pose', True)
+        self.flag_init_cam_all_frames = g('flag_init_cam_all_frames', False)
+        self.cam_fix_frames = [tuple(x) for x in g('cam_fix_frames', [[0, None]])]
+        self.smpl = smpl if smpl is not None else SMPL(SMPL_MODEL_DIR, pose_type='body26fk', create_transl=False).to(self.device)
+        self.mt_model = mt_model if mt_model is not None else MotionTrajJointModel(None, self.device, log, smpl=self.smpl, results_root=results_root)
+        self.timings = {}
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # host preprocessing of one person (global_recon_model.py:88-148)
+    # ------------------------------------------------------------------------------------------------------------------------
+    def _person_arrays(self, src):
+        d = {}
+        d['visible'] = visible = src['bboxes_dict']['exist'].copy()                      # float64, compared with == 1 / == 0
+        d['visible_orig'] = visible.copy()
+        nz = np.where(visible)[0]
+        d['fr_start'], d['fr_end'] = start, end = nz[0], nz[-1] + 1
+        d['exist_frames'] = visible == 1
+        d['exist_frames'][start:end] = True
+        d['exist_len'] = end - start
+        d['max_len'] = max_len = visible.shape[0]
+        d['frames'] = np.arange(max_len)
+        vis_frames = visible == 1
+        d['frame2ind'] = {f: i for i, f in enumerate(d['frames'])}
+        d['scale'] = None
+        rm = src['smpl_pose_quat_wroot']
+        nvis = rm.shape[0]
+        aa = Rotation.from_matrix(rm.reshape((-1, 3, 3))).as_rotvec().reshape((nvis, -1, 3)).astype(np.float32)
+        d['smpl_pose'] = aa[:, 1:].reshape(-1, 69)
+        d['smpl_beta'] = src['smpl_beta']
+        d['smpl_orient_cam'] = aa[:, 0]
+        d['root_trans_cam'] = src['root_trans']
+        kp = np.concatenate((src['kp_2d'][:, :24], np.ones_like(src['kp_2d'][:, :24, [0]])), axis=-1)
+        kps = np.zeros((int(vis_frames.sum()), 26, 3))
+        kps[:, SMPL_TO_BODY26FK[:, 0]] = kp[:, SMPL_TO_BODY26FK[:, 1]]
+        d['kp_2d'], d['kp_2d_score'] = kps[:, :, :2], kps[:, :, 2]
+        d['kp_2d_aligned'] = d['kp_2d'].copy()
+        d['cam_K'] = src['cam_K'].astype(np.float32)
+        if not np.all(visible):
+            for key in ('kp_2d', 'kp_2d_score', 'kp_2d_aligned', 'cam_K'):
+                full = np.zeros((max_len,) + d[key].shape[1:], dtype=d[key].dtype)
+                full[vis_frames] = d[key]
+                d[key] = full
+            vis_ind = np.where(visible)[0]
+            for key in ('smpl_pose', 'smpl_beta', 'root_trans_cam', 'smpl_orient_cam'):
+                d[key] = nt.lerp_extrapolate(vis_ind, d[key], max_len)
+        for key in ('smpl_pose', 'smpl_beta', 'root_trans_cam', 'smpl_orient_cam'):
+            d[key] = np.ascontiguousarray(d[key], dtype=np.float32)
+        if self.flag_filter_pose:
+            self._filter_pose(d)
+        d['vis_frames'] = d['visible'] == 1
+        d['invis_frames'] = d['visible'] == 0
+        # identity initial camera: world := camera frame (:141-144)
+        d['root_trans_world_base'] = d['root_trans_cam'].copy()
+        d['smpl_orient_world_base'] = nt.quat_to_aa(nt.rotmat_to_quat(nt.aa_to_rotmat(d['smpl_orient_cam'])))
+        d['smpl_pose_nofill'] = d['smpl_pose'].copy()
+        d['smpl_pose_nofill'][~d['exist_frames']] = 0.0
+        return d
+
+    @staticmethod
+    def _filter_pose(d):
+        """:250-271 -- sequential and data dependent, stays on the host."""
+        visible = d['visible']
+        quat = nt.aa_to_quat(d['smpl_orient_cam'])
+        jump = nt.quat_angle_between(quat[1:], quat[:-1])
+        ind = np.where((jump > np.pi / 3) & (visible[1:] != 0))[0] + 1
+        ind_set = set(int(i) for i in ind)
+        for i in ind:
+            if visible[i - 1]:
+                if i + 1 < quat.shape[0] and visible[i + 1] and (i + 1) not in ind_set:
+                    visible[i - 1] = 0
+                else:
+                    visible[i] = 0
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # scene initialisation after the priors have run (:166-246)
+    # ------------------------------------------------------------------------------------------------------------------------
+    def _init_scene(self, in_dict, persons):
+        first = next(iter(persons.values()))
+        num_fr = first['max_len']
+        for d in persons.values():
+            d['person_transform_cam'] = nt.make_transform(d['smpl_orient_cam'], d['root_trans_cam'])
+            d['person2cam'] = nt.invert_transform(d['person_transform_cam'])
+            d['person_transform_world'] = nt.make_transform(d['smpl_orient_world'], d['root_trans_world'])
+            n = int(d['exist_len'])
+            d['traj_local_xy'] = np.zeros(2, np.float32)
+            d['traj_local_dxy'] = np.zeros((n - 1, 2), np.float32)
+            d['traj_local_heading'] = np.zeros(1, np.float32)
+            d['traj_local_dheading'] = np.zeros(n - 1, np.float32)
+            d['traj_local_z'] = np.zeros(n, np.float32)
+            d['traj_local_rot'] = np.zeros((n, 6), np.float32)
+        ids = list(persons.keys())
+        rel = {}
+        for i in range(len(ids)):
+            for j in range(len(ids)):
+                if i != j:
+                    rel[(i, j)] = np.matmul(nt.invert_transform(persons[ids[i]]['person_transform_cam']), persons[ids[j]]['person_transform_cam'])
+        fr_num_persons = sum(d['vis_frames'].astype(np.int64) for d in persons.values())
+        n_empty = int((fr_num_persons == 0).sum())
+        data = {
+            'seq_name': in_dict['seq_name'], 'person_data': persons, 'seq_len': num_fr, 'fr_num_persons': fr_num_persons,
+            'cam_pose': np.tile(np.eye(4, dtype=np.float32), (num_fr, 1, 1)), 'cam_pose_inv': np.tile(np.eye(4, dtype=np.float32), (num_fr, 1, 1)),
+            'cam_inv_rot_residual': np.zeros((n_empty, 6), np.float32), 'cam_inv_trans_residual': np.zeros((num_fr, 3), np.float32),
+            'rel_transform_cam': rel, 'gt': in_dict.get('gt', {}), 'gt_meta': in_dict.get('gt_meta', {}),
+            'meta': {'algo': 'global_recon', 'num_fr': num_fr},
+        }
+        self._init_cam_pose(data, all_frames=False)
+        # heading initialisation from the camera (:273-292); the resulting world trajectory is produced by the device forward pass
+        for d in persons.values():
+            w = np.matmul(data['cam_pose_inv'], d['person_transform_cam'])
+            q = nt.rotmat_to_quat(np.ascontiguousarray(w[:, :3, :3]))
+            qi = nt.interp_orient_sep_heading(q[d['vis_frames']], d['vis_frames'])
+            local = nt.global_to_local_traj(w[:, :3, 3], qi)[d['exist_frames']]
+            for (s, e) in self.cam_fix_frames:
+                d['traj_local_pred'][s:e, -2:] = local[s:e, -2:]
+        return data
+
+    def _init_cam_pose(self, data, all_frames):
+        """:294-317 -- camera-to-world from the FIRST person only; with all_frames the frames the first person is not seen in are
+        left as zero matrices (the reference's forward fill writes into a discarded tensor)."""
+        first = next(iter(data['person_data'].values()))
+        cand = np.matmul(first['person_transform_world'], first['person2cam']) * first['vis_frames'][:, None, None].astype(np.float32)
+        ind = data['fr_num_persons'] > 0
+        start = np.where(ind)[0][0]
+        inf = np.zeros_like(data['cam_pose'])
+        inf[ind] = cand[ind]
+        if not all_frames:
+            inf[...] = inf[[start]].copy()
+        inf[:, :3, :3] = nt.sixd_to_rotmat(nt.rotmat_to_6d(inf[:, :3, :3]))
+        data['pose_infer_cam_pose_inv'] = inf
+        data['cam_pose_inv'] = inf
+        data['cam_pose'] = nt.invert_transform(inf)
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # batched pipeline
+    # ------------------------------------------------------------------------------------------------------------------------
+    def init_data_batch(self, in_dicts, latents=None):
+        """Host preprocessing + ONE batched prior inference + scene initialisation.  latents: optional list (per sequence) of
+        {person idx: {'motion': (n_windows,128), 'traj': (1,128)}} replacing the Gaussian draws."""
+        t0 = time.time()
+        dev = self.device
+        scenes = [{idx: self._person_arrays(src) for idx, src in in_dict['est'].items()} for in_dict in in_dicts]
+        flat = [(si, idx, d) for si, persons in enumerate(scenes) for idx, d in persons.items()]
+        lens = [int(d['exist_len']) for _, _, d in flat]
+        Tm = max(lens)
+        nw = num_windows(Tm)
+        pose = np.zeros((len(flat), Tm, 69), np.float32)
+        vis = np.zeros((len(flat), Tm), np.float32)
+        for k, (si, idx, d) in enumerate(flat):
+            ex = d['exist_frames']
+            pose[k, :lens[k]] = d['smpl_pose_nofill'][ex]
+            vis[k, :lens[k]] = d['visible'][ex]
+        if latents is not None:
+            meps = np.zeros((len(flat), nw, NZ), np.float32)
+            teps = np.zeros((len(flat), NZ), np.float32)
+            for k, (si, idx, d) in enumerate(flat):
+                m = np.asarray(latents[si][idx]['motion'], np.float32)
+                meps[k, :m.shape[0]] = m
+                teps[k] = np.asarray(latents[si][idx]['traj'], np.float32).reshape(-1)
+            meps, teps = torch.from_numpy(meps).to(dev), torch.from_numpy(teps).to(dev)
+        else:
+            meps, teps = torch.randn((len(flat), nw, NZ), device=dev), torch.randn((len(flat), NZ), device=dev)
+        t1 = time.time()
+        out = self.mt_model.infer_padded(torch.from_numpy(pose).to(dev), torch.from_numpy(vis).to(dev), lens, meps, teps)
+        out = {k: v.cpu().numpy() for k, v in out.items()}
+        t2 = time.time()
+        for k, (si, idx, d) in enumerate(flat):                                              # infer_motion_traj :370-392
+            ex, n = d['exist_frames'], lens[k]
+            d['infilled'] = d['traj_predicted'] = True
+            d['smpl_pose'] = d['smpl_pose'].copy()
+            d['smpl_pose'][ex] = out['pose'][k, :n]
+            d['traj_local_pred'] = out['local_traj'][k, :n].copy()
+            d['smpl_orient_world_base'][ex] = out['orient'][k, :n]
+            d['root_trans_world_base'][ex] = out['trans'][k, :n]
+            d['smpl_orient_world'], d['root_trans_world'] = d['smpl_orient_world_base'], d['root_trans_world_base']
+        datas = [self._init_scene(in_dict, persons) for in_dict, persons in zip(in_dicts, scenes)]
+        t3 = time.time()
+        # root-relative joints, cached for the whole optimisation: one batched skinning call
+        poses = np.concatenate([d['smpl_pose'] for _, _, d in flat])
+        betas = np.concatenate([d['smpl_beta'] for _, _, d in flat])
+        zeros = torch.zeros((poses.shape[0], 3), device=dev)
+        with torch.no_grad():
+            jl = self.smpl(global_orient=zeros, body_pose=torch.from_numpy(poses).to(dev), betas=torch.from_numpy(betas).to(dev),
+                           root_trans=zeros, return_verts=False).joints
+        j_locals, off = [dict() for _ in scenes], 0
+        for si, idx, d in flat:
+            j_locals[si][idx] = jl[off:off + d['max_len']]
+            off += d['max_len']
+        # first world trajectory + (optionally) the all-frames camera, then the 'init' forward pass (:241-246)
+        datas_t = [self._to_torch(d) for d in datas]
+        packed = packing.PackedScenes(datas_t, j_locals, dev, self.cam_fix_frames)
+        self._run(packed, self._forward_only_desc())
+        if self.flag_init_cam_all_frames:
+            packed.unpack_into(datas_t, None, self.specs)
+            for dt, dn in zip(datas_t, datas):
+                for idx, pd in dt['person_data'].items():
+                    dn['person_data'][idx]['person_transform_world'] = nt.make_transform(pd['smpl_orient_world'].cpu().numpy(), pd['root_trans_world'].cpu().numpy())
+                self._init_cam_pose(dn, all_frames=True)
+                dt['cam_pose'] = torch.from_numpy(dn['cam_pose'])
+                dt['cam_pose_inv'] = torch.from_numpy(dn['cam_pose_inv'])
+            packed = packing.PackedScenes(datas_t, j_locals, dev, self.cam_fix_frames)
+            self._run(packed, self._forward_only_desc())
+        self.timings.update(host_pre=t1 - t0, priors=t2 - t1, host_init=t3 - t2, lbs_pack_init=time.time() - t3)
+        return datas_t, packed
+
+    @staticmethod
+    def _to_torch(data):
+        def conv(x):
+            if isinstance(x, np.ndarray):
+                return torch.from_numpy(np.ascontiguousarray(x))
+            if isinstance(x, dict):
+                return {k: conv(v) for k, v in x.items()}
+            return x
+        return conv(data)
+
+    def _forward_only_desc(self):
+        first = next(iter(self.opt_stage_specs.values()))
+        sd = packing.stage_desc(first, self.specs, has_world_dheading=False, niters=0)
+        sd.var_mask = 0
+        sd.flags &= ~packing.FLAG_CAM_FROM_PERSON           # stage 'init' keeps the initial camera (:473)
+        return sd
+
+    def _run(self, packed, sd):
+        import ctypes
+        L = _lib.lib()
+        sb = packed.struct()
+        ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=self.device)
+        _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, _lib.ptr(ws), _lib.current_stream()))
+
+    def optimize_batch(self, in_dicts, latents=None, max_iters=None):
+        """`max_iters` caps the iterations of every stage (tests); None = the configured schedule."""
+        datas, packed = self.init_data_batch(in_dicts, latents)
+        t0 = time.time()
+        has_wd = False
+        last_spec = None
+        for stage, spec in self.opt_stage_specs.items():
+            sd = packing.stage_desc(spec, self.specs, has_world_dheading=has_wd,
+                                    niters=None if max_iters is None else min(max_iters, spec['opt_niters']))
+            self._run(packed, sd)
+            has_wd = has_wd or 'world_dheading' in spec['opt_variables']
+            last_spec = spec
+            if spec.get('reinitialize_cam', False):
+                packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
+        torch.cuda.synchronize(self.device)
+        self.timings['optimise'] = time.time() - t0
+        t0 = time.time()
+        packed.has_world_dheading = has_wd
+        packed.unpack_into(datas, {'opt_variables': sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))} if last_spec else None, self.specs)
+        self.last_losses = packed.t['losses'].cpu().numpy()
+        outs = [self._to_numpy(d) for d in datas]
+        self.timings['unpack'] = time.time() - t0
+        return outs
+
+    @staticmethod
+    def _to_numpy(x):
+        if isinstance(x, torch.Tensor):
+            return x.detach().cpu().numpy()
+        if isinstance(x, dict):
+            return {k: GlobalReconOptimizer._to_numpy(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [GlobalReconOptimizer._to_numpy(v) for v in x]
+        return x
+
+    # -- reference entry points ---------------------------------------------------------------------------------------------------
+    def init_data(self, in_dict, latents=None):
+        datas, _ = self.init_data_batch([in_dict], None if latents is None else [latents])
+        return datas[0]
+
+    def optimize(self, in_dict, continue_opt=False, latents=None, max_iters=None):
+        if continue_opt:
+            raise NotImplementedError('continue_opt=True (restart from a previous data dict) is not implemented')
+        return self.optimize_batch([in_dict], None if latents is None else [latents], max_iters)[0]

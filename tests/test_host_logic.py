@@ -1,0 +1,72 @@
+"""CPU tests of the product's host-side logic (no GPU): numpy transform helpers vs the oracle, and the per-person preprocessing
+(frame / visibility bookkeeping must be bit-exact) vs fixtures produced by the unmodified reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import make_golden as mg
+from oracle.port import transforms as tf
+from glamr_amd.lib.utils import np_transform as nt
+from glamr_amd.utils import synth
+
+
+def _close(a, b, tol=2e-6):
+    assert np.abs(np.asarray(a, np.float64) - np.asarray(b.detach().numpy() if hasattr(b, 'detach') else b, np.float64)).max() < tol
+
+
+def test_numpy_transforms_match_oracle():
+    x = mg.seeded_inputs('geom')
+    aa, aa2, d6, trans = x['aa'], x['aa2'], x['d6'], x['trans']
+    ta, ta2, td6, tt = map(torch.tensor, (aa, aa2, d6, trans))
+    R = nt.aa_to_rotmat(aa)
+    _close(R, tf.aa_to_rotmat(ta))
+    _close(nt.rotmat_to_quat(R), tf.rotmat_to_quat(tf.aa_to_rotmat(ta)))
+    q1, q2 = nt.aa_to_quat(aa), nt.aa_to_quat(aa2)
+    _close(q1, tf.aa_to_quat(ta))
+    _close(nt.quat_to_aa(q1), tf.quat_to_aa(tf.aa_to_quat(ta)))
+    _close(nt.quat_mul(q1, q2), tf.quat_mul(tf.aa_to_quat(ta), tf.aa_to_quat(ta2)))
+    _close(nt.quat_angle_between(q1, q2), tf.quat_angle_between(tf.aa_to_quat(ta), tf.aa_to_quat(ta2)), 2e-4)
+    _close(nt.quat_to_rotmat(q1), tf.quat_to_rotmat(tf.aa_to_quat(ta)))
+    _close(nt.sixd_to_rotmat(d6), tf.sixd_to_rotmat(td6))
+    M = nt.make_transform(aa, trans)
+    _close(M, tf.make_transform(ta, tt, 'axis_angle'))
+    _close(nt.invert_transform(M), tf.invert_transform(tf.make_transform(ta, tt, 'axis_angle')))
+    tg, qg = tf.local_to_global_traj(torch.tensor(x['local']))
+    _close(nt.global_to_local_traj(tg.numpy(), qg.numpy()), tf.global_to_local_traj(tg, qg), 5e-6)
+    vis = np.ones(64, bool)
+    vis[20:31] = False
+    vis[60:] = False
+    _close(nt.interp_orient_sep_heading(qg.numpy()[vis], vis), tf.interp_orient_sep_heading(qg[torch.tensor(vis)], torch.tensor(vis)), 5e-6)
+
+
+@pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES[:3])
+def test_person_preprocessing_is_bit_exact(golden, cfg_id, T, P, K):
+    from glamr_amd.global_recon.models.global_recon_model import GlobalReconOptimizer
+    g = golden('grecon_%s_T%d_P%d' % (cfg_id, T, P))
+    in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model())
+    opt = GlobalReconOptimizer.__new__(GlobalReconOptimizer)       # host logic only: no device, no library
+    opt.flag_filter_pose = True
+    for pi in range(P):
+        d = opt._person_arrays(in_dict['est'][pi])
+        for key in ('visible', 'visible_orig', 'exist_frames', 'vis_frames', 'invis_frames', 'kp_2d_score', 'kp_2d_aligned', 'cam_K'):
+            assert np.array_equal(np.asarray(d[key]), g['init_p%d_%s' % (pi, key)]), key
+        assert int(d['fr_start']) == int(g['init_p%d_fr_start' % pi]) and int(d['fr_end']) == int(g['init_p%d_fr_end' % pi])
+        assert int(d['exist_len']) == int(g['init_p%d_exist_len' % pi])
+        for key in ('smpl_beta', 'smpl_orient_cam', 'root_trans_cam', 'smpl_pose_nofill'):
+            assert np.abs(d[key] - g['init_p%d_%s' % (pi, key)]).max() < 1e-6, key
+
+
+def test_filter_pose_drops_orientation_jumps():
+    """filter_pose look-ahead rule (global_recon_model.py:256-262): of two frames around a > 60 degree jump the EARLIER one is
+    dropped unless the next frame is itself a jump or invisible."""
+    from glamr_amd.global_recon.models.global_recon_model import GlobalReconOptimizer
+    T = 12
+    orient = np.tile(np.array([[0.1, 0.0, 0.0]], np.float32), (T, 1))
+    orient[5] = [0.1, 2.0, 0.0]            # isolated flip: jumps at 5 and at 6
+    d = {'visible': np.ones(T), 'smpl_orient_cam': orient}
+    GlobalReconOptimizer._filter_pose(d)
+    ref = {'visible': torch.ones(T, dtype=torch.float64), 'smpl_orient_cam': torch.tensor(orient)}
+    from oracle.port.grecon import GlobalReconOptimizer as Ora
+    Ora.filter_pose(Ora.__new__(Ora), ref)
+    assert np.array_equal(d['visible'], ref['visible'].numpy())
+    assert d['visible'].sum() < T
