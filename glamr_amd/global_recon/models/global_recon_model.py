@@ -263,6 +263,7 @@ class GlobalReconOptimizer:
                 dt['cam_pose_inv'] = torch.from_numpy(dn['cam_pose_inv'])
             packed = packing.PackedScenes(datas_t, j_locals, dev, self.cam_fix_frames)
             self._run(packed, self._forward_only_desc())
+        packed.unpack_into(datas_t, None, self.specs)        # world trajectory / projections of the 'init' forward pass
         self.timings.update(host_pre=t1 - t0, priors=t2 - t1, host_init=t3 - t2, lbs_pack_init=time.time() - t3)
         return datas_t, packed
 
