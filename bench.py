@@ -1,0 +1,170 @@
+"""Headline benchmark: sequences/sec of end-to-end global reconstruction (GlobalReconOptimizer.optimize_batch) on 300-frame,
+1-person, dynamic-camera synthetic sequences (BASELINE.json configs[1], cfg `glamr_dynamic`, 500 Adam iterations).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A "step" = one pass of the hot path over one batch of B independent synthetic sequences per GPU: host parsing of the HybrIK-format
+dictionaries, motion infilling + trajectory prediction, SMPL skinning, scene initialisation and the full optimisation schedule.
+The timed region starts from HOST dictionaries (the reference's entry point hands over host data), so `value` is host- and
+PCIe-inclusive -- a conservative reading of the contract; the device-only rates are reported next to it.  Multi-GPU: one process
+per GPU (torch.distributed over RCCL), sequences are independent, so ranks share nothing on the data path (weak scaling);
+the only collectives are the barrier and the max-reduction of the elapsed time.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the fused optimiser stage), `cpu_baseline` the CPU
+oracle (a port of the reference, oracle/port) timed on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic HBM-level traffic of one (person, iteration) of the fused optimiser, SURVEY.md 8(d) K5: parameters + Adam moments
+# (read + write) 2 x 58 KB, cached joints 94 KB, keypoint targets + scores 94 KB, intrinsics 11 KB, trajectory prior 13 KB,
+# HybrIK orientation/translation 7 KB, transforms 60 KB
+ALGO_BYTES_PER_PERSON_ITER = (2 * 58 + 94 + 94 + 11 + 13 + 7 + 60) * 1024
+HBM_PEAK_GBS = 8000.0
+CFG_ID, NUM_FRAMES = 'glamr_dynamic', 300
+
+
+def build_model(asset_root, device):
+    import torch
+    from glamr_amd.global_recon.models import model_dict
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.lib.models.smpl import SMPL
+    from glamr_amd.models.prior_models import MotionTrajJointModel
+    smpl = SMPL(os.path.join(asset_root, 'data', 'body_models', 'smpl'), pose_type='body26fk',
+                extra_regressor_path=os.path.join(asset_root, 'data', 'J_regressor_extra.npy')).to(device)
+    mt = MotionTrajJointModel(None, device, None, smpl=smpl, results_root=os.path.join(asset_root, 'results'))
+    return model_dict['global_recon_model'](get_config(CFG_ID), device, None, smpl=smpl, mt_model=mt)
+
+
+def ensure_assets():
+    from glamr_amd.utils import synth
+    from glamr_amd.models.layouts import INFILLER_LAYOUT, TRAJPRED_LAYOUT
+    root = os.path.join(tempfile.gettempdir(), 'glamr_bench_assets_%d' % os.getuid())
+    if not os.path.exists(os.path.join(root, 'data', 'J_regressor_extra.npy')):
+        synth.write_smpl_assets(root)
+    ck = os.path.join(root, 'results', 'traj_pred', 'traj_pred_demo', 'version_0', 'checkpoints', 'model-best-epoch=0000.ckpt')
+    if not os.path.exists(ck):
+        synth.write_checkpoints(root, INFILLER_LAYOUT, TRAJPRED_LAYOUT)
+    return root
+
+
+def cpu_baseline(asset_root, iters=40):
+    """The CPU oracle (oracle/port: torch autograd + Adam, full SMPL skinning per iteration like the reference) on ONE 300-frame
+    sequence: init_data in full, `iters` of the 500 iterations timed, extrapolated to the schedule."""
+    import torch
+    from oracle.port import build
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.utils import synth
+    cfg = get_config(CFG_ID)
+    opt = build.load_optimizer(asset_root, cfg)
+    in_dict = synth.make_in_dict(seed=0, num_frames=NUM_FRAMES, num_persons=1, smpl_model=synth.make_smpl_model())
+    t0 = time.time()
+    data = opt.init_data(in_dict)
+    t_init = time.time() - t0
+    spec = cfg['opt_stage_specs']['init_opt']
+    opt.optimize_main(data, spec['opt_variables'], spec['opt_lr'], 3, spec['loss_cfg'], {'stage': 'init_opt'})          # warm-up
+    t0 = time.time()
+    opt.optimize_main(data, spec['opt_variables'], spec['opt_lr'], iters, spec['loss_cfg'], {'stage': 'init_opt'})
+    per_iter = (time.time() - t0) / iters
+    total = t_init + per_iter * spec['opt_niters']
+    return {'value': 1.0 / total, 'unit': 'sequences/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle/port on 1 sequence of %d frames: init_data (%.2f s) + %d of %d Adam iterations timed (%.1f ms/iter), '
+                      'extrapolated to the full schedule (%.1f s/sequence)' % (NUM_FRAMES, t_init, iters, spec['opt_niters'], per_iter * 1e3, total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=64, help='independent sequences per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from glamr_amd.utils import synth
+    if rank == 0:
+        asset_root = ensure_assets()
+    if world > 1:
+        dist.barrier()
+    asset_root = ensure_assets()
+    model = build_model(asset_root, dev)
+    md = synth.make_smpl_model()
+    B = args.batch
+    # every rank works on its own sequences: seeds rank*B .. rank*B + B - 1 (independent units, no data-path collective)
+    in_dicts = [synth.make_in_dict(seed=rank * B + i, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md) for i in range(B)]
+
+    def step():
+        return model.optimize_batch(in_dicts)
+
+    for _ in range(args.warmup):
+        step()
+    model.kernel_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.time() - t0
+    tm = dict(model.timings)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        iters = sum(s['opt_niters'] for s in model.opt_stage_specs.values())
+        kms = [ms for ms in model.kernel_ms]                       # one entry per optimiser-stage launch in the timed region
+        k_avg = sum(kms) / max(1, len(kms))
+        algo_bytes = B * iters * ALGO_BYTES_PER_PERSON_ITER
+        achieved = algo_bytes / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
+        device_s = tm.get('priors', 0) + tm.get('lbs_pack_init', 0) + tm.get('optimise', 0)
+        out = {
+            'metric': 'sequences/sec (300-frame, 1-person) end-to-end global_recon', 'value': B * world * args.steps / elapsed,
+            'unit': 'sequences/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: %d-frame 1-person dynamic-camera sequences, cfg %s (%d Adam iterations), '
+                                   'batch of %d independent sequences per GPU, host dictionaries in' % (NUM_FRAMES, CFG_ID, iters, B),
+                       'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world},
+            'roofline': {'kernel': 'grecon_stage_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': k_avg,
+                         'us_per_iteration': k_avg * 1e3 / iters, 'dependent_boundary_floor_us': 1.45,
+                         'note': 'latency-bound: one workgroup per scene, state L2-resident; algorithmic bytes = %d B per person-iteration '
+                                 '(SURVEY.md 8d K5) x %d scenes x %d iterations' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},
+            'stage_seconds_last_step': {k: round(v, 4) for k, v in tm.items()},
+            'device_only_sequences_per_sec': B / device_s if device_s > 0 else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(asset_root)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

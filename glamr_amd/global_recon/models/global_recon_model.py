@@ -297,16 +297,23 @@ class GlobalReconOptimizer:
         t0 = time.time()
         has_wd = False
         last_spec = None
+        events = []
         for stage, spec in self.opt_stage_specs.items():
             sd = packing.stage_desc(spec, self.specs, has_world_dheading=has_wd,
                                     niters=None if max_iters is None else min(max_iters, spec['opt_niters']))
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))   # on the stream the kernel runs on
+            ev[0].record()
             self._run(packed, sd)
+            ev[1].record()
+            events.append(ev)
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             last_spec = spec
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
         torch.cuda.synchronize(self.device)
         self.timings['optimise'] = time.time() - t0
+        if getattr(self, 'kernel_ms', None) is not None:
+            self.kernel_ms.extend(a.elapsed_time(b) for a, b in events)
         t0 = time.time()
         packed.has_world_dheading = has_wd
         packed.unpack_into(datas, {'opt_variables': sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))} if last_spec else None, self.specs)
