@@ -17,7 +17,6 @@ import time
 
 import numpy as np
 import torch
-from scipy.spatial.transform import Rotation
 
 from ... import _lib
 from ...lib.models.smpl import SMPL, SMPL_MODEL_DIR
@@ -88,7 +87,7 @@ class GlobalReconOptimizer:
         d['scale'] = None
         rm = src['smpl_pose_quat_wroot']
         nvis = rm.shape[0]
-        aa = Rotation.from_matrix(rm.reshape((-1, 3, 3))).as_rotvec().reshape((nvis, -1, 3)).astype(np.float32)
+        aa = nt.rotmat_to_rotvec_nearest(rm.reshape((-1, 3, 3))).reshape((nvis, -1, 3)).astype(np.float32)     # = scipy Rotation.from_matrix(..).as_rotvec() (:105-108)
         d['smpl_pose'] = aa[:, 1:].reshape(-1, 69)
         d['smpl_beta'] = src['smpl_beta']
         d['smpl_orient_cam'] = aa[:, 0]
@@ -250,22 +249,21 @@ class GlobalReconOptimizer:
             j_locals[si][idx] = jl[off:off + d['max_len']]
             off += d['max_len']
         # first world trajectory + (optionally) the all-frames camera, then the 'init' forward pass (:241-246)
-        datas_t = [self._to_torch(d) for d in datas]
-        packed = packing.PackedScenes(datas_t, j_locals, dev, self.cam_fix_frames)
+        packed = packing.PackedScenes(datas, j_locals, dev, self.cam_fix_frames)
         self._run(packed, self._forward_only_desc())
         if self.flag_init_cam_all_frames:
-            packed.unpack_into(datas_t, None, self.specs)
-            for dt, dn in zip(datas_t, datas):
-                for idx, pd in dt['person_data'].items():
-                    dn['person_data'][idx]['person_transform_world'] = nt.make_transform(pd['smpl_orient_world'].cpu().numpy(), pd['root_trans_world'].cpu().numpy())
+            h = packed.fetch(('orient_world', 'trans_world'))
+            for si, dn in enumerate(datas):
+                for pi, idx in enumerate(packed.person_ids[si]):
+                    T = dn['seq_len']
+                    dn['person_data'][idx]['person_transform_world'] = nt.make_transform(h['orient_world'][si * packed.P + pi, :T],
+                                                                                           h['trans_world'][si * packed.P + pi, :T])
                 self._init_cam_pose(dn, all_frames=True)
-                dt['cam_pose'] = torch.from_numpy(dn['cam_pose'])
-                dt['cam_pose_inv'] = torch.from_numpy(dn['cam_pose_inv'])
-            packed = packing.PackedScenes(datas_t, j_locals, dev, self.cam_fix_frames)
+            packed.set_cam_pose([dn['cam_pose'] for dn in datas])
             self._run(packed, self._forward_only_desc())
-        packed.unpack_into(datas_t, None, self.specs)        # world trajectory / projections of the 'init' forward pass
+        packed.unpack_into(datas, None, self.specs, as_torch=False)      # world trajectory / projections of the 'init' forward pass
         self.timings.update(host_pre=t1 - t0, priors=t2 - t1, host_init=t3 - t2, lbs_pack_init=time.time() - t3)
-        return datas_t, packed
+        return datas, packed
 
     @staticmethod
     def _to_torch(data):
@@ -316,9 +314,10 @@ class GlobalReconOptimizer:
             self.kernel_ms.extend(a.elapsed_time(b) for a, b in events)
         t0 = time.time()
         packed.has_world_dheading = has_wd
-        packed.unpack_into(datas, {'opt_variables': sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))} if last_spec else None, self.specs)
+        packed.unpack_into(datas, {'opt_variables': sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))} if last_spec else None,
+                           self.specs, as_torch=False)
         self.last_losses = packed.t['losses'].cpu().numpy()
-        outs = [self._to_numpy(d) for d in datas]
+        outs = datas
         self.timings['unpack'] = time.time() - t0
         return outs
 

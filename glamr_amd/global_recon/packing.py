@@ -133,7 +133,6 @@ class PackedScenes:
                 n = fe - fs
                 t['fr_start'][slot], t['fr_end'][slot] = fs, fe
                 t['vis'][slot, :Ts] = cpu(pd['vis_frames']).float()
-                t['j_local'][slot, :Ts] = cpu(j_locals[si][idx]).float()
                 t['kp_2d'][slot, :Ts] = cpu(pd['kp_2d_aligned']).float()
                 t['kp_score'][slot, :Ts] = cpu(pd['kp_2d_score']).float()
                 t['cam_K'][slot, :Ts] = cpu(pd['cam_K']).reshape(Ts, 9).float()
@@ -159,7 +158,20 @@ class PackedScenes:
             if P > 1 and d.get('rel_transform_cam'):
                 for (i, j), M in d['rel_transform_cam'].items():
                     t['rel_transform_cam'][si, i, j, :Ts] = cpu(M)[:, :3, :].reshape(Ts, 12).float()
+        jl_host = t.pop('j_local')
         self.t = {k: v.contiguous().to(device) for k, v in t.items()}
+        first_jl = j_locals[0][self.person_ids[0][0]]
+        if torch.is_tensor(first_jl) and first_jl.device == torch.device(device) and first_jl.device.type != 'cpu':
+            jl_dev = torch.zeros(jl_host.shape, dtype=torch.float32, device=device)      # device-to-device copies only
+            for si, d in enumerate(datas):
+                for pi, idx in enumerate(self.person_ids[si]):
+                    jl_dev[si * P + pi, :int(d['seq_len'])] = j_locals[si][idx]
+            self.t['j_local'] = jl_dev
+        else:
+            for si, d in enumerate(datas):
+                for pi, idx in enumerate(self.person_ids[si]):
+                    jl_host[si * P + pi, :int(d['seq_len'])] = cpu(j_locals[si][idx]).float()
+            self.t['j_local'] = jl_host.contiguous().to(device)
         self.has_world_dheading = any('world_dheading' in pd for d in datas for pd in d['person_data'].values())
 
     def struct(self):
@@ -174,50 +186,61 @@ class PackedScenes:
         l = self.layout
         return self.t['params'][si, l['person0'] + pi * l['person_stride']:l['person0'] + (pi + 1) * l['person_stride']]
 
-    def unpack_into(self, datas, stage_specs, model_specs):
+    def set_cam_pose(self, cam_poses):
+        """cam_poses: list (per scene) of (T,4,4) world->camera arrays."""
+        host = torch.zeros((self.S, self.T, 12), dtype=torch.float32)
+        for si, c in enumerate(cam_poses):
+            c = torch.as_tensor(c).float()
+            host[si, :c.shape[0]] = c[:, :3, :].reshape(-1, 12)
+        self.t['cam_pose'] = host.to(self.device)
+
+    def fetch(self, names=('params', 'cam_pose', 'orient_world', 'trans_world', 'kp_2d_pred', 'orient_cam_in_world', 'losses')):
+        """One device->host copy per tensor."""
+        return {k: self.t[k].detach().cpu().numpy() for k in names}
+
+    def unpack_into(self, datas, stage_specs, model_specs, as_torch=True):
         """Writes optimised variables and the outputs of the last forward pass back into the `data` dictionaries, with the
         tensor names the reference uses (global_recon_model.py:396-426,459-480,512-528,598-606)."""
         l, T, P = self.layout, self.T, self.P
-        tt = self.t
+        h = self.fetch()
+        conv = (lambda a: torch.from_numpy(np.ascontiguousarray(a))) if as_torch else (lambda a: np.ascontiguousarray(a))
         var = set(stage_specs['opt_variables']) if stage_specs is not None else set()
         for si, d in enumerate(datas):
             Ts = int(d['seq_len'])
-            dev = d['cam_pose'].device
-            cam = torch.zeros((Ts, 4, 4), device=dev)
-            cam[:, :3, :] = tt['cam_pose'][si, :Ts].view(Ts, 3, 4).to(dev)
+            cam = np.zeros((Ts, 4, 4), np.float32)
+            cam[:, :3, :] = h['cam_pose'][si, :Ts].reshape(Ts, 3, 4)
             cam[:, 3, 3] = 1.0
-            d['cam_pose'] = cam
-            inv = torch.zeros_like(cam)
-            inv[:, :3, :3] = cam[:, :3, :3].transpose(1, 2)
-            inv[:, :3, 3] = -torch.einsum('tji,tj->ti', cam[:, :3, :3], cam[:, :3, 3])
+            inv = np.zeros_like(cam)
+            inv[:, :3, :3] = cam[:, :3, :3].transpose(0, 2, 1)
+            inv[:, :3, 3] = -np.einsum('tji,tj->ti', cam[:, :3, :3], cam[:, :3, 3])
             inv[:, 3, 3] = 1.0
-            d['cam_pose_inv'] = inv
-            prm = tt['params'][si]
+            d['cam_pose'], d['cam_pose_inv'] = conv(cam), conv(inv)
+            prm = h['params'][si]
             if 'cam' in var:
-                r6 = prm[l['cam_rot6d']:l['cam_rot6d'] + 6 * T].view(T, 6)
-                tr = prm[l['cam_trans']:l['cam_trans'] + 3 * T].view(T, 3)
+                r6 = prm[l['cam_rot6d']:l['cam_rot6d'] + 6 * T].reshape(T, 6)
+                tr = prm[l['cam_trans']:l['cam_trans'] + 3 * T].reshape(T, 3)
                 if model_specs.get('flag_fixed_cam', False):
-                    d['cam_rot_6d_fix'], d['cam_trans_fix'] = r6[:1].clone().to(dev), tr[:1].clone().to(dev)
+                    d['cam_rot_6d_fix'], d['cam_trans_fix'] = conv(r6[:1]), conv(tr[:1])
                 else:
-                    d['cam_rot_6d'], d['cam_trans'] = r6[:Ts].clone().to(dev), tr[:Ts].clone().to(dev)
+                    d['cam_rot_6d'], d['cam_trans'] = conv(r6[:Ts]), conv(tr[:Ts])
             else:
-                empty = torch.where(d['fr_num_persons'] == 0)[0]
-                d['cam_inv_rot_residual'] = prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].view(T, 6)[empty.to(prm.device)].clone().to(dev)
-                d['cam_inv_trans_residual'] = prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].view(T, 3)[:Ts].clone().to(dev)
+                empty = np.where(np.asarray(d['fr_num_persons']) == 0)[0]
+                d['cam_inv_rot_residual'] = conv(prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].reshape(T, 6)[empty])
+                d['cam_inv_trans_residual'] = conv(prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].reshape(T, 3)[:Ts])
             for pi, idx in enumerate(self.person_ids[si]):
                 pd = d['person_data'][idx]
                 slot = si * P + pi
                 n = int(pd['fr_end']) - int(pd['fr_start'])
-                pp = self.person_params(si, pi)
-                pd['traj_local_xy'] = pp[l['local_xy']:l['local_xy'] + 2].clone().to(dev)
-                pd['traj_local_heading'] = pp[l['local_heading']:l['local_heading'] + 1].clone().to(dev)
-                pd['traj_local_dxy'] = pp[l['local_dxy']:l['local_dxy'] + 2 * T].view(T, 2)[1:n].clone().to(dev)
-                pd['traj_local_dheading'] = pp[l['local_dheading']:l['local_dheading'] + T][1:n].clone().to(dev)
-                pd['traj_local_z'] = pp[l['local_z']:l['local_z'] + T][:n].clone().to(dev)
-                pd['traj_local_rot'] = pp[l['local_rot']:l['local_rot'] + 6 * T].view(T, 6)[:n].clone().to(dev)
+                pp = prm[l['person0'] + pi * l['person_stride']:l['person0'] + (pi + 1) * l['person_stride']]
+                pd['traj_local_xy'] = conv(pp[l['local_xy']:l['local_xy'] + 2])
+                pd['traj_local_heading'] = conv(pp[l['local_heading']:l['local_heading'] + 1])
+                pd['traj_local_dxy'] = conv(pp[l['local_dxy']:l['local_dxy'] + 2 * T].reshape(T, 2)[1:n])
+                pd['traj_local_dheading'] = conv(pp[l['local_dheading']:l['local_dheading'] + T][1:n])
+                pd['traj_local_z'] = conv(pp[l['local_z']:l['local_z'] + T][:n])
+                pd['traj_local_rot'] = conv(pp[l['local_rot']:l['local_rot'] + 6 * T].reshape(T, 6)[:n])
                 if 'world_dheading' in var or 'world_dheading' in pd:
-                    pd['world_dheading'] = pp[l['world_dheading']:l['world_dheading'] + T][:Ts].clone().unsqueeze(-1).to(dev)
-                pd['smpl_orient_world'] = tt['orient_world'][slot, :Ts].clone().to(dev)
-                pd['root_trans_world'] = tt['trans_world'][slot, :Ts].clone().to(dev)
-                pd['kp_2d_pred'] = tt['kp_2d_pred'][slot, :Ts].clone().to(dev)
-                pd['smpl_orient_cam_in_world'] = tt['orient_cam_in_world'][slot, :Ts].clone().to(dev)
+                    pd['world_dheading'] = conv(pp[l['world_dheading']:l['world_dheading'] + T][:Ts, None])
+                pd['smpl_orient_world'] = conv(h['orient_world'][slot, :Ts])
+                pd['root_trans_world'] = conv(h['trans_world'][slot, :Ts])
+                pd['kp_2d_pred'] = conv(h['kp_2d_pred'][slot, :Ts])
+                pd['smpl_orient_cam_in_world'] = conv(h['orient_cam_in_world'][slot, :Ts])

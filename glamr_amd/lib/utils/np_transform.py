@@ -193,3 +193,47 @@ def interp_orient_sep_heading(q_vis, vis_frames):
     l6 = lerp_extrapolate(idx, loc6, n).astype(F)
     qi = quat_mul(heading_to_quat(safe_atan2(hv[..., 1], hv[..., 0])), rotmat_to_quat(sixd_to_rotmat(l6)))
     return quat_mul(qi, np.broadcast_to(_BASE, qi.shape))
+
+
+def rotmat_to_rotvec_nearest(M):
+    """(N,3,3) approximately-orthogonal float matrices -> (N,3) rotation vectors (float64), equal to
+    scipy `Rotation.from_matrix(M).as_rotvec()` (global_recon_model.py:105-108) to double-precision round-off, without its
+    per-call LAPACK SVD: the nearest rotation (polar factor) is reached by three Newton steps X <- (X + X^-T)/2, which converge
+    quadratically from HybrIK's float32-accurate matrices; the quaternion is then extracted from the dominant diagonal pattern and
+    mapped to angle * axis with the positive-w convention."""
+    X = np.asarray(M, dtype=np.float64)
+    for _ in range(3):
+        a, b, c = X[:, 0, 0], X[:, 0, 1], X[:, 0, 2]
+        d, e, f = X[:, 1, 0], X[:, 1, 1], X[:, 1, 2]
+        g, h, i = X[:, 2, 0], X[:, 2, 1], X[:, 2, 2]
+        cof = np.stack([np.stack([e * i - f * h, f * g - d * i, d * h - e * g], -1),
+                        np.stack([c * h - b * i, a * i - c * g, b * g - a * h], -1),
+                        np.stack([b * f - c * e, c * d - a * f, a * e - b * d], -1)], -2)      # cofactor matrix = det * X^-T
+        det = a * cof[:, 0, 0] + b * cof[:, 0, 1] + c * cof[:, 0, 2]
+        X = 0.5 * (X + cof / det[:, None, None])
+    m00, m11, m22 = X[:, 0, 0], X[:, 1, 1], X[:, 2, 2]
+    tr = m00 + m11 + m22
+    q = np.empty((X.shape[0], 4))                                   # (x, y, z, w)
+    choice = np.argmax(np.stack([m00, m11, m22, tr], -1), axis=-1)
+    for k in range(3):
+        idx = np.where(choice == k)[0]
+        if len(idx) == 0:
+            continue
+        i_, j_, k_ = k, (k + 1) % 3, (k + 2) % 3
+        q[idx, i_] = 1 - tr[idx] + 2 * X[idx, i_, i_]
+        q[idx, j_] = X[idx, j_, i_] + X[idx, i_, j_]
+        q[idx, k_] = X[idx, k_, i_] + X[idx, i_, k_]
+        q[idx, 3] = X[idx, k_, j_] - X[idx, j_, k_]
+    idx = np.where(choice == 3)[0]
+    q[idx, 0] = X[idx, 2, 1] - X[idx, 1, 2]
+    q[idx, 1] = X[idx, 0, 2] - X[idx, 2, 0]
+    q[idx, 2] = X[idx, 1, 0] - X[idx, 0, 1]
+    q[idx, 3] = 1 + tr[idx]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[q[:, 3] < 0] *= -1
+    s = np.linalg.norm(q[:, :3], axis=1)
+    angle = 2 * np.arctan2(s, q[:, 3])
+    small = angle <= 1e-3
+    a2 = angle * angle
+    scale = np.where(small, 2 + a2 / 12 + 7 * a2 * a2 / 2880, angle / np.where(small, 1.0, np.sin(angle / 2)))
+    return q[:, :3] * scale[:, None]
