@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(PKG_DIR, 'libglamr_hip.so')
 HEADER = os.path.join(os.path.dirname(PKG_DIR), 'include', 'glamr_hip.h')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+EXTRA_FLAGS = {k: v.split() for k, v in (kv.split('=', 1) for kv in os.environ.get('GLAMR_EXTRA_FLAGS', '').split(';') if kv)}
 
 
 def _sources():
@@ -38,7 +39,7 @@ def build_library(force=False, verbose=False):
     for src in _sources():
         obj = os.path.join(bdir, os.path.basename(src) + '.o')
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)

@@ -5,19 +5,61 @@
 
 namespace glamr {
 
+constexpr int RT_MAX_CH = 16;
+constexpr int RT_SCAN_FLOATS = 2 * RT_MAX_CH * 16;    // two generations x channels x waves
+constexpr int RT_RED_FLOATS = RT_SCAN_FLOATS + 16;     // + a region of its own for reduce_sum (scans may follow it without a barrier)
+
 struct DeviceRT {
-  float* red;   // LDS: [16] wave partials + [1] carry
+  float* red;   // LDS scratch of RT_RED_FLOATS floats
+  int gen = 0;  // scan_multi alternates between two halves of `red` so consecutive calls need no barrier in between
+  // In-place inclusive prefix (reverse: suffix) sums of up to RT_MAX_CH arrays ch[c][i*stride], i in [0,n).  Element i is read and
+  // written by thread i mod blockDim only, so a caller whose next phase touches only its own elements needs no barrier after it;
+  // one barrier per chunk of blockDim elements happens inside.
+  __device__ void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    const int nchunks = (n + blockDim.x - 1) / blockDim.x;
+    float carry[RT_MAX_CH];
+    for (int c = 0; c < nch; ++c) carry[c] = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+      const int base = (reverse ? (nchunks - 1 - k) : k) * blockDim.x;
+      const int i = base + threadIdx.x;                 // thread i mod blockDim always handles element i, in both directions
+      const size_t idx = (size_t)i * stride;
+      float* r = red + (gen & 1) * (RT_MAX_CH * 16);
+      gen++;
+      float x[RT_MAX_CH];
+      for (int c = 0; c < nch; ++c) {
+        float v = (i < n) ? ch[c][idx] : 0.f;
+        if (!reverse) {
+          for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_up(v, off); if (lane >= off) v += y; }
+          if (lane == 63) r[c * 16 + wave] = v;
+        } else {
+          for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_down(v, off); if (lane + off < 64) v += y; }
+          if (lane == 0) r[c * 16 + wave] = v;
+        }
+        x[c] = v;
+      }
+      __syncthreads();
+      for (int c = 0; c < nch; ++c) {
+        float pre = carry[c], tot = 0.f;
+        for (int w = 0; w < nw; ++w) { const float t = r[c * 16 + w]; tot += t; if (reverse ? (w > wave) : (w < wave)) pre += t; }
+        if (i < n) ch[c][idx] = x[c] + pre;
+        carry[c] += tot;
+      }
+    }
+  }
   __device__ __forceinline__ int tid() const { return threadIdx.x; }
   __device__ __forceinline__ int nthreads() const { return blockDim.x; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ float reduce_sum(float v) const {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    float* r = red + RT_SCAN_FLOATS;
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
     __syncthreads();
     float s = 0.f;
     const int nw = (blockDim.x + 63) >> 6;
-    for (int w = 0; w < nw; ++w) s += red[w];
+    for (int w = 0; w < nw; ++w) s += r[w];
     return s;
   }
   // in-place inclusive prefix (or suffix) sum over a[i*stride], i in [0,n); ends with a barrier

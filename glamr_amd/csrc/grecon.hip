@@ -21,18 +21,22 @@ struct KernelArgs {
   float* workspace;
   size_t ws_floats_per_scene;
   float* grads_out;
+  int use_lds;
+  unsigned fast_floats;
 };
 
 __global__ __launch_bounds__(MAX_THREADS) void grecon_stage_kernel(KernelArgs a) {
-  __shared__ float red[32];
+  __shared__ float red[RT_RED_FLOATS];
   __shared__ Scene sc;
   __shared__ glamr_stage_desc s_st;        // the scene keeps POINTERS to these: they must live in LDS, not in a thread's private copy
   __shared__ glamr_param_layout s_lay;
+  extern __shared__ __attribute__((aligned(16))) float arena[];     // prefix-sum buffers and neighbour-read arrays, when they fit
   const int si = blockIdx.x;
   if (threadIdx.x == 0) {
     s_st = a.st;
     s_lay = a.lay;
-    assemble_scene(a.b, s_lay, &s_st, si, a.b.n_persons[si], a.b.seq_len[si], a.workspace + (size_t)si * a.ws_floats_per_scene, a.grads_out, sc);
+    assemble_scene(a.b, s_lay, &s_st, si, a.b.n_persons[si], a.b.seq_len[si], a.workspace + (size_t)si * a.ws_floats_per_scene, a.grads_out, sc,
+                   a.use_lds ? arena : nullptr, a.fast_floats);
   }
   __syncthreads();
   glamr::DeviceRT rt{red};
@@ -80,7 +84,15 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   ka.grads_out = grads_out;
   int threads = (batch->max_len + 63) / 64 * 64;
   if (threads > MAX_THREADS) threads = MAX_THREADS;
-  hipLaunchKernelGGL(grecon_stage_kernel, dim3(batch->n_scenes), dim3(threads), 0, stream, ka);
+  // on-chip arena: prefix-sum / neighbour-exchange arrays first, then as much of the compact keypoint table as fits
+  constexpr size_t LDS_BUDGET = 150 * 1024;
+  const size_t base = scene_fast_floats(batch->max_persons, batch->max_len) * sizeof(float);
+  const size_t want = base + (size_t)NJ * 6 * batch->max_persons * batch->max_len * sizeof(float);
+  ka.use_lds = base <= LDS_BUDGET;
+  const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
+  ka.fast_floats = (unsigned)(dyn / sizeof(float));
+  GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grecon_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+  hipLaunchKernelGGL(grecon_stage_kernel, dim3(batch->n_scenes), dim3(threads), dyn, stream, ka);
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }

@@ -54,6 +54,12 @@ struct PersonState {
   float* g_theta; float* g_xy;        // [T], [T][2]
   float* kp_2d_pred; float* orient_cam_in_world;   // outputs
   float* kp_wsum;                     // [NJ] sum over visible frames of thresholded score^2
+  float* Lc;                          // [12][T] cached trajectory row of frame t (dx dy z r6[6] h), written in phase A
+  float* kpc;                         // [njc][6][T] compact keypoint data of the scored joints: j_local(3) target(2) weight(1)
+  float* kpc_ws;                      // global fallback for kpc
+  int njc; int jidx[NJ];              // joints whose residual weight is non-zero somewhere
+  float* h_prior;                     // [T] row e: heading angle of the prior row, atan2s(sin, cos)  (constant per stage)
+  float* oc6;                         // [T][6] first two columns of aa2R_k(orient_cam) (cam_traj_rot target, constant)
 };
 
 struct Scene {
@@ -74,6 +80,8 @@ struct Scene {
   float* losses;                      // [GLAMR_NUM_LOSSES]
   int store_grad;
   int rel_stride_p, rel_stride_t;     // padded person count / frame count of rel_cam
+  float* fast_free; size_t fast_left; // unused tail of the on-chip arena (claimed by setup for kpc when it fits)
+  int TM;                             // padded frame count (array strides)
 };
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------
@@ -140,15 +148,38 @@ GLAMR_HD LocalRow local_row(const S& sc, int p, int e) {
   if (e == 0) {
     L.dx = pr[0] + P[l.local_xy + 0];
     L.dy = pr[1] + P[l.local_xy + 1];
-    L.h = rm::atan2s(pr[10], pr[9]) + P[l.local_heading];
+    L.h = sc.ps[p].h_prior[e] + P[l.local_heading];
   } else {
     L.dx = pr[0] + P[l.local_dxy + e * 2 + 0];
     L.dy = pr[1] + P[l.local_dxy + e * 2 + 1];
-    L.h = rm::atan2s(pr[10], pr[9]) + (c.dheading_mask ? P[l.local_dheading + e] * c.dheading_mask[e] : 0.0f);
+    L.h = sc.ps[p].h_prior[e] + (c.dheading_mask ? P[l.local_dheading + e] * c.dheading_mask[e] : 0.0f);
   }
   L.z = pr[2] + P[l.local_z + e];
   for (int k = 0; k < 6; ++k) L.r6[k] = pr[3 + k] + P[l.local_rot + e * 6 + k];
   return L;
+}
+
+GLAMR_HD void store_row(float* Lc, int TM, int t, const LocalRow& L) {
+  Lc[0 * TM + t] = L.dx; Lc[1 * TM + t] = L.dy; Lc[2 * TM + t] = L.z;
+  for (int k = 0; k < 6; ++k) Lc[(3 + k) * TM + t] = L.r6[k];
+  Lc[9 * TM + t] = L.h;
+}
+GLAMR_HD LocalRow load_row(const float* Lc, int TM, int t) {
+  LocalRow L;
+  L.dx = Lc[0 * TM + t]; L.dy = Lc[1 * TM + t]; L.z = Lc[2 * TM + t];
+  for (int k = 0; k < 6; ++k) L.r6[k] = Lc[(3 + k) * TM + t];
+  L.h = Lc[9 * TM + t];
+  return L;
+}
+
+// Adam on n consecutive parameters: all loads first (one exposed memory latency instead of n), then the arithmetic, then the stores
+template <int N>
+GLAMR_HD void adam_block(float* p, float* m, float* v, float* gstore, int base, const float (&g)[N], const AdamCoef& c) {
+  float P[N], M[N], V[N];
+  for (int k = 0; k < N; ++k) { P[k] = p[base + k]; M[k] = m[base + k]; V[k] = v[base + k]; }
+  for (int k = 0; k < N; ++k) adam(P[k], M[k], V[k], g[k], c);
+  for (int k = 0; k < N; ++k) { p[base + k] = P[k]; m[base + k] = M[k]; v[base + k] = V[k]; }
+  if (gstore) for (int k = 0; k < N; ++k) gstore[base + k] = g[k];
 }
 
 // orientation chain of frame e: q = hq(theta) (x) R2q(6d->R(r6)) (x) base ; aa = q2aa(q)
@@ -210,18 +241,21 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
   l.scene_stride = l.person0 + max_persons * l.person_stride;
 }
 
+GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(12 + 30 * max_persons) * max_len; }
+
 GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
   glamr_param_layout l;
   param_layout(max_persons, max_len, l);
   const size_t T = (size_t)max_len;
   size_t n = 3 * (size_t)l.person0 + 4 * 12 * T + 2 * T + 64;                       // cm cv cg | cam_inv g_cam g_caminv g_avg | fill_src n_vis | pair_first
-  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 6 + 3 + 3 + 1 + 2 + 1) * T + 32);   // m v g | theta xy d6 g_ow g_tw g_theta g_xy vis_rank | kp_wsum
+  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 6 + 3 + 3 + 1 + 2 + 12 + 6 * NJ + 1 + 1 + 6) * T + 32);   // m v g | theta xy d6 g_ow g_tw g_theta g_xy vis_rank | kp_wsum
   return n;
 }
 
 // Binds scene `si` of the batch to pointers (no computation).  `ws` = this scene's workspace slice.
 GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layout& l, const glamr_stage_desc* st, int si,
-                             int n_persons, int seq_len, float* ws, float* grads_out, Scene& sc) {
+                             int n_persons, int seq_len, float* ws, float* grads_out, Scene& sc, float* fast = nullptr,
+                             size_t fast_floats = 0) {
   const size_t TM = (size_t)b.max_len;
   sc.P = n_persons; sc.T = seq_len; sc.lay = &l; sc.st = st;
   sc.rel_cam = b.rel_transform_cam ? b.rel_transform_cam + (size_t)si * b.max_persons * b.max_persons * TM * 12 : nullptr;
@@ -231,10 +265,13 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   sc.store_grad = grads_out != nullptr;
   float* w = ws;
   auto take = [&](size_t n) { float* r = w; w += n; return r; };
+  // arrays other threads read (neighbouring frames, prefix sums) go to the on-chip arena when the caller provides one
+  float* f = fast;
+  auto takef = [&](size_t n) { if (!fast) return take(n); float* r = f; f += n; return r; };
   sc.cm = take(l.person0); sc.cv = take(l.person0);
   float* cg_ws = take(l.person0);
   sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : cg_ws;
-  sc.cam_inv = take(12 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
+  sc.cam_inv = takef(12 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
   sc.fill_src = reinterpret_cast<int*>(take(TM)); sc.n_vis_persons = reinterpret_cast<int*>(take(TM));
   sc.pair_first = reinterpret_cast<int*>(take(64));
   for (int p = 0; p < b.max_persons; ++p) {
@@ -245,10 +282,12 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     s.m = take(l.person_stride); s.v = take(l.person_stride);
     float* g_ws = take(l.person_stride);
     s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
-    s.theta = take(TM); s.xy = take(2 * TM); s.d6 = take(6 * TM); s.g_ow = take(3 * TM); s.g_tw = take(3 * TM);
-    s.g_theta = take(TM); s.g_xy = take(2 * TM);
+    s.theta = takef(TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.g_ow = takef(3 * TM); s.g_tw = takef(3 * TM);
+    s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef(12 * TM);
+    s.kpc_ws = take((size_t)NJ * 6 * TM); s.kpc = s.kpc_ws; s.njc = 0;
     c.vis_rank = reinterpret_cast<int*>(take(TM));
     s.kp_wsum = take(32);
+    s.h_prior = take(TM); s.oc6 = take(6 * TM);
     c.fr_start = b.fr_start[slot]; c.fr_end = b.fr_end[slot];
     c.vis = b.vis + slot * TM;
     c.j_local = b.j_local + slot * TM * NJ * 3;
@@ -266,6 +305,9 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     s.kp_2d_pred = b.kp_2d_pred + slot * TM * NJ * 2;
     s.orient_cam_in_world = b.orient_cam_in_world + slot * TM * 3;
   }
+  sc.fast_free = fast ? f : nullptr;
+  sc.fast_left = fast ? fast_floats - (size_t)(f - fast) : 0;
+  sc.TM = (int)TM;
   // rel_transform_cam is indexed with the padded person count
   sc.rel_stride_p = b.max_persons;
   sc.rel_stride_t = (int)TM;
@@ -342,6 +384,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       }
     }
   }
+  for (int p = 0; p < P; ++p)
+    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      const PersonConst& c = sc.pc[p];
+      if (t < c.fr_end - c.fr_start) sc.ps[p].h_prior[t] = rm::atan2s(c.prior[(size_t)t * 11 + 10], c.prior[(size_t)t * 11 + 9]);
+      float Rb[9];
+      rm::aa_to_rotmat_k(c.orient_cam + t * 3, Rb);
+      for (int r = 0; r < 3; ++r) { sc.ps[p].oc6[t * 6 + r] = Rb[r * 3 + 0]; sc.ps[p].oc6[t * 6 + 3 + r] = Rb[r * 3 + 1]; }
+    }
   // per-joint sum over visible frames of thresholded score^2 (first_frame_only broadcasting of kp_2d, loss_func.py:27-33)
   for (int p = 0; p < P; ++p)
     for (int j = 0; j < NJ; ++j) {
@@ -353,6 +403,39 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       c = rt.reduce_sum(c);
       if (rt.tid() == 0) sc.ps[p].kp_wsum[j] = c;
     }
+  rt.sync();
+  // scored joints and their compact per-frame table (joint position, 2-D target, residual weight), on chip when it fits
+  if (rt.tid() == 0)
+    for (int p = 0; p < P; ++p) {
+      PersonState& s = sc.ps[p];
+      s.njc = 0;
+      if (on(GLAMR_LOSS_KP_2D)) for (int j = 0; j < NJ; ++j) if (s.kp_wsum[j] > 0.f) s.jidx[s.njc++] = j;
+      const size_t need = (size_t)s.njc * 6 * sc.TM;
+      if (sc.fast_free && need <= sc.fast_left) { s.kpc = sc.fast_free; sc.fast_free += need; sc.fast_left -= need; } else s.kpc = s.kpc_ws;
+    }
+  rt.sync();
+  for (int p = 0; p < P; ++p) {
+    const PersonConst& c = sc.pc[p];
+    PersonState& s = sc.ps[p];
+    const bool kp_first = ffo(GLAMR_LOSS_KP_2D);
+    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      const bool kp_frame = c.vis[t] != 0.f && (!kp_first || c.vis_rank[t] == 0);
+      const float rank_w = (c.vis_rank[t] >= 0 && c.vis_rank[t] < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
+      for (int jj = 0; jj < s.njc; ++jj) {
+        const int j = s.jidx[jj];
+        float w = 0.f;
+        if (kp_frame) {
+          if (kp_first) w = s.kp_wsum[j] * rank_w;
+          else { const float sj = c.kp_score[(size_t)t * NJ + j]; const float q = sj < st.kp_min_conf ? 0.f : sj; w = q * q * rank_w; }
+        }
+        float* o = s.kpc + (size_t)jj * 6 * sc.TM + t;
+        for (int k = 0; k < 3; ++k) o[k * sc.TM] = c.j_local[((size_t)t * NJ + j) * 3 + k];
+        o[3 * sc.TM] = c.kp_2d[((size_t)t * NJ + j) * 2 + 0];
+        o[4 * sc.TM] = c.kp_2d[((size_t)t * NJ + j) * 2 + 1];
+        o[5 * sc.TM] = w;
+      }
+    }
+  }
   rt.sync();
 
   const int niters = st.niters;
@@ -369,50 +452,64 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) lsum[i] = 0.f;
     float kp_dist_cnt = 0.f;
 
-    // ---- A: heading increments ---------------------------------------------------------------------------------------
-    for (int p = 0; p < P; ++p) {
-      const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
-      for (int e = rt.tid(); e < n; e += rt.nthreads()) {
-        const LocalRow L = local_row(sc, p, e);
-        sc.ps[p].theta[e] = rm::atan2s(sinf(L.h), cosf(L.h));
-      }
-    }
-    rt.sync();
-    for (int p = 0; p < P; ++p) rt.scan(sc.ps[p].theta, sc.pc[p].fr_end - sc.pc[p].fr_start, 1, false);
-    // ---- B: planar displacement in world axes -------------------------------------------------------------------------
-    for (int p = 0; p < P; ++p) {
-      const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
-      for (int e = rt.tid(); e < n; e += rt.nthreads()) {
-        const LocalRow L = local_row(sc, p, e);
-        float dx = L.dx, dy = L.dy;
-        if (e > 0) {
-          const float th = sc.ps[p].theta[e - 1];
-          const float c = cosf(th), s = sinf(th);
-          dx = L.dx * c - L.dy * s;
-          dy = L.dx * s + L.dy * c;
+    // ---- A: heading increments (arrays are indexed by VIDEO frame t and zero outside the person's existing range, so the
+    //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
+    for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int p = 0; p < P; ++p) {
+        const PersonConst& c = sc.pc[p];
+        float v = 0.f;
+        if (t >= c.fr_start && t < c.fr_end) {
+          const LocalRow L = local_row(sc, p, t - c.fr_start);
+          store_row(sc.ps[p].Lc, sc.TM, t, L);
+          float sh, ch;
+          rm::sincos_(L.h, sh, ch);
+          v = rm::atan2s(sh, ch);
         }
-        sc.ps[p].xy[e * 2 + 0] = dx;
-        sc.ps[p].xy[e * 2 + 1] = dy;
+        sc.ps[p].theta[t] = v;
       }
+    {
+      float* ch[8];
+      for (int p = 0; p < P; ++p) ch[p] = sc.ps[p].theta;
+      rt.scan_multi(ch, P, T, 1, false);
     }
     rt.sync();
-    for (int p = 0; p < P; ++p) {
-      rt.scan(sc.ps[p].xy, sc.pc[p].fr_end - sc.pc[p].fr_start, 2, false);
-      rt.scan(sc.ps[p].xy + 1, sc.pc[p].fr_end - sc.pc[p].fr_start, 2, false);
-    }
-    // ---- C: world orientation / translation ---------------------------------------------------------------------------
-    for (int p = 0; p < P; ++p) {
-      const PersonConst& c = sc.pc[p];
-      PersonState& s = sc.ps[p];
-      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
-        float ob[3], tb[3];
+    // ---- B: planar displacement in world axes -------------------------------------------------------------------------
+    for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int p = 0; p < P; ++p) {
+        const PersonConst& c = sc.pc[p];
+        float dx = 0.f, dy = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const int e = t - c.fr_start;
-          const LocalRow L = local_row(sc, p, e);
+          const LocalRow L = load_row(sc.ps[p].Lc, sc.TM, t);
+          dx = L.dx; dy = L.dy;
+          if (e > 0) {
+            const float th = sc.ps[p].theta[t - 1];
+            float cs, sn;
+            rm::sincos_(th, sn, cs);
+            dx = L.dx * cs - L.dy * sn;
+            dy = L.dx * sn + L.dy * cs;
+          }
+        }
+        sc.ps[p].xy[t * 2 + 0] = dx;
+        sc.ps[p].xy[t * 2 + 1] = dy;
+      }
+    {
+      float* ch[16];
+      for (int p = 0; p < P; ++p) { ch[2 * p] = sc.ps[p].xy; ch[2 * p + 1] = sc.ps[p].xy + 1; }
+      rt.scan_multi(ch, 2 * P, T, 2, false);
+    }
+    // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
+    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      for (int p = 0; p < P; ++p) {
+        const PersonConst& c = sc.pc[p];
+        PersonState& s = sc.ps[p];
+        float ob[3], tb[3];
+        if (t >= c.fr_start && t < c.fr_end) {
+          const LocalRow L = load_row(s.Lc, sc.TM, t);
           OrientFwd o;
-          orient_base_fwd(s.theta[e], L.r6, o);
+          orient_base_fwd(s.theta[t], L.r6, o);
           for (int k = 0; k < 3; ++k) ob[k] = o.aa[k];
-          tb[0] = s.xy[e * 2 + 0]; tb[1] = s.xy[e * 2 + 1]; tb[2] = L.z;
+          tb[0] = s.xy[t * 2 + 0]; tb[1] = s.xy[t * 2 + 1]; tb[2] = L.z;
         } else {
           for (int k = 0; k < 3; ++k) { ob[k] = c.base_orient[t * 3 + k]; tb[k] = c.base_trans[t * 3 + k]; }
         }
@@ -429,18 +526,25 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           s.d6[t * 6 + 3 + k] = Rk[k * 3 + 1];
         }
       }
+      // ---- D: camera of this frame, unless it is derived from the persons (needs other frames' transforms) -----------------
+      if (!cam_from_person) {
+        float M[12], Mi[12];
+        if (var_cam) {
+          const int row = fixed_cam ? 0 : t;
+          float R[9];
+          rm::rot6d_to_rotmat(sc.cp + l.cam_rot6d + row * 6, R);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sc.cp[l.cam_trans + row * 3 + i]; }
+        } else {
+          for (int k = 0; k < 12; ++k) M[k] = sc.cam_pose[(size_t)t * 12 + k];
+        }
+        invert34(M, Mi);
+        for (int k = 0; k < 12; ++k) { sc.cam_pose[(size_t)t * 12 + k] = M[k]; sc.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
+      }
     }
     rt.sync();
-    // ---- D: camera ------------------------------------------------------------------------------------------------------
-    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
-      float M[12], Mi[12];
-      if (var_cam) {
-        const int row = fixed_cam ? 0 : t;
-        float R[9];
-        rm::rot6d_to_rotmat(sc.cp + l.cam_rot6d + row * 6, R);
-        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sc.cp[l.cam_trans + row * 3 + i]; }
-        invert34(M, Mi);
-      } else if (cam_from_person) {
+    if (cam_from_person) {
+      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+        float M[12], Mi[12];
         const int src = sc.fill_src[t];
         float avg[12];
         for (int k = 0; k < 12; ++k) avg[k] = 0.f;
@@ -461,16 +565,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         rm::rot6d_to_rotmat(r6, R);
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sc.cp[l.cam_inv_trans_res + t * 3 + i]; }
         invert34(Mi, M);
-      } else {
-        for (int k = 0; k < 12; ++k) M[k] = sc.cam_pose[(size_t)t * 12 + k];
-        invert34(M, Mi);
+        for (int k = 0; k < 12; ++k) { sc.cam_pose[(size_t)t * 12 + k] = M[k]; sc.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
       }
-      for (int k = 0; k < 12; ++k) {
-        sc.cam_pose[(size_t)t * 12 + k] = M[k];
-        sc.cam_inv[(size_t)t * 12 + k] = Mi[k];
-      }
+      rt.sync();
     }
-    rt.sync();
     // ---- E: residuals and per-frame gradients -----------------------------------------------------------------------------
     const float w_kp = active(GLAMR_LOSS_KP_2D) ? st.loss_weight[GLAMR_LOSS_KP_2D] / n_vis_total : 0.f;
     const float n_ctr = ffo(GLAMR_LOSS_CAM_TRAJ_ROT) ? (float)P : n_vis_total;
@@ -485,6 +583,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     const float w_rel = (active(GLAMR_LOSS_REL_TRANSFORM) && P > 1) ? st.loss_weight[GLAMR_LOSS_REL_TRANSFORM] / n_rel : 0.f;
     const float min_conf = st.kp_min_conf;
 
+    float gfix[9];
+    for (int k = 0; k < 9; ++k) gfix[k] = 0.f;
     for (int t = rt.tid(); t < T; t += rt.nthreads()) {
       float gC[12], gCi[12];
       for (int k = 0; k < 12; ++k) { gC[k] = 0.f; gCi[k] = 0.f; }
@@ -509,15 +609,15 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         rm::rotmat_to_aa(Mk, ociw);
         if (last) for (int k = 0; k < 3; ++k) s.orient_cam_in_world[t * 3 + k] = ociw[k];
         if (on(GLAMR_LOSS_CAM_TRAJ_ROT) && visible && (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) || c.vis_rank[t] == 0)) {
-          float Ra[9], Rb[9];
+          float Ra[9];
           rm::aa_to_rotmat_k(ociw, Ra);
-          rm::aa_to_rotmat_k(c.orient_cam + t * 3, Rb);
+          const float* tgt = s.oc6 + t * 6;
           const float fw = (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) && c.vis_rank[t] == 0) ? st.first_frame_weight[GLAMR_LOSS_CAM_TRAJ_ROT] : 1.0f;
           float gRa[9];
           for (int k = 0; k < 9; ++k) gRa[k] = 0.f;
           for (int r = 0; r < 3; ++r)
             for (int col = 0; col < 2; ++col) {
-              const float d = (Rb[r * 3 + col] - Ra[r * 3 + col]) * fw;
+              const float d = (tgt[col * 3 + r] - Ra[r * 3 + col]) * fw;
               lsum[GLAMR_LOSS_CAM_TRAJ_ROT] += d * d;
               gRa[r * 3 + col] = -2.0f * d * fw * w_ctr;
             }
@@ -543,8 +643,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           const float* K = c.cam_K + (size_t)t * 9;
           const float rank_w = (c.vis_rank[t] >= 0 && c.vis_rank[t] < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
           const bool kp_frame = visible && (!kp_first || c.vis_rank[t] == 0);
-          for (int j = 0; j < NJ; ++j) {
-            const float* jl = c.j_local + ((size_t)t * NJ + j) * 3;
+          // one joint: project, accumulate the residual value and (weight > 0) its gradient
+          auto joint = [&](const float jl[3], float kx, float ky, float wj, float sc_raw, int jout) {
             float J[3], X[3];
             rm::mat3_vec(Rs, jl, J);
             for (int k = 0; k < 3; ++k) J[k] += tw[k];
@@ -554,24 +654,20 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
             const float hy = K[3] * X[0] + K[4] * X[1] + K[5] * X[2];
             const float hz = K[6] * X[0] + K[7] * X[1] + K[8] * X[2] + 1e-8f;
             const float u = hx / hz, v = hy / hz;
-            if (last) { s.kp_2d_pred[((size_t)t * NJ + j) * 2 + 0] = u; s.kp_2d_pred[((size_t)t * NJ + j) * 2 + 1] = v; }
-            const float du = u - c.kp_2d[((size_t)t * NJ + j) * 2 + 0], dv = v - c.kp_2d[((size_t)t * NJ + j) * 2 + 1];
-            const float sc_raw = c.kp_score[(size_t)t * NJ + j];
-            if (last && on(GLAMR_LOSS_KP_2D_DIST) && sc_raw > min_conf && (!ffo(GLAMR_LOSS_KP_2D_DIST) || t == 0)) {
-              lsum[GLAMR_LOSS_KP_2D_DIST] += sqrtf(du * du + dv * dv);
-              kp_dist_cnt += 1.0f;
+            const float du = u - kx, dv = v - ky;
+            if (jout >= 0) {
+              s.kp_2d_pred[((size_t)t * NJ + jout) * 2 + 0] = u;
+              s.kp_2d_pred[((size_t)t * NJ + jout) * 2 + 1] = v;
+              if (on(GLAMR_LOSS_KP_2D_DIST) && sc_raw > min_conf && (!ffo(GLAMR_LOSS_KP_2D_DIST) || t == 0)) {
+                lsum[GLAMR_LOSS_KP_2D_DIST] += sqrtf(du * du + dv * dv);
+                kp_dist_cnt += 1.0f;
+              }
             }
-            if (!kp_frame || !on(GLAMR_LOSS_KP_2D)) continue;
-            // weight of this residual: score^2 (thresholded); with first_frame_only the first visible frame's residual is
-            // multiplied by the sum of score^2 over ALL visible frames (broadcast quirk)
-            float wj;
-            if (kp_first) wj = s.kp_wsum[j] * rank_w;
-            else { const float scj = sc_raw < min_conf ? 0.f : sc_raw; wj = scj * scj * rank_w; }
+            if (wj == 0.f) return;
             lsum[GLAMR_LOSS_KP_2D] += (gmof(du, 1e4f) + gmof(dv, 1e4f)) * wj;
-            if (w_kp == 0.f || wj == 0.f) continue;
+            if (w_kp == 0.f) return;
             const float gu = gmof_d(du, 1e4f) * wj * w_kp, gv = gmof_d(dv, 1e4f) * wj * w_kp;
-            // u = hx / hz, v = hy / hz
-            const float ghx = gu / hz, ghy = gv / hz, ghz = -(gu * u + gv * v) / hz;
+            const float ghx = gu / hz, ghy = gv / hz, ghz = -(gu * u + gv * v) / hz;      // u = hx / hz, v = hy / hz
             float gX[3];
             for (int k = 0; k < 3; ++k) gX[k] = K[k] * ghx + K[3 + k] * ghy + K[6 + k] * ghz;
             for (int i = 0; i < 3; ++i) {
@@ -583,6 +679,30 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
             for (int i = 0; i < 3; ++i) {
               g_tw[i] += gJ[i];
               for (int k = 0; k < 3; ++k) gRs[i * 3 + k] += gJ[i] * jl[k];
+            }
+          };
+          if (last) {
+            // all 26 joints from the full arrays: the projections are an output (kp_2d_pred) and feed the monitor term
+            for (int j = 0; j < NJ; ++j) {
+              const float sc_raw = c.kp_score[(size_t)t * NJ + j];
+              float wj = 0.f;
+              if (kp_frame && on(GLAMR_LOSS_KP_2D)) {
+                // with first_frame_only the first visible frame's residual is multiplied by the sum of score^2 over ALL visible
+                // frames (broadcast quirk, loss_func.py:27-33)
+                if (kp_first) wj = s.kp_wsum[j] * rank_w;
+                else { const float scj = sc_raw < min_conf ? 0.f : sc_raw; wj = scj * scj * rank_w; }
+              }
+              const float* jl = c.j_local + ((size_t)t * NJ + j) * 3;
+              joint(jl, c.kp_2d[((size_t)t * NJ + j) * 2 + 0], c.kp_2d[((size_t)t * NJ + j) * 2 + 1], wj, sc_raw, j);
+            }
+          } else {
+            // only the joints that carry a score (14 of 26 for HybrIK input), from the compact table
+            for (int jj = 0; jj < s.njc; ++jj) {
+              const float* o = s.kpc + (size_t)jj * 6 * sc.TM + t;
+              const float wj = o[5 * sc.TM];
+              if (wj == 0.f) continue;
+              const float jl[3] = {o[0], o[sc.TM], o[2 * sc.TM]};
+              joint(jl, o[3 * sc.TM], o[4 * sc.TM], wj, 0.f, -1);
             }
           }
           if (w_kp != 0.f && kp_frame) rm::aa_to_rotmat_s_bwd(ow, gRs, g_ow);
@@ -664,49 +784,36 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         lsum[GLAMR_LOSS_CAM_UP_REG] += Mi[2 * 4 + 1] * fw;
         gCi[2 * 4 + 1] += fw * w_up;
       }
-      for (int k = 0; k < 12; ++k) { sc.g_cam[(size_t)t * 12 + k] = gC[k]; sc.g_caminv[(size_t)t * 12 + k] = gCi[k]; }
-    }
-    rt.sync();
-    // ---- G: camera gradients ------------------------------------------------------------------------------------------------
-    if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
-      for (int t = rt.tid(); t < T; t += rt.nthreads())
-        for (int k = 0; k < 3; ++k) { const float r = sc.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
-    if (update && var_cam) {
-      float gfix[9];
-      for (int k = 0; k < 9; ++k) gfix[k] = 0.f;
-      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      if (cam_from_person) {
+        for (int k = 0; k < 12; ++k) { sc.g_cam[(size_t)t * 12 + k] = gC[k]; sc.g_caminv[(size_t)t * 12 + k] = gCi[k]; }
+      } else if (update && var_cam) {
+        // ---- G (own camera parameters): this frame's gradient is complete, no other thread contributes -------------------
         const int row = fixed_cam ? 0 : t;
-        float gM[12];
-        for (int k = 0; k < 12; ++k) gM[k] = sc.g_cam[(size_t)t * 12 + k];
-        invert34_bwd(sc.cam_pose + (size_t)t * 12, sc.g_caminv + (size_t)t * 12, gM);
+        invert34_bwd(M, gCi, gC);
         float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
-        get_R(gM, gR);
+        get_R(gC, gR);
         rm::rot6d_to_rotmat_bwd(sc.cp + l.cam_rot6d + row * 6, gR, g6);
         if (fixed_cam) {
           for (int k = 0; k < 6; ++k) gfix[k] += g6[k];
-          for (int k = 0; k < 3; ++k) gfix[6 + k] += gM[k * 4 + 3];
+          for (int k = 0; k < 3; ++k) gfix[6 + k] += gC[k * 4 + 3];
         } else {
-          for (int k = 0; k < 6; ++k) {
-            const int i = l.cam_rot6d + t * 6 + k;
-            if (sc.store_grad) sc.cg[i] = g6[k];
-            adam(sc.cp[i], sc.cm[i], sc.cv[i], g6[k], ac);
-          }
-          for (int k = 0; k < 3; ++k) {
-            const int i = l.cam_trans + t * 3 + k;
-            if (sc.store_grad) sc.cg[i] = gM[k * 4 + 3];
-            adam(sc.cp[i], sc.cm[i], sc.cv[i], gM[k * 4 + 3], ac);
-          }
+          const float gt3[3] = {gC[3], gC[7], gC[11]};
+          adam_block<6>(sc.cp, sc.cm, sc.cv, sc.store_grad ? sc.cg : nullptr, l.cam_rot6d + t * 6, g6, ac);
+          adam_block<3>(sc.cp, sc.cm, sc.cv, sc.store_grad ? sc.cg : nullptr, l.cam_trans + t * 3, gt3, ac);
         }
       }
-      if (fixed_cam) {
-        for (int k = 0; k < 9; ++k) gfix[k] = rt.reduce_sum(gfix[k]);
-        if (rt.tid() == 0) {
-          for (int k = 0; k < 6; ++k) { const int i = l.cam_rot6d + k; if (sc.store_grad) sc.cg[i] = gfix[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[k], ac); }
-          for (int k = 0; k < 3; ++k) { const int i = l.cam_trans + k; if (sc.store_grad) sc.cg[i] = gfix[6 + k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[6 + k], ac); }
-        }
+      if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
+        for (int k = 0; k < 3; ++k) { const float r = sc.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
+    }
+    if (update && var_cam && fixed_cam) {
+      for (int k = 0; k < 9; ++k) gfix[k] = rt.reduce_sum(gfix[k]);
+      if (rt.tid() == 0) {
+        for (int k = 0; k < 6; ++k) { const int i = l.cam_rot6d + k; if (sc.store_grad) sc.cg[i] = gfix[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[k], ac); }
+        for (int k = 0; k < 3; ++k) { const int i = l.cam_trans + k; if (sc.store_grad) sc.cg[i] = gfix[6 + k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[6 + k], ac); }
       }
     } else if (update && cam_from_person) {
-      // gradient of the averaged camera-to-world transform of every frame, then folded onto its source frame
+      // ---- G (camera derived from the persons): gradient of every frame's averaged transform, folded onto its source frame ----
+      rt.sync();
       for (int t = rt.tid(); t < T; t += rt.nthreads()) {
         float gMi[12];
         for (int k = 0; k < 12; ++k) gMi[k] = sc.g_caminv[(size_t)t * 12 + k];
@@ -715,7 +822,6 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         const int src = sc.fill_src[t];
         float avg6[6];
         {
-          // recompute r6 of this frame
           float avg[12];
           for (int k = 0; k < 12; ++k) avg[k] = 0.f;
           for (int p = 0; p < P; ++p) {
@@ -735,7 +841,6 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         rm::rot6d_to_rotmat_bwd(avg6, gR, g6);
         float* ga = sc.g_avg + (size_t)t * 12;
         for (int r = 0; r < 3; ++r) { ga[r * 4 + 0] = g6[r]; ga[r * 4 + 1] = g6[3 + r]; ga[r * 4 + 2] = 0.f; ga[r * 4 + 3] = gMi[r * 4 + 3]; }
-        // residual parameters
         float g_tres[3] = {gMi[3], gMi[7], gMi[11]};
         if (active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
           const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
@@ -750,7 +855,6 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         if (sc.n_vis_persons[t] == 0) continue;                 // only frames with persons are sources
         float ga[12];
         for (int k = 0; k < 12; ++k) ga[k] = 0.f;
-        // frames filled from t: t itself, the run of empty frames after it, and (for the first source) the leading run
         for (int u = 0; u < T; ++u) {
           if (sc.fill_src[u] != t) continue;
           for (int k = 0; k < 12; ++k) ga[k] += sc.g_avg[(size_t)u * 12 + k];
@@ -770,8 +874,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           for (int k = 0; k < 3; ++k) { sc.ps[p].g_ow[t * 3 + k] += g_ow[k]; sc.ps[p].g_tw[t * 3 + k] += gTw[k * 4 + 3]; }
         }
       }
-      rt.sync();
-    } else if (update && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
+      // the fold writes g_ow / g_tw of frame t from thread t only: the owner continues without a barrier
+    } else if (update && !var_cam && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
       // camera neither optimised nor derived from the persons: the residual only feels its own regulariser
       const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
       for (int t = rt.tid(); t < T; t += rt.nthreads())
@@ -782,23 +886,23 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           adam(sc.cp[i], sc.cm[i], sc.cv[i], g, ac);
         }
     }
-    // ---- H: reverse of the orientation chain; direct parameter gradients ----------------------------------------------------
+    // ---- H: reverse of the orientation chain; direct parameter gradients (own frame only) -----------------------------------
     const float w_rot = active(GLAMR_LOSS_LOCAL_ROT_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_ROT_REG] / n_exist : 0.f;
     const float w_z = active(GLAMR_LOSS_LOCAL_Z_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_Z_REG] / n_exist : 0.f;
     const float w_dxy = active(GLAMR_LOSS_LOCAL_DXY_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_DXY_REG] / n_exist_m1 : 0.f;
     const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
-    for (int p = 0; p < P; ++p) {
-      const PersonConst& c = sc.pc[p];
-      PersonState& s = sc.ps[p];
-      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int p = 0; p < P; ++p) {
+        const PersonConst& c = sc.pc[p];
+        PersonState& s = sc.ps[p];
         const bool ex = t >= c.fr_start && t < c.fr_end;
         const int e = t - c.fr_start;
         float ob[3];
         LocalRow L;
         OrientFwd o;
         if (ex) {
-          L = local_row(sc, p, e);
-          orient_base_fwd(s.theta[e], L.r6, o);
+          L = load_row(s.Lc, sc.TM, t);
+          orient_base_fwd(s.theta[t], L.r6, o);
           for (int k = 0; k < 3; ++k) ob[k] = o.aa[k];
         } else {
           for (int k = 0; k < 3; ++k) ob[k] = c.base_orient[t * 3 + k];
@@ -817,19 +921,21 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
             adam(s.p[i], s.m[i], s.v[i], gw, ac);
           }
         }
-        if (!ex) continue;
+        if (!ex) { s.g_theta[t] = 0.f; s.g_xy[t * 2 + 0] = 0.f; s.g_xy[t * 2 + 1] = 0.f; continue; }
         float gth = 0.f, gr6[6] = {0, 0, 0, 0, 0, 0};
-        orient_base_bwd(s.theta[e], L.r6, o, g_ob, gth, gr6);
-        s.g_theta[e] = gth;
-        s.g_xy[e * 2 + 0] = s.g_tw[t * 3 + 0];
-        s.g_xy[e * 2 + 1] = s.g_tw[t * 3 + 1];
+        orient_base_bwd(s.theta[t], L.r6, o, g_ob, gth, gr6);
+        s.g_theta[t] = gth;
+        s.g_xy[t * 2 + 0] = s.g_tw[t * 3 + 0];
+        s.g_xy[t * 2 + 1] = s.g_tw[t * 3 + 1];
         // local_rot / local_z: gradient is final here (+ regularisers loss_func.py:189-237)
-        for (int k = 0; k < 6; ++k) {
-          const int i = l.local_rot + e * 6 + k;
-          const float r = s.p[i] * FPS;
-          if (on(GLAMR_LOSS_LOCAL_ROT_REG)) lsum[GLAMR_LOSS_LOCAL_ROT_REG] += r * r;
-          const float g = gr6[k] + 2.0f * FPS * r * w_rot;
-          if (update && (st.var_mask & GLAMR_VAR_LOCAL_ROT)) { if (sc.store_grad) s.g[i] = g; adam(s.p[i], s.m[i], s.v[i], g, ac); }
+        {
+          float g6r[6];
+          for (int k = 0; k < 6; ++k) {
+            const float r = s.p[l.local_rot + e * 6 + k] * FPS;
+            if (on(GLAMR_LOSS_LOCAL_ROT_REG)) lsum[GLAMR_LOSS_LOCAL_ROT_REG] += r * r;
+            g6r[k] = gr6[k] + 2.0f * FPS * r * w_rot;
+          }
+          if (update && (st.var_mask & GLAMR_VAR_LOCAL_ROT)) adam_block<6>(s.p, s.m, s.v, sc.store_grad ? s.g : nullptr, l.local_rot + e * 6, g6r, ac);
         }
         {
           const int i = l.local_z + e;
@@ -839,60 +945,64 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           if (update && (st.var_mask & GLAMR_VAR_LOCAL_Z)) { if (sc.store_grad) s.g[i] = g; adam(s.p[i], s.m[i], s.v[i], g, ac); }
         }
       }
-    }
-    rt.sync();
     if (update) {
-      for (int p = 0; p < P; ++p) {
-        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
-        rt.scan(sc.ps[p].g_xy, n, 2, true);
-        rt.scan(sc.ps[p].g_xy + 1, n, 2, true);
-      }
-      // ---- I: reverse of B ----------------------------------------------------------------------------------------------
-      for (int p = 0; p < P; ++p) {
-        PersonState& s = sc.ps[p];
-        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
-        for (int e = rt.tid(); e < n; e += rt.nthreads()) {
-          // contribution of d[e+1] = Rot(theta[e]) L[e+1].xy to g_theta[e]
-          if (e + 1 < n) {
-            const LocalRow Ln = local_row(sc, p, e + 1);
-            const float th = s.theta[e], cs = cosf(th), sn = sinf(th);
-            const float gdx = s.g_xy[(e + 1) * 2 + 0], gdy = s.g_xy[(e + 1) * 2 + 1];
-            s.g_theta[e] += gdx * (-Ln.dx * sn - Ln.dy * cs) + gdy * (Ln.dx * cs - Ln.dy * sn);
-          }
-        }
+      {
+        float* ch[16];
+        for (int p = 0; p < P; ++p) { ch[2 * p] = sc.ps[p].g_xy; ch[2 * p + 1] = sc.ps[p].g_xy + 1; }
+        rt.scan_multi(ch, 2 * P, T, 2, true);
       }
       rt.sync();
-      for (int p = 0; p < P; ++p) {
-        PersonState& s = sc.ps[p];
-        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
-        for (int e = rt.tid(); e < n; e += rt.nthreads()) {
-          float gx = s.g_xy[e * 2 + 0], gy = s.g_xy[e * 2 + 1];
+      // ---- I: reverse of B ----------------------------------------------------------------------------------------------
+      for (int t = rt.tid(); t < T; t += rt.nthreads())
+        for (int p = 0; p < P; ++p) {
+          const PersonConst& c = sc.pc[p];
+          PersonState& s = sc.ps[p];
+          if (t < c.fr_start || t >= c.fr_end) continue;
+          const int e = t - c.fr_start, n = c.fr_end - c.fr_start;
+          // contribution of d[e+1] = Rot(theta[e]) L[e+1].xy to g_theta[e]
+          if (e + 1 < n) {
+            const LocalRow Ln = load_row(s.Lc, sc.TM, t + 1);
+            const float th = s.theta[t];
+            float cs, sn;
+            rm::sincos_(th, sn, cs);
+            const float gdx = s.g_xy[(t + 1) * 2 + 0], gdy = s.g_xy[(t + 1) * 2 + 1];
+            s.g_theta[t] += gdx * (-Ln.dx * sn - Ln.dy * cs) + gdy * (Ln.dx * cs - Ln.dy * sn);
+          }
+          float gx = s.g_xy[t * 2 + 0], gy = s.g_xy[t * 2 + 1];
           if (e > 0) {
-            const float th = s.theta[e - 1], cs = cosf(th), sn = sinf(th);
+            const float th = s.theta[t - 1];
+            float cs, sn;
+            rm::sincos_(th, sn, cs);
             const float a = gx * cs + gy * sn, b = -gx * sn + gy * cs;
             gx = a; gy = b;
           }
+          const float g[2] = {gx, gy};
           if (e == 0) {
-            if (st.var_mask & GLAMR_VAR_LOCAL_XY) {
-              const float g[2] = {gx, gy};
+            if (st.var_mask & GLAMR_VAR_LOCAL_XY)
               for (int k = 0; k < 2; ++k) { const int i = l.local_xy + k; if (sc.store_grad) s.g[i] = g[k]; adam(s.p[i], s.m[i], s.v[i], g[k], ac); }
-            }
           } else {
-            const float g[2] = {gx, gy};
+            float g2[2];
             for (int k = 0; k < 2; ++k) {
-              const int i = l.local_dxy + e * 2 + k;
-              const float r = s.p[i] * FPS;
+              const float r = s.p[l.local_dxy + e * 2 + k] * FPS;
               if (on(GLAMR_LOSS_LOCAL_DXY_REG)) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r;
-              const float gt = g[k] + 2.0f * FPS * r * w_dxy;
-              if (st.var_mask & GLAMR_VAR_LOCAL_DXY) { if (sc.store_grad) s.g[i] = gt; adam(s.p[i], s.m[i], s.v[i], gt, ac); }
+              g2[k] = g[k] + 2.0f * FPS * r * w_dxy;
             }
+            if (st.var_mask & GLAMR_VAR_LOCAL_DXY) adam_block<2>(s.p, s.m, s.v, sc.store_grad ? s.g : nullptr, l.local_dxy + e * 2, g2, ac);
           }
         }
-        rt.sync();
-        rt.scan(s.g_theta, n, 1, true);
-        // ---- J: reverse of A ----------------------------------------------------------------------------------------------
-        for (int e = rt.tid(); e < n; e += rt.nthreads()) {
-          const float gh = s.g_theta[e];
+      {
+        float* ch[8];
+        for (int p = 0; p < P; ++p) ch[p] = sc.ps[p].g_theta;
+        rt.scan_multi(ch, P, T, 1, true);
+      }
+      // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
+      for (int t = rt.tid(); t < T; t += rt.nthreads())
+        for (int p = 0; p < P; ++p) {
+          const PersonConst& c = sc.pc[p];
+          PersonState& s = sc.ps[p];
+          if (t < c.fr_start || t >= c.fr_end) continue;
+          const int e = t - c.fr_start;
+          const float gh = s.g_theta[t];
           if (e == 0) {
             if (st.var_mask & GLAMR_VAR_LOCAL_HEADING) { const int i = l.local_heading; if (sc.store_grad) s.g[i] = gh; adam(s.p[i], s.m[i], s.v[i], gh, ac); }
           } else {
@@ -900,12 +1010,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
             const float v = s.p[i];
             if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
             if (!(st.var_mask & GLAMR_VAR_LOCAL_DHEADING)) continue;
-            const float g = (sc.pc[p].dheading_mask ? gh * sc.pc[p].dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cosf(v) - 1.0f) * (-sinf(v)) + sinf(v) * cosf(v)) * w_dh;
+            const float g = (c.dheading_mask ? gh * c.dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cosf(v) - 1.0f) * (-sinf(v)) + sinf(v) * cosf(v)) * w_dh;
             if (sc.store_grad) s.g[i] = g;
             adam(s.p[i], s.m[i], s.v[i], g, ac);
           }
         }
-      }
     }
     // regulariser values that do not depend on being optimised (reported every evaluation)
     if (last) {
@@ -938,8 +1047,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         o[GLAMR_LOSS_CAM_UP_REG] = tot[GLAMR_LOSS_CAM_UP_REG] / n_up;
       }
     }
-    rt.sync();
   }
+  rt.sync();
 }
 
 }  // namespace grecon

@@ -197,7 +197,7 @@ __global__ void masked_mean_kernel(const float* ctx, int max_len, const int* len
 // local trajectory -> global translation / orientation for one sequence per workgroup (traj_utils.py:65-88 + quat->aa)
 __global__ __launch_bounds__(256) void traj_to_global_kernel(const float* raw, int ldraw, int max_len, const int* lens, float* local, float* trans,
                                                              float* orient, float* scratch) {
-  __shared__ float red[32];
+  __shared__ float red[RT_RED_FLOATS];
   DeviceRT rt{red};
   const int b = blockIdx.x, n = lens[b];
   float* L = local + (size_t)b * max_len * 11;

@@ -20,6 +20,12 @@
 namespace glamr {
 namespace rm {
 
+// sine and cosine of the same angle (kept as two calls: the device sincosf writes through pointers and measured slower)
+GLAMR_HD void sincos_(float x, float& s, float& c) {
+  s = sinf(x);
+  c = cosf(x);
+}
+
 // ---- elementary pieces ---------------------------------------------------------------------------------------------
 
 // torch_safe_atan2: y += eps where |y| < eps and |x| < eps
@@ -261,8 +267,10 @@ GLAMR_HD void aa_to_quat(const float aa[3], float q[4], float eps = 1e-6f) {
   const float th = sqrt_clamped(th2, eps);
   const float half = th * 0.5f;
   const bool pos = th2 > 0.0f;
-  const float k = pos ? sdiv(sinf(half), th, eps) : 0.5f;
-  q[0] = pos ? cosf(half) : 1.0f;
+  float sh, ch;
+  sincos_(half, sh, ch);
+  const float k = pos ? sdiv(sh, th, eps) : 0.5f;
+  q[0] = pos ? ch : 1.0f;
   q[1] = aa[0] * k; q[2] = aa[1] * k; q[3] = aa[2] * k;
 }
 GLAMR_HD void aa_to_quat_bwd(const float aa[3], const float gq[4], float gaa[3], float eps = 1e-6f) {
@@ -270,7 +278,8 @@ GLAMR_HD void aa_to_quat_bwd(const float aa[3], const float gq[4], float gaa[3],
   const float th = sqrt_clamped(th2, eps);
   const float half = th * 0.5f;
   const bool pos = th2 > 0.0f;
-  const float sh = sinf(half), ch = cosf(half);
+  float sh, ch;
+  sincos_(half, sh, ch);
   const float k = pos ? sdiv(sh, th, eps) : 0.5f;
   for (int i = 0; i < 3; ++i) gaa[i] += gq[1 + i] * k;
   if (pos) {
@@ -292,7 +301,9 @@ GLAMR_HD void aa_to_rotmat_k(const float aa[3], float R[9]) {
     const float th = sqrtf(th2);
     const float inv = 1.0f / (th + 1e-6f);
     const float wx = aa[0] * inv, wy = aa[1] * inv, wz = aa[2] * inv;
-    const float c = cosf(th), s = sinf(th), k = 1.0f - c;
+    float c, s;
+    sincos_(th, s, c);
+    const float k = 1.0f - c;
     R[0] = c + wx * wx * k;       R[1] = wx * wy * k - wz * s;  R[2] = wy * s + wx * wz * k;
     R[3] = wz * s + wx * wy * k;  R[4] = c + wy * wy * k;       R[5] = -wx * s + wy * wz * k;
     R[6] = -wy * s + wx * wz * k; R[7] = wx * s + wy * wz * k;  R[8] = c + wz * wz * k;
@@ -308,7 +319,9 @@ GLAMR_HD void aa_to_rotmat_k_bwd(const float aa[3], const float g[9], float gaa[
     const float th = sqrtf(th2);
     const float den = th + 1e-6f, inv = 1.0f / den;
     const float w[3] = {aa[0] * inv, aa[1] * inv, aa[2] * inv};
-    const float c = cosf(th), s = sinf(th), k = 1.0f - c;
+    float c, s;
+    sincos_(th, s, c);
+    const float k = 1.0f - c;
     float gww = 0.f;                                  // sum_ij g_ij w_i w_j
     float gw[3] = {0.f, 0.f, 0.f};
     for (int i = 0; i < 3; ++i)
@@ -339,7 +352,9 @@ GLAMR_HD void aa_to_rotmat_s(const float r[3], float R[9]) {
   const float angle = sqrtf(ax * ax + ay * ay + az * az);
   const float inv = 1.0f / angle;
   const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
-  const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+  float s, cc;
+  sincos_(angle, s, cc);
+  const float c1 = 1.0f - cc;
   R[0] = 1.0f + c1 * (-(y * y + z * z)); R[1] = s * (-z) + c1 * (x * y);        R[2] = s * (y) + c1 * (x * z);
   R[3] = s * (z) + c1 * (x * y);         R[4] = 1.0f + c1 * (-(x * x + z * z)); R[5] = s * (-x) + c1 * (y * z);
   R[6] = s * (-y) + c1 * (x * z);        R[7] = s * (x) + c1 * (y * z);         R[8] = 1.0f + c1 * (-(x * x + y * y));
@@ -348,7 +363,9 @@ GLAMR_HD void aa_to_rotmat_s_bwd(const float r[3], const float gR[9], float gr[3
   const float ax = r[0] + 1e-8f, ay = r[1] + 1e-8f, az = r[2] + 1e-8f;
   const float angle = sqrtf(ax * ax + ay * ay + az * az), inv = 1.0f / angle;
   const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
-  const float s = sinf(angle), c = cosf(angle), c1 = 1.0f - c;
+  float s, c;
+  sincos_(angle, s, c);
+  const float c1 = 1.0f - c;
   const float K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
   const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
   float g_s = 0.f, g_c1 = 0.f;

@@ -10,6 +10,9 @@ struct HostRT {
   int nthreads() const { return 1; }
   void sync() const {}
   float reduce_sum(float v) const { return v; }
+  void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) const {
+    for (int c = 0; c < nch; ++c) scan(ch[c], n, stride, reverse);
+  }
   void scan(float* a, int n, int stride, bool reverse) const {
     if (!reverse) { for (int i = 1; i < n; ++i) a[(size_t)i * stride] += a[(size_t)(i - 1) * stride]; }
     else { for (int i = n - 2; i >= 0; --i) a[(size_t)i * stride] += a[(size_t)(i + 1) * stride]; }
