@@ -102,6 +102,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
 
+    from glamr_amd import parallel
     from glamr_amd.utils import synth
     if rank == 0:
         asset_root = ensure_assets()
@@ -112,7 +113,7 @@ def main():
     md = synth.make_smpl_model()
     B = args.batch
     # every rank works on its own sequences: seeds rank*B .. rank*B + B - 1 (independent units, no data-path collective)
-    in_dicts = [synth.make_in_dict(seed=rank * B + i, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md) for i in range(B)]
+    in_dicts = [synth.make_in_dict(seed=sd, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md) for sd in parallel.weak_scaling_seeds(B, rank)]
 
     def step():
         return model.optimize_batch(in_dicts)
@@ -131,10 +132,7 @@ def main():
         dist.barrier()
     elapsed = time.time() - t0
     tm = dict(model.timings)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(elapsed, dev)
 
     if rank == 0:
         iters = sum(s['opt_niters'] for s in model.opt_stage_specs.values())

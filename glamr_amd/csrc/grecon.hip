@@ -12,7 +12,10 @@
 namespace glamr {
 namespace grecon {
 
-constexpr int MAX_THREADS = 512;
+#ifndef GLAMR_GRECON_MAX_THREADS
+#define GLAMR_GRECON_MAX_THREADS 512
+#endif
+constexpr int MAX_THREADS = GLAMR_GRECON_MAX_THREADS;
 
 struct KernelArgs {
   glamr_scene_batch b;
