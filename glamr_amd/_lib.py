@@ -27,6 +27,14 @@ class SceneBatch(Structure):
                                         'kp_2d_pred', 'orient_cam_in_world')]
 
 
+class RawBatch(Structure):
+    _fields_ = [('n_slots', c_int32), ('max_len', c_int32)] + [(n, c_void_p) for n in ('seq_len', 'exist', 'rotmats', 'betas', 'root_trans', 'kp_2d')]
+
+
+class PersonArrays(Structure):
+    _fields_ = [(n, c_void_p) for n in ('visible_orig', 'smpl_pose', 'smpl_beta', 'trans_cam', 'nets_pose', 'nets_vis')]
+
+
 class ParamLayout(Structure):
     _fields_ = [(n, c_int32) for n in ('scene_stride', 'cam_rot6d', 'cam_trans', 'cam_inv_rot_res', 'cam_inv_trans_res',
                                        'person_stride', 'person0', 'local_xy', 'local_dxy', 'local_heading', 'local_dheading',
@@ -47,6 +55,10 @@ _SIGNATURES = {
     'glamr_nets_destroy': (c_int, [c_void_p]),
     'glamr_nets_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
     'glamr_nets_infer': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
+    'glamr_init_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'glamr_init_prepare': (c_int, [POINTER(RawBatch), POINTER(SceneBatch), POINTER(PersonArrays), c_int, c_void_p, c_void_p]),
+    'glamr_init_scenes': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays)] + [c_void_p] * 6),
+    'glamr_init_cam_all_frames': (c_int, [POINTER(SceneBatch), c_void_p]),
     'glamr_grecon_param_layout': (c_int, [c_int, c_int, POINTER(ParamLayout)]),
     'glamr_grecon_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'glamr_grecon_run_stage': (c_int, [POINTER(SceneBatch), POINTER(StageDesc), c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,428 @@
+// Device-side GlobalReconOptimizer.init_data (global_recon/models/global_recon_model.py:76-248): everything between the HybrIK wire
+// format and the first optimisation stage that the reference does with numpy / scipy / torch on the host, as three small kernels,
+// so a batch of sequences never returns to the host between upload and result.
+//
+//   prep_person_kernel   one workgroup per person: first/last detection, rotation matrices -> axis-angle (nearest rotation, the
+//                        scipy Rotation.from_matrix semantics :105-108), linear inter/extrapolation over undetected frames with
+//                        scipy interp1d's bracketing and float32 arithmetic (:132-136), 24 -> 26 keypoint remap with binary
+//                        scores (:118-123), filter_pose (:250-271, one thread: sequential and data dependent), masks,
+//                        identity-camera world pose (:141-144), inputs of the motion priors (:356-359)
+//   init_scene_kernel    one workgroup per scene, after the priors: scatter of their outputs (:370-392), person transforms and
+//                        relative transforms (:166-183), initial camera from the first person (:294-317), heading initialisation
+//                        from the camera with separately interpolated heading / local orientation (:273-292, traj_utils.py:120-141)
+//   cam_all_frames_kernel  init_cam_pose(all_frames=True) (:243-244, :304-317) incl. its zero matrices where the first person is unseen
+#include "common.hpp"
+#include "rotmath.hpp"
+
+namespace glamr {
+namespace init {
+
+constexpr int NJ = 26;
+// (body26fk index, smpl index) pairs whose joint names coincide (lib/utils/joints.py through global_recon_model.py:82-85)
+__constant__ int kMapDst[14] = {8, 5, 2, 21, 23, 25, 7, 4, 1, 20, 22, 24, 6, 0};
+__constant__ int kMapSrc[14] = {8, 5, 2, 17, 19, 21, 7, 4, 1, 16, 18, 20, 12, 0};
+
+// nearest rotation of an approximately orthogonal 3x3 (polar factor by Newton steps in double), then quaternion -> rotation
+// vector with the positive-w convention: equals scipy Rotation.from_matrix(M).as_rotvec() to double round-off
+__device__ void rotmat_to_rotvec_nearest(const float* Mf, float out[3]) {
+  double X[9];
+  for (int i = 0; i < 9; ++i) X[i] = Mf[i];
+  for (int it = 0; it < 3; ++it) {
+    const double a = X[0], b = X[1], c = X[2], d = X[3], e = X[4], f = X[5], g = X[6], h = X[7], i = X[8];
+    const double C[9] = {e * i - f * h, f * g - d * i, d * h - e * g, c * h - b * i, a * i - c * g, b * g - a * h, b * f - c * e, c * d - a * f, a * e - b * d};
+    const double det = a * C[0] + b * C[1] + c * C[2];
+    for (int k = 0; k < 9; ++k) X[k] = 0.5 * (X[k] + C[k] / det);
+  }
+  const double m00 = X[0], m11 = X[4], m22 = X[8], tr = m00 + m11 + m22;
+  double q[4];   // x y z w
+  int choice = 3;
+  double best = tr;
+  if (m00 > best) { best = m00; choice = 0; }
+  if (m11 > best) { best = m11; choice = 1; }
+  if (m22 > best) { best = m22; choice = 2; }
+  if (choice == 3) {
+    q[0] = X[7] - X[5]; q[1] = X[2] - X[6]; q[2] = X[3] - X[1]; q[3] = 1 + tr;
+  } else {
+    const int i_ = choice, j_ = (choice + 1) % 3, k_ = (choice + 2) % 3;
+    q[i_] = 1 - tr + 2 * X[i_ * 3 + i_];
+    q[j_] = X[j_ * 3 + i_] + X[i_ * 3 + j_];
+    q[k_] = X[k_ * 3 + i_] + X[i_ * 3 + k_];
+    q[3] = X[k_ * 3 + j_] - X[j_ * 3 + k_];
+  }
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; ++k) q[k] /= n;
+  if (q[3] < 0) for (int k = 0; k < 4; ++k) q[k] = -q[k];
+  const double s = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  const double angle = 2 * atan2(s, q[3]);
+  const double a2 = angle * angle;
+  const double scale = (angle <= 1e-3) ? (2 + a2 / 12 + 7 * a2 * a2 / 2880) : angle / sin(angle / 2);
+  for (int k = 0; k < 3; ++k) out[k] = (float)(q[k] * scale);
+}
+
+// scipy interp1d(kind='linear', assume_sorted, fill_value='extrapolate') bracket of frame t among the frames with flag != 0
+__device__ void bracket(const float* flag, int T, int first, int last, int t, int& lo, int& hi) {
+  lo = t - 1;
+  while (lo >= 0 && flag[lo] == 0.f) --lo;
+  if (lo < 0) lo = first;                      // t <= first flagged frame: first two points
+  if (lo == last) {                            // t beyond the last flagged frame: last two points
+    hi = last;
+    lo = last - 1;
+    while (flag[lo] == 0.f) --lo;
+    return;
+  }
+  hi = lo + 1;
+  while (flag[hi] == 0.f) ++hi;
+}
+__device__ __forceinline__ float lerp_f32(float ylo, float yhi, int lo, int hi, int t) {      // float32 abscissae (:134-135)
+  const float slope = (yhi - ylo) / (float)(hi - lo);
+  return slope * (float)(t - lo) + ylo;
+}
+__device__ __forceinline__ float lerp_f64(float ylo, float yhi, int lo, int hi, int t) {      // integer abscissae promote to double
+  const double slope = ((double)yhi - (double)ylo) / (double)(hi - lo);                        // (traj_utils.py:130-135)
+  return (float)(slope * (double)(t - lo) + (double)ylo);
+}
+
+struct PrepArgs {
+  int T;                       // padded frames per slot
+  const int32_t* seq_len;      // (slots) frames actually present
+  const float* exist; const float* rotmats; const float* betas; const float* root_trans; const float* kp24;
+  int filter_pose;
+  // outputs
+  float* visible_orig; float* visible; float* pose; float* beta; float* orient_cam; float* trans_cam;
+  float* kp26; float* score; float* base_orient; float* base_trans; int32_t* fr_start; int32_t* fr_end;
+  float* nets_pose; float* nets_vis;
+  float* scratch;              // (slots, T, 72 + 2)
+};
+
+__global__ __launch_bounds__(256) void prep_person_kernel(PrepArgs a) {
+  __shared__ int s_first, s_last, s_nvis;
+  const int slot = blockIdx.x, T = a.T, n_fr = a.seq_len[slot];
+  const size_t o1 = (size_t)slot * T;
+  const float* exist = a.exist + o1;
+  float* aa_raw = a.scratch + o1 * 74;                 // [T][72]
+  float* jumpf = a.scratch + o1 * 74 + (size_t)T * 72; // [T]
+  float* vis = a.visible + o1;
+  if (threadIdx.x == 0) { s_first = T; s_last = -1; s_nvis = 0; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float e = (t < n_fr) ? exist[t] : 0.f;
+    a.visible_orig[o1 + t] = e;
+    vis[t] = e;
+    if (e != 0.f) {
+      atomicMin(&s_first, t);
+      atomicMax(&s_last, t);
+      atomicAdd(&s_nvis, 1);
+      for (int j = 0; j < 24; ++j) rotmat_to_rotvec_nearest(a.rotmats + ((o1 + t) * 24 + j) * 9, aa_raw + (size_t)t * 72 + j * 3);
+    }
+  }
+  __syncthreads();
+  const int first = s_first, last = s_last;
+  if (s_nvis < 2) {            // an empty slot (scene with fewer persons than the batch maximum): outputs stay zero
+    if (threadIdx.x == 0) { a.fr_start[slot] = 0; a.fr_end[slot] = 1; }
+    return;
+  }
+  const bool all_vis = (s_nvis == n_fr);
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float pose[72], beta[10], tr[3];
+    if (t >= n_fr) {
+      for (int k = 0; k < 72; ++k) pose[k] = 0.f;
+      for (int k = 0; k < 10; ++k) beta[k] = 0.f;
+      for (int k = 0; k < 3; ++k) tr[k] = 0.f;
+    } else if (all_vis) {
+      for (int k = 0; k < 72; ++k) pose[k] = aa_raw[(size_t)t * 72 + k];
+      for (int k = 0; k < 10; ++k) beta[k] = a.betas[(o1 + t) * 10 + k];
+      for (int k = 0; k < 3; ++k) tr[k] = a.root_trans[(o1 + t) * 3 + k];
+    } else {
+      int lo, hi;
+      bracket(exist, n_fr, first, last, t, lo, hi);
+      for (int k = 0; k < 72; ++k) pose[k] = lerp_f32(aa_raw[(size_t)lo * 72 + k], aa_raw[(size_t)hi * 72 + k], lo, hi, t);
+      for (int k = 0; k < 10; ++k) beta[k] = lerp_f32(a.betas[(o1 + lo) * 10 + k], a.betas[(o1 + hi) * 10 + k], lo, hi, t);
+      for (int k = 0; k < 3; ++k) tr[k] = lerp_f32(a.root_trans[(o1 + lo) * 3 + k], a.root_trans[(o1 + hi) * 3 + k], lo, hi, t);
+    }
+    for (int k = 0; k < 69; ++k) a.pose[(o1 + t) * 69 + k] = pose[3 + k];
+    for (int k = 0; k < 10; ++k) a.beta[(o1 + t) * 10 + k] = beta[k];
+    for (int k = 0; k < 3; ++k) { a.orient_cam[(o1 + t) * 3 + k] = pose[k]; a.trans_cam[(o1 + t) * 3 + k] = tr[k]; }
+    // identity initial camera: world := camera frame; the orientation goes through aa -> R -> quat -> aa (transform_rot :142)
+    float R[9], ob[3];
+    rm::aa_to_rotmat_k(pose, R);
+    rm::rotmat_to_aa(R, ob);
+    for (int k = 0; k < 3; ++k) { a.base_orient[(o1 + t) * 3 + k] = ob[k]; a.base_trans[(o1 + t) * 3 + k] = tr[k]; }
+    // 24 SMPL keypoints -> 26 body26fk slots with binary scores, zero on undetected frames
+    float* kp = a.kp26 + (o1 + t) * NJ * 2;
+    float* sc = a.score + (o1 + t) * NJ;
+    for (int j = 0; j < NJ; ++j) { kp[j * 2] = 0.f; kp[j * 2 + 1] = 0.f; sc[j] = 0.f; }
+    if (t < n_fr && exist[t] != 0.f)
+      for (int m = 0; m < 14; ++m) {
+        kp[kMapDst[m] * 2 + 0] = a.kp24[((o1 + t) * 24 + kMapSrc[m]) * 2 + 0];
+        kp[kMapDst[m] * 2 + 1] = a.kp24[((o1 + t) * 24 + kMapSrc[m]) * 2 + 1];
+        sc[kMapDst[m]] = 1.0f;
+      }
+  }
+  __syncthreads();
+  // filter_pose: frames whose root orientation jumps by more than 60 degrees
+  if (a.filter_pose) {
+    for (int t = threadIdx.x + 1; t < n_fr; t += blockDim.x) {
+      float q1[4], q0[4], qc[4], d[4];
+      rm::aa_to_quat(a.orient_cam + (o1 + t) * 3, q1);
+      rm::aa_to_quat(a.orient_cam + (o1 + t - 1) * 3, q0);
+      qc[0] = q0[0]; qc[1] = -q0[1]; qc[2] = -q0[2]; qc[3] = -q0[3];
+      rm::quat_mul(q1, qc, d);
+      float sarg = 2.0f * d[0] * d[0] - 1.0f;
+      sarg = fminf(fmaxf(sarg, -1.0f + 1e-6f), 1.0f - 1e-6f);
+      jumpf[t] = (acosf(sarg) > 1.0471975511965976f && vis[t] != 0.f) ? 1.f : 0.f;
+    }
+    if (threadIdx.x == 0) jumpf[0] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int i = 1; i < n_fr; ++i) {
+        if (jumpf[i] == 0.f) continue;
+        if (vis[i - 1] != 0.f) {
+          if (i + 1 < n_fr && vis[i + 1] != 0.f && jumpf[i + 1] == 0.f) vis[i - 1] = 0.f;
+          else vis[i] = 0.f;
+        }
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { a.fr_start[slot] = first; a.fr_end[slot] = last + 1; }
+  // inputs of the motion priors: existing frames shifted to row 0, pose zeroed outside them (all of [first, last] exists)
+  const int n = last + 1 - first;
+  for (int e = threadIdx.x; e < T; e += blockDim.x) {
+    const bool ok = e < n;
+    for (int k = 0; k < 69; ++k) a.nets_pose[(o1 + e) * 69 + k] = ok ? a.pose[(o1 + first + e) * 69 + k] : 0.f;
+    a.nets_vis[o1 + e] = ok ? vis[first + e] : 0.f;
+  }
+}
+
+struct SceneInitArgs {
+  glamr_scene_batch b;
+  const float* trans_cam;      // (slots, T, 3)
+  float* smpl_pose;            // (slots, T, 69)
+  const float* n_pose; const float* n_local; const float* n_trans; const float* n_orient;   // prior outputs, rows [0, n)
+  float* scratch;              // (slots, T, 8 + 16)
+};
+
+__device__ void person_transform(const float aa[3], const float tr[3], float M[12]) {
+  float R[9];
+  rm::aa_to_rotmat_k(aa, R);
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = tr[i]; }
+}
+__device__ void inv34(const float M[12], float O[12]) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) O[i * 4 + j] = M[j * 4 + i];
+    O[i * 4 + 3] = -(M[3] * M[i] + M[7] * M[4 + i] + M[11] * M[8 + i]);
+  }
+}
+__device__ void mul34(const float A[12], const float B[12], float C[12]) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) C[i * 4 + j] = A[i * 4 + 0] * B[j] + A[i * 4 + 1] * B[4 + j] + A[i * 4 + 2] * B[8 + j];
+    C[i * 4 + 3] += A[i * 4 + 3];
+  }
+}
+// re-orthonormalise the rotation block through the 6D representation (rot6d_to_rotmat(rotmat_to_rot6d(.)) :315)
+__device__ void reortho(float M[12]) {
+  const float d6[6] = {M[0], M[4], M[8], M[1], M[5], M[9]};
+  float R[9];
+  rm::rot6d_to_rotmat(d6, R);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j];
+}
+// quaternion_to_rotation_matrix (kornia: normalises first)
+__device__ void quat_to_rotmat(const float q_[4], float R[9]) {
+  const float n = fmaxf(sqrtf(q_[0] * q_[0] + q_[1] * q_[1] + q_[2] * q_[2] + q_[3] * q_[3]), 1e-12f);
+  const float w = q_[0] / n, x = q_[1] / n, y = q_[2] / n, z = q_[3] / n;
+  const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+  R[0] = 1.f - (ty * y + tz * z); R[1] = ty * x - tz * w; R[2] = tz * x + ty * w;
+  R[3] = ty * x + tz * w; R[4] = 1.f - (tx * x + tz * z); R[5] = tz * y - tx * w;
+  R[6] = tz * x - ty * w; R[7] = tz * y + tx * w; R[8] = 1.f - (tx * x + ty * y);
+}
+
+__global__ __launch_bounds__(256) void init_scene_kernel(SceneInitArgs a) {
+  __shared__ int s_start;
+  __shared__ float s_caminv[12];
+  const glamr_scene_batch& b = a.b;
+  const int si = blockIdx.x, T = b.max_len, MP = b.max_persons, P = b.n_persons[si], n_fr = b.seq_len[si];
+  const float base[4] = {0.5f, 0.5f, 0.5f, 0.5f}, basec[4] = {0.5f, -0.5f, -0.5f, -0.5f};
+  float* vis_w = const_cast<float*>(b.vis);
+  // ---- scatter of the prior outputs into video-frame positions; person transforms --------------------------------------------
+  for (int p = 0; p < P; ++p) {
+    const size_t slot = (size_t)si * MP + p, o1 = slot * T;
+    const int fs = b.fr_start[slot], n = b.fr_end[slot] - fs;
+    float* prior = const_cast<float*>(b.traj_local_pred) + o1 * 11;
+    float* bo = const_cast<float*>(b.base_orient) + o1 * 3;
+    float* bt = const_cast<float*>(b.base_trans) + o1 * 3;
+    float* p2c = const_cast<float*>(b.person2cam) + o1 * 12;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const int e = t - fs;
+      if (e >= 0 && e < n) {
+        for (int k = 0; k < 69; ++k) a.smpl_pose[(o1 + t) * 69 + k] = a.n_pose[(o1 + e) * 69 + k];
+        for (int k = 0; k < 3; ++k) { bo[t * 3 + k] = a.n_orient[(o1 + e) * 3 + k]; bt[t * 3 + k] = a.n_trans[(o1 + e) * 3 + k]; }
+      }
+      if (t < n) for (int k = 0; k < 11; ++k) prior[t * 11 + k] = a.n_local[(o1 + t) * 11 + k];
+      else for (int k = 0; k < 11; ++k) prior[t * 11 + k] = 0.f;
+      float Tc[12], inv[12];
+      person_transform(b.orient_cam + (o1 + t) * 3, a.trans_cam + (o1 + t) * 3, Tc);
+      inv34(Tc, inv);
+      for (int k = 0; k < 12; ++k) p2c[t * 12 + k] = inv[k];
+    }
+  }
+  if (threadIdx.x == 0) s_start = T;
+  __syncthreads();
+  // ---- relative transforms between persons in the camera frame (:178-183); first frame anybody is seen in -----------------------
+  for (int t = threadIdx.x; t < n_fr; t += blockDim.x) {
+    bool any = false;
+    for (int p = 0; p < P; ++p) any = any || vis_w[((size_t)si * MP + p) * T + t] != 0.f;
+    if (any) atomicMin(&s_start, t);
+    if (P > 1 && b.rel_transform_cam)
+      for (int i = 0; i < P; ++i)
+        for (int j = 0; j < P; ++j) {
+          if (i == j) continue;
+          float Ti[12], Tj[12], Ii[12], R[12];
+          person_transform(b.orient_cam + (((size_t)si * MP + i) * T + t) * 3, a.trans_cam + (((size_t)si * MP + i) * T + t) * 3, Ti);
+          person_transform(b.orient_cam + (((size_t)si * MP + j) * T + t) * 3, a.trans_cam + (((size_t)si * MP + j) * T + t) * 3, Tj);
+          inv34(Ti, Ii);
+          mul34(Ii, Tj, R);
+          float* dst = const_cast<float*>(b.rel_transform_cam) + ((((size_t)si * MP + i) * MP + j) * T + t) * 12;
+          for (int k = 0; k < 12; ++k) dst[k] = R[k];
+        }
+  }
+  __syncthreads();
+  // ---- initial camera: the FIRST person's world pose composed with its person->camera transform at the start frame (:294-317) ---
+  if (threadIdx.x == 0) {
+    const size_t o1 = (size_t)si * MP * T;         // person 0
+    const int st = s_start;
+    float Tw[12], C[12];
+    person_transform(b.base_orient + (o1 + st) * 3, b.base_trans + (o1 + st) * 3, Tw);
+    mul34(Tw, b.person2cam + (o1 + st) * 12, C);
+    const float v = vis_w[o1 + st];
+    for (int k = 0; k < 12; ++k) C[k] *= v;          // a zero matrix when person 0 is not the one seen first (bug-compatible)
+    reortho(C);
+    for (int k = 0; k < 12; ++k) s_caminv[k] = C[k];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float M[12];
+    inv34(s_caminv, M);
+    for (int k = 0; k < 12; ++k) b.cam_pose[((size_t)si * T + t) * 12 + k] = M[k];
+  }
+  // ---- heading of the trajectory prior from the camera (:273-292) -------------------------------------------------------------------
+  for (int p = 0; p < P; ++p) {
+    const size_t slot = (size_t)si * MP + p, o1 = slot * T;
+    const int fs = b.fr_start[slot], n = b.fr_end[slot] - fs;
+    const float* vis = vis_w + o1;
+    float* hv = a.scratch + o1 * 24;                 // [T][8]: heading vec (2) + local 6d (6) at visible frames
+    float* hh = hv + (size_t)T * 8;                  // [T]: heading of the interpolated orientation
+    float* wt = hh + T;                              // unused spare
+    (void)wt;
+    __shared__ int s_fv, s_lv;
+    if (threadIdx.x == 0) { s_fv = T; s_lv = -1; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_fr; t += blockDim.x) {
+      if (vis[t] == 0.f) continue;
+      atomicMin(&s_fv, t);
+      atomicMax(&s_lv, t);
+      float Tc[12], W[12], R[9], q[4], qb[4];
+      person_transform(b.orient_cam + (o1 + t) * 3, a.trans_cam + (o1 + t) * 3, Tc);
+      mul34(s_caminv, Tc, W);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i * 3 + j] = W[i * 4 + j];
+      rm::rotmat_to_quat(R, q);
+      rm::quat_mul(q, basec, qb);
+      const float h = 2.0f * rm::atan2s(qb[3], qb[0]);
+      const float nn = fmaxf(sqrtf(qb[0] * qb[0] + qb[3] * qb[3]), 1e-9f);
+      const float hqc[4] = {qb[0] / nn, 0.f, 0.f, -qb[3] / nn};
+      float lq[4], Rl[9];
+      rm::quat_mul(hqc, qb, lq);
+      quat_to_rotmat(lq, Rl);
+      hv[t * 8 + 0] = cosf(h); hv[t * 8 + 1] = sinf(h);
+      for (int r = 0; r < 3; ++r) { hv[t * 8 + 2 + r] = Rl[r * 3 + 0]; hv[t * 8 + 5 + r] = Rl[r * 3 + 1]; }
+    }
+    __syncthreads();
+    const int fv = s_fv, lv = s_lv;
+    for (int t = threadIdx.x; t < n_fr; t += blockDim.x) {
+      int lo, hi;
+      bracket(vis, n_fr, fv, lv, t, lo, hi);
+      float v8[8];
+      for (int k = 0; k < 8; ++k) v8[k] = lerp_f64(hv[lo * 8 + k], hv[hi * 8 + k], lo, hi, t);
+      float hq[4], R[9], lq[4], q1[4], qi[4], qb[4];
+      rm::heading_quat(rm::atan2s(v8[1], v8[0]), hq);
+      rm::rot6d_to_rotmat(v8 + 2, R);
+      rm::rotmat_to_quat(R, lq);
+      rm::quat_mul(hq, lq, q1);
+      rm::quat_mul(q1, base, qi);
+      rm::quat_mul(qi, basec, qb);                  // traj_global2local_heading removes the base orientation again
+      hh[t] = 2.0f * rm::atan2s(qb[3], qb[0]);
+    }
+    __syncthreads();
+    float* prior = const_cast<float*>(b.traj_local_pred) + o1 * 11;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      const int t = fs + e;
+      const float dh = (t == 0) ? hh[0] : hh[t] - hh[t - 1];
+      prior[e * 11 + 9] = cosf(dh);
+      prior[e * 11 + 10] = sinf(dh);
+    }
+    __syncthreads();
+  }
+}
+
+// init_cam_pose(all_frames=True): camera-to-world per frame from the first person where it is seen, zeros elsewhere
+__global__ void cam_all_frames_kernel(glamr_scene_batch b) {
+  const int si = blockIdx.x, T = b.max_len, MP = b.max_persons;
+  const size_t o1 = (size_t)si * MP * T;
+  for (int t = threadIdx.x; t < b.seq_len[si]; t += blockDim.x) {
+    float Tw[12], C[12], M[12];
+    person_transform(b.orient_world + (o1 + t) * 3, b.trans_world + (o1 + t) * 3, Tw);
+    mul34(Tw, b.person2cam + (o1 + t) * 12, C);
+    const float v = b.vis[o1 + t];
+    bool any = false;
+    for (int p = 0; p < b.n_persons[si]; ++p) any = any || b.vis[o1 + (size_t)p * T + t] != 0.f;
+    // frames nobody is seen in keep the +0 of zeros_like (:301-302); frames where only OTHER persons are seen get the signed zeros of
+    // the product with vis_frames (:297) -- the sign of these zeros decides atan2 branches downstream, so it is part of the contract
+    for (int k = 0; k < 12; ++k) C[k] = any ? C[k] * v : 0.f;
+    reortho(C);
+    inv34(C, M);
+    for (int k = 0; k < 12; ++k) b.cam_pose[((size_t)si * T + t) * 12 + k] = M[k];
+  }
+}
+
+}  // namespace init
+}  // namespace glamr
+
+using namespace glamr;
+using namespace glamr::init;
+
+extern "C" size_t glamr_init_workspace_bytes(int n_slots, int max_len) {
+  if (n_slots <= 0 || max_len <= 0) return 0;
+  return (size_t)n_slots * max_len * 74 * sizeof(float);
+}
+
+extern "C" int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, int filter_pose,
+                                  void* workspace, void* stream_) {
+  GLAMR_REQUIRE(raw && batch && pa && workspace, "null argument");
+  GLAMR_REQUIRE(raw->n_slots == batch->n_scenes * batch->max_persons && raw->max_len == batch->max_len, "raw batch and scene batch disagree on geometry");
+  GLAMR_REQUIRE(raw->seq_len && raw->exist && raw->rotmats && raw->betas && raw->root_trans && raw->kp_2d, "a raw input array is NULL");
+  GLAMR_REQUIRE(pa->visible_orig && pa->smpl_pose && pa->smpl_beta && pa->trans_cam && pa->nets_pose && pa->nets_vis, "a person array is NULL");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PrepArgs a{raw->max_len, raw->seq_len, raw->exist, raw->rotmats, raw->betas, raw->root_trans, raw->kp_2d, filter_pose,
+             pa->visible_orig, const_cast<float*>(batch->vis), pa->smpl_pose, pa->smpl_beta, const_cast<float*>(batch->orient_cam), pa->trans_cam,
+             const_cast<float*>(batch->kp_2d), const_cast<float*>(batch->kp_score), const_cast<float*>(batch->base_orient),
+             const_cast<float*>(batch->base_trans), const_cast<int32_t*>(batch->fr_start), const_cast<int32_t*>(batch->fr_end),
+             pa->nets_pose, pa->nets_vis, static_cast<float*>(workspace)};
+  hipLaunchKernelGGL(prep_person_kernel, dim3(raw->n_slots), dim3(256), 0, stream, a);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
+                                 const float* nets_local_traj, const float* nets_trans, const float* nets_orient, void* workspace, void* stream_) {
+  GLAMR_REQUIRE(batch && pa && nets_pose_out && nets_local_traj && nets_trans && nets_orient && workspace, "null argument");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SceneInitArgs a{*batch, pa->trans_cam, pa->smpl_pose, nets_pose_out, nets_local_traj, nets_trans, nets_orient, static_cast<float*>(workspace)};
+  hipLaunchKernelGGL(init_scene_kernel, dim3(batch->n_scenes), dim3(256), 0, stream, a);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_init_cam_all_frames(const glamr_scene_batch* batch, void* stream_) {
+  GLAMR_REQUIRE(batch, "null argument");
+  hipLaunchKernelGGL(cam_all_frames_kernel, dim3(batch->n_scenes), dim3(256), 0, static_cast<hipStream_t>(stream_), *batch);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}

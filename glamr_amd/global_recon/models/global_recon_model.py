@@ -196,8 +196,9 @@ class GlobalReconOptimizer:
     # ------------------------------------------------------------------------------------------------------------------------
     # batched pipeline
     # ------------------------------------------------------------------------------------------------------------------------
-    def init_data_batch(self, in_dicts, latents=None):
-        """Host preprocessing + ONE batched prior inference + scene initialisation.  latents: optional list (per sequence) of
+    def init_data_batch_host(self, in_dicts, latents=None):
+        """Host-side variant of init_data_batch (numpy; kept for cam_fix_frames other than the default and as a cross-check):
+        host preprocessing + ONE batched prior inference + scene initialisation.  latents: optional list (per sequence) of
         {person idx: {'motion': (n_windows,128), 'traj': (1,128)}} replacing the Gaussian draws."""
         t0 = time.time()
         dev = self.device
@@ -265,6 +266,177 @@ class GlobalReconOptimizer:
         self.timings.update(host_pre=t1 - t0, priors=t2 - t1, host_init=t3 - t2, lbs_pack_init=time.time() - t3)
         return datas, packed
 
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # device pipeline: the host only scatters the HybrIK arrays to their frame rows (pose_est/hybrik_demo/demo.py:317-354 layout)
+    # ------------------------------------------------------------------------------------------------------------------------
+    def init_data_batch(self, in_dicts, latents=None):
+        """init_data (:76-248) for a batch of sequences.  Returns (datas, packed): `datas` are light per-sequence dictionaries that
+        are completed from the device arrays when the optimisation has finished (or immediately by init_data())."""
+        if self.cam_fix_frames != [(0, None)]:
+            return self.init_data_batch_host(in_dicts, latents)
+        import ctypes
+        t0 = time.time()
+        dev, L = self.device, _lib.lib()
+        S = len(in_dicts)
+        ids = [list(d['est'].keys()) for d in in_dicts]
+        P = max(len(x) for x in ids)
+        Ts = [len(d['est'][i[0]]['bboxes_dict']['exist']) for d, i in zip(in_dicts, ids)]
+        T = max(Ts)
+        if P > 8:
+            raise NotImplementedError('at most 8 persons per scene')
+        n_slots = S * P
+        h = dict(exist=np.zeros((n_slots, T), np.float32), rot=np.zeros((n_slots, T, 216), np.float32), betas=np.zeros((n_slots, T, 10), np.float32),
+                 trans=np.zeros((n_slots, T, 3), np.float32), kp=np.zeros((n_slots, T, 48), np.float32), K=np.zeros((n_slots, T, 9), np.float32))
+        seq_len_slot = np.zeros(n_slots, np.int32)
+        lens = np.full(n_slots, 11, np.int32)
+        exists = {}
+        for si, d in enumerate(in_dicts):
+            for pi, idx in enumerate(ids[si]):
+                src = d['est'][idx]
+                k = si * P + pi
+                ex = np.asarray(src['bboxes_dict']['exist'])
+                vi = np.flatnonzero(ex)
+                exists[(si, idx)] = ex
+                seq_len_slot[k] = ex.shape[0]
+                lens[k] = vi[-1] + 1 - vi[0]
+                h['exist'][k, :ex.shape[0]] = ex
+                h['rot'][k, vi] = src['smpl_pose_quat_wroot'].reshape(len(vi), 216)
+                h['betas'][k, vi] = src['smpl_beta']
+                h['trans'][k, vi] = src['root_trans']
+                h['kp'][k, vi] = src['kp_2d'][:, :24].reshape(len(vi), 48)
+                h['K'][k, vi] = src['cam_K'].reshape(len(vi), 9)
+        t1 = time.time()
+        g = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
+        packed = packing.PackedScenes.empty(S, P, T, dev)
+        packed.person_ids = ids
+        packed.t['cam_K'] = g['K']
+        packed.t['n_persons'] = torch.tensor([len(x) for x in ids], dtype=torch.int32, device=dev)
+        packed.t['seq_len'] = torch.tensor(Ts, dtype=torch.int32, device=dev)
+        seq_len_dev = torch.from_numpy(seq_len_slot).to(dev)
+        f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        pa_t = dict(visible_orig=f32(n_slots, T), smpl_pose=f32(n_slots, T, 69), smpl_beta=f32(n_slots, T, 10), trans_cam=f32(n_slots, T, 3),
+                    nets_pose=f32(n_slots, T, 69), nets_vis=f32(n_slots, T))
+        # the cached joints are produced in place by the skinning kernel: keep a placeholder until then
+        packed.t['j_local'] = f32(1)
+        raw = _lib.RawBatch()
+        raw.n_slots, raw.max_len = n_slots, T
+        for name, ten in (('seq_len', seq_len_dev), ('exist', g['exist']), ('rotmats', g['rot']), ('betas', g['betas']), ('root_trans', g['trans']), ('kp_2d', g['kp'])):
+            setattr(raw, name, ctypes.c_void_p(ten.data_ptr()))
+        pa = _lib.PersonArrays()
+        for name, ten in pa_t.items():
+            setattr(pa, name, ctypes.c_void_p(ten.data_ptr()))
+        sb = packed.struct()
+        ws = torch.empty(L.glamr_init_workspace_bytes(n_slots, T), dtype=torch.uint8, device=dev)
+        st = _lib.current_stream()
+        _lib.check(L.glamr_init_prepare(ctypes.byref(raw), ctypes.byref(sb), ctypes.byref(pa), int(self.flag_filter_pose), _lib.ptr(ws), st))
+        # motion priors on every person of every sequence in one call
+        nw = num_windows(int(lens.max()))
+        if latents is not None:
+            meps = np.zeros((n_slots, nw, NZ), np.float32)
+            teps = np.zeros((n_slots, NZ), np.float32)
+            for si in range(S):
+                for pi, idx in enumerate(ids[si]):
+                    m = np.asarray(latents[si][idx]['motion'], np.float32)
+                    meps[si * P + pi, :m.shape[0]] = m
+                    teps[si * P + pi] = np.asarray(latents[si][idx]['traj'], np.float32).reshape(-1)
+            meps, teps = torch.from_numpy(meps).to(dev), torch.from_numpy(teps).to(dev)
+        else:
+            meps, teps = torch.randn((n_slots, nw, NZ), device=dev), torch.randn((n_slots, NZ), device=dev)
+        out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], lens, meps, teps)
+        _lib.check(L.glamr_init_scenes(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
+                                       _lib.ptr(out['orient']), _lib.ptr(ws), st))
+        # root-relative joints of every frame, cached for the whole optimisation (SURVEY.md App. B step 8)
+        zeros = f32(n_slots * T, 3)
+        with torch.no_grad():
+            jl = self.smpl(global_orient=zeros, body_pose=pa_t['smpl_pose'].view(-1, 69), betas=pa_t['smpl_beta'].view(-1, 10), root_trans=zeros,
+                           return_verts=False).joints
+        packed.t['j_local'] = jl.view(n_slots, T, 26, 3)
+        self._run(packed, self._forward_only_desc())
+        if self.flag_init_cam_all_frames:
+            sb = packed.struct()
+            _lib.check(L.glamr_init_cam_all_frames(ctypes.byref(sb), st))
+            self._run(packed, self._forward_only_desc())
+        packed.person_arrays = pa_t
+        packed.exists = exists
+        packed.keepalive = (g, ws, out, seq_len_dev)
+        datas = [{'seq_name': d['seq_name'], 'seq_len': Ts[si], 'gt': d.get('gt', {}), 'gt_meta': d.get('gt_meta', {}),
+                  'meta': {'algo': 'global_recon', 'num_fr': Ts[si]}, '_pending': True} for si, d in enumerate(in_dicts)]
+        self.timings.update(host_pre=t1 - t0, priors=0.0, host_init=0.0, lbs_pack_init=time.time() - t1)
+        return datas, packed
+
+    def _materialise(self, datas, packed, stage_vars):
+        """Builds the reference-style output dictionaries (numpy) from the device arrays: ONE device->host copy per array."""
+        P, T, l = packed.P, packed.T, packed.layout
+        names = ('fr_start', 'fr_end', 'vis', 'kp_2d', 'kp_score', 'cam_K', 'traj_local_pred', 'orient_cam', 'base_orient', 'base_trans', 'person2cam',
+                 'cam_pose', 'params', 'orient_world', 'trans_world', 'kp_2d_pred', 'orient_cam_in_world')
+        h = packed.fetch(names)
+        pa = {k: v.cpu().numpy() for k, v in packed.person_arrays.items() if k not in ('nets_pose', 'nets_vis')}
+        rel = packed.t['rel_transform_cam'].cpu().numpy() if 'rel_transform_cam' in packed.t else None
+        eye_row = np.array([0, 0, 0, 1], np.float32)
+
+        def to44(m12):
+            out = np.zeros(m12.shape[:-1] + (4, 4), np.float32)
+            out[..., :3, :] = m12.reshape(m12.shape[:-1] + (3, 4))
+            out[..., 3, :] = eye_row
+            return out
+        for si, d in enumerate(datas):
+            Ts = d['seq_len']
+            persons = {}
+            for pi, idx in enumerate(packed.person_ids[si]):
+                k = si * P + pi
+                fs, fe = int(h['fr_start'][k]), int(h['fr_end'][k])
+                n = fe - fs
+                vis = h['vis'][k, :Ts]
+                visible = vis.astype(np.float64)
+                exist = np.zeros(Ts, bool)
+                exist[fs:fe] = True
+                pp = h['params'][si, l['person0'] + pi * l['person_stride']:l['person0'] + (pi + 1) * l['person_stride']]
+                pd = {
+                    'visible': visible, 'visible_orig': pa['visible_orig'][k, :Ts].astype(np.float64), 'fr_start': fs, 'fr_end': fe,
+                    'exist_frames': exist, 'exist_len': n, 'max_len': Ts, 'frames': np.arange(Ts), 'vis_frames': vis == 1, 'invis_frames': vis == 0,
+                    'frame2ind': {f: f for f in range(Ts)}, 'scale': None,
+                    'smpl_pose': pa['smpl_pose'][k, :Ts], 'smpl_beta': pa['smpl_beta'][k, :Ts], 'smpl_orient_cam': h['orient_cam'][k, :Ts],
+                    'root_trans_cam': pa['trans_cam'][k, :Ts], 'kp_2d': h['kp_2d'][k, :Ts].astype(np.float64),
+                    'kp_2d_score': h['kp_score'][k, :Ts].astype(np.float64), 'kp_2d_aligned': h['kp_2d'][k, :Ts].astype(np.float64),
+                    'cam_K': h['cam_K'][k, :Ts].reshape(Ts, 3, 3), 'infilled': True, 'traj_predicted': True,
+                    'traj_local_pred': h['traj_local_pred'][k, :n], 'smpl_orient_world_base': h['base_orient'][k, :Ts],
+                    'root_trans_world_base': h['base_trans'][k, :Ts], 'person2cam': to44(h['person2cam'][k, :Ts]),
+                    'smpl_orient_world': h['orient_world'][k, :Ts], 'root_trans_world': h['trans_world'][k, :Ts],
+                    'kp_2d_pred': h['kp_2d_pred'][k, :Ts], 'smpl_orient_cam_in_world': h['orient_cam_in_world'][k, :Ts],
+                    'traj_local_xy': pp[l['local_xy']:l['local_xy'] + 2].copy(), 'traj_local_heading': pp[l['local_heading']:l['local_heading'] + 1].copy(),
+                    'traj_local_dxy': pp[l['local_dxy']:l['local_dxy'] + 2 * T].reshape(T, 2)[1:n].copy(),
+                    'traj_local_dheading': pp[l['local_dheading']:l['local_dheading'] + T][1:n].copy(),
+                    'traj_local_z': pp[l['local_z']:l['local_z'] + T][:n].copy(),
+                    'traj_local_rot': pp[l['local_rot']:l['local_rot'] + 6 * T].reshape(T, 6)[:n].copy(),
+                }
+                if 'world_dheading' in stage_vars:
+                    pd['world_dheading'] = pp[l['world_dheading']:l['world_dheading'] + T][:Ts, None].copy()
+                persons[idx] = pd
+            cam = to44(h['cam_pose'][si, :Ts])
+            d['person_data'] = persons
+            d['cam_pose'] = cam
+            d['cam_pose_inv'] = nt.invert_transform(cam)
+            d['fr_num_persons'] = sum(p_['vis_frames'].astype(np.int64) for p_ in persons.values())
+            prm = h['params'][si]
+            if 'cam' in stage_vars:
+                r6 = prm[l['cam_rot6d']:l['cam_rot6d'] + 6 * T].reshape(T, 6)
+                tr = prm[l['cam_trans']:l['cam_trans'] + 3 * T].reshape(T, 3)
+                if self.specs.get('flag_fixed_cam', False):
+                    d['cam_rot_6d_fix'], d['cam_trans_fix'] = r6[:1].copy(), tr[:1].copy()
+                else:
+                    d['cam_rot_6d'], d['cam_trans'] = r6[:Ts].copy(), tr[:Ts].copy()
+            empty = np.where(d['fr_num_persons'] == 0)[0]
+            d['cam_inv_rot_residual'] = prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].reshape(T, 6)[empty].copy()
+            d['cam_inv_trans_residual'] = prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].reshape(T, 3)[:Ts].copy()
+            if rel is not None:
+                npers = len(packed.person_ids[si])
+                d['rel_transform_cam'] = {(i, j): to44(rel[si, i, j, :Ts]) for i in range(npers) for j in range(npers) if i != j}
+            else:
+                d['rel_transform_cam'] = {}
+            d.pop('_pending', None)
+        return datas
+
     @staticmethod
     def _to_torch(data):
         def conv(x):
@@ -314,8 +486,11 @@ class GlobalReconOptimizer:
             self.kernel_ms.extend(a.elapsed_time(b) for a, b in events)
         t0 = time.time()
         packed.has_world_dheading = has_wd
-        packed.unpack_into(datas, {'opt_variables': sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))} if last_spec else None,
-                           self.specs, as_torch=False)
+        all_vars = sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))
+        if datas and datas[0].get('_pending'):
+            self._materialise(datas, packed, all_vars)
+        else:
+            packed.unpack_into(datas, {'opt_variables': all_vars} if last_spec else None, self.specs, as_torch=False)
         self.last_losses = packed.t['losses'].cpu().numpy()
         outs = datas
         self.timings['unpack'] = time.time() - t0
@@ -333,7 +508,9 @@ class GlobalReconOptimizer:
 
     # -- reference entry points ---------------------------------------------------------------------------------------------------
     def init_data(self, in_dict, latents=None):
-        datas, _ = self.init_data_batch([in_dict], None if latents is None else [latents])
+        datas, packed = self.init_data_batch([in_dict], None if latents is None else [latents])
+        if datas[0].get('_pending'):
+            self._materialise(datas, packed, [])
         return datas[0]
 
     def optimize(self, in_dict, continue_opt=False, latents=None, max_iters=None):

@@ -82,6 +82,27 @@ class PackedScenes:
 
     INT_FIELDS = ('n_persons', 'seq_len', 'fr_start', 'fr_end')
 
+    @classmethod
+    def empty(cls, n_scenes, max_persons, max_len, device, with_rel=None):
+        """All arrays allocated (zero) directly on `device`; the init kernels fill them (glamr_init_prepare / glamr_init_scenes)."""
+        self = cls.__new__(cls)
+        S, P, T = n_scenes, max_persons, max_len
+        self.device, self.S, self.P, self.T = device, S, P, T
+        self.layout = param_layout_py(P, T)
+        f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
+        i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=device)
+        self.t = dict(n_persons=i32(S), seq_len=i32(S), fr_start=i32(S * P), fr_end=i32(S * P), vis=f32(S * P, T), j_local=None,
+                      kp_2d=f32(S * P, T, NJ, 2), kp_score=f32(S * P, T, NJ), cam_K=f32(S * P, T, 9), traj_local_pred=f32(S * P, T, 11),
+                      orient_cam=f32(S * P, T, 3), base_orient=f32(S * P, T, 3), base_trans=f32(S * P, T, 3), person2cam=f32(S * P, T, 12),
+                      cam_pose=f32(S, T, 12), params=f32(S, self.layout['scene_stride']), losses=f32(S, _lib.NUM_LOSSES),
+                      orient_world=f32(S * P, T, 3), trans_world=f32(S * P, T, 3), kp_2d_pred=f32(S * P, T, NJ, 2),
+                      orient_cam_in_world=f32(S * P, T, 3))
+        if P > 1 if with_rel is None else with_rel:
+            self.t['rel_transform_cam'] = f32(S, P, P, T, 12)
+        self.person_ids = None
+        self.has_world_dheading = False
+        return self
+
     def __init__(self, datas, j_locals, device, cam_fix_frames=((0, None),)):
         """datas: list of `data` dicts (one per sequence); j_locals: list (per scene) of dict idx -> (T,26,3) joints computed
         with zero root orientation and zero root translation."""

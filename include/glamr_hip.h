@@ -200,6 +200,43 @@ size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len);
 int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out,
                            void* workspace, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Device-side init_data -- replaces GlobalReconOptimizer.init_data (global_recon_model.py:76-248) between the HybrIK wire format
+ * (pose_est/hybrik_demo/demo.py:317-354) and the first optimisation stage.  The host only scatters the per-detection arrays to
+ * their video-frame rows; everything else (rotation matrices -> axis-angle, gap interpolation, keypoint remap, filter_pose, masks,
+ * person / relative transforms, initial camera, heading initialisation) runs in three kernels.
+ * ------------------------------------------------------------------------------------------------------------------- */
+typedef struct glamr_raw_batch {
+  int32_t n_slots, max_len;              /* n_slots = n_scenes * max_persons */
+  const int32_t* seq_len;                /* dev (n_slots) video frames of the slot's scene */
+  const float* exist;                    /* dev (n_slots, max_len) bboxes_dict['exist'] */
+  const float* rotmats;                  /* dev (n_slots, max_len, 24, 9) smpl_pose_quat_wroot rows at their frame positions */
+  const float* betas;                    /* dev (n_slots, max_len, 10) */
+  const float* root_trans;               /* dev (n_slots, max_len, 3) */
+  const float* kp_2d;                    /* dev (n_slots, max_len, 24, 2) first 24 HybrIK keypoints */
+} glamr_raw_batch;
+
+typedef struct glamr_person_arrays {     /* per-person state that is not an input of the optimiser kernel; all dev, written */
+  float* visible_orig;                   /* (n_slots, max_len) */
+  float* smpl_pose;                      /* (n_slots, max_len, 69) interpolated, then infilled on existing frames */
+  float* smpl_beta;                      /* (n_slots, max_len, 10) */
+  float* trans_cam;                      /* (n_slots, max_len, 3) root_trans_cam */
+  float* nets_pose;                      /* (n_slots, max_len, 69) rows [0, exist_len): input of glamr_nets_infer */
+  float* nets_vis;                       /* (n_slots, max_len) */
+} glamr_person_arrays;
+
+size_t glamr_init_workspace_bytes(int n_slots, int max_len);
+/* Fills vis, kp_2d, kp_score, orient_cam, base_orient, base_trans, fr_start, fr_end of `batch` (declared const there because the
+ * optimiser only reads them) and every array of `pa`.  cam_K is written by the host directly. */
+int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, int filter_pose,
+                       void* workspace, void* stream);
+/* After glamr_nets_infer: scatters its outputs, fills traj_local_pred, person2cam, rel_transform_cam, cam_pose of `batch`. */
+int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
+                      const float* nets_local_traj, const float* nets_trans, const float* nets_orient, void* workspace, void* stream);
+/* init_cam_pose(all_frames=True) (:243-244) from the orient_world / trans_world of the last forward pass. */
+int glamr_init_cam_all_frames(const glamr_scene_batch* batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
