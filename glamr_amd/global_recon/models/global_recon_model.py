@@ -40,6 +40,12 @@ def _cfg_parts(cfg):
     return cfg.grecon_model_specs, cfg.opt_stage_specs, getattr(cfg, 'id', 'glamr')
 
 
+class ResidentInputs:
+    """A batch of sequences in HBM as stage_inputs() leaves it: the HybrIK arrays on their frame rows (`g`), lengths, optional latent
+    draws, plus the host-side bookkeeping (person ids, sequence names) that never needs the device."""
+    pass
+
+
 class GlobalReconOptimizer:
 
     def __init__(self, cfg, device=torch.device('cuda'), log=None, smpl=None, mt_model=None, results_root='results'):
@@ -270,14 +276,11 @@ class GlobalReconOptimizer:
     # ------------------------------------------------------------------------------------------------------------------------
     # device pipeline: the host only scatters the HybrIK arrays to their frame rows (pose_est/hybrik_demo/demo.py:317-354 layout)
     # ------------------------------------------------------------------------------------------------------------------------
-    def init_data_batch(self, in_dicts, latents=None):
-        """init_data (:76-248) for a batch of sequences.  Returns (datas, packed): `datas` are light per-sequence dictionaries that
-        are completed from the device arrays when the optimisation has finished (or immediately by init_data())."""
-        if self.cam_fix_frames != [(0, None)]:
-            return self.init_data_batch_host(in_dicts, latents)
-        import ctypes
+    def stage_inputs(self, in_dicts, latents=None):
+        """Host dictionaries -> HBM: scatters the per-detection HybrIK arrays to their frame rows and uploads them (the ONLY
+        host->device traffic of a batch).  Returns a ResidentInputs; everything after this runs on device arrays."""
         t0 = time.time()
-        dev, L = self.device, _lib.lib()
+        dev = self.device
         S = len(in_dicts)
         ids = [list(d['est'].keys()) for d in in_dicts]
         P = max(len(x) for x in ids)
@@ -306,14 +309,41 @@ class GlobalReconOptimizer:
                 h['trans'][k, vi] = src['root_trans']
                 h['kp'][k, vi] = src['kp_2d'][:, :24].reshape(len(vi), 48)
                 h['K'][k, vi] = src['cam_K'].reshape(len(vi), 9)
+        rin = ResidentInputs()
+        rin.S, rin.P, rin.T, rin.Ts, rin.ids, rin.lens, rin.exists = S, P, T, Ts, ids, lens, exists
+        rin.g = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
+        rin.n_persons = torch.tensor([len(x) for x in ids], dtype=torch.int32, device=dev)
+        rin.seq_len = torch.tensor(Ts, dtype=torch.int32, device=dev)
+        rin.seq_len_slot = torch.from_numpy(seq_len_slot).to(dev)
+        rin.meps = rin.teps = None
+        if latents is not None:
+            nw = num_windows(int(lens.max()))
+            meps = np.zeros((n_slots, nw, NZ), np.float32)
+            teps = np.zeros((n_slots, NZ), np.float32)
+            for si in range(S):
+                for pi, idx in enumerate(ids[si]):
+                    m = np.asarray(latents[si][idx]['motion'], np.float32)
+                    meps[si * P + pi, :m.shape[0]] = m
+                    teps[si * P + pi] = np.asarray(latents[si][idx]['traj'], np.float32).reshape(-1)
+            rin.meps, rin.teps = torch.from_numpy(meps).to(dev), torch.from_numpy(teps).to(dev)
+        rin.meta = [{'seq_name': d['seq_name'], 'seq_len': Ts[si], 'gt': d.get('gt', {}), 'gt_meta': d.get('gt_meta', {})} for si, d in enumerate(in_dicts)]
+        self.timings['host_pre'] = time.time() - t0
+        return rin
+
+    def init_resident(self, rin):
+        """init_data (:76-248) on device-resident inputs: per-person preparation, motion priors, scene assembly, cached joints and
+        the 'init' forward pass -- kernel launches only, nothing crosses PCIe.  Returns (datas, packed): `datas` are light
+        per-sequence dictionaries that collect() completes from the device arrays."""
+        import ctypes
         t1 = time.time()
-        g = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
+        dev, L = self.device, _lib.lib()
+        S, P, T, g = rin.S, rin.P, rin.T, rin.g
+        n_slots = S * P
         packed = packing.PackedScenes.empty(S, P, T, dev)
-        packed.person_ids = ids
+        packed.person_ids = rin.ids
         packed.t['cam_K'] = g['K']
-        packed.t['n_persons'] = torch.tensor([len(x) for x in ids], dtype=torch.int32, device=dev)
-        packed.t['seq_len'] = torch.tensor(Ts, dtype=torch.int32, device=dev)
-        seq_len_dev = torch.from_numpy(seq_len_slot).to(dev)
+        packed.t['n_persons'] = rin.n_persons
+        packed.t['seq_len'] = rin.seq_len
         f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         pa_t = dict(visible_orig=f32(n_slots, T), smpl_pose=f32(n_slots, T, 69), smpl_beta=f32(n_slots, T, 10), trans_cam=f32(n_slots, T, 3),
                     nets_pose=f32(n_slots, T, 69), nets_vis=f32(n_slots, T))
@@ -321,7 +351,7 @@ class GlobalReconOptimizer:
         packed.t['j_local'] = f32(1)
         raw = _lib.RawBatch()
         raw.n_slots, raw.max_len = n_slots, T
-        for name, ten in (('seq_len', seq_len_dev), ('exist', g['exist']), ('rotmats', g['rot']), ('betas', g['betas']), ('root_trans', g['trans']), ('kp_2d', g['kp'])):
+        for name, ten in (('seq_len', rin.seq_len_slot), ('exist', g['exist']), ('rotmats', g['rot']), ('betas', g['betas']), ('root_trans', g['trans']), ('kp_2d', g['kp'])):
             setattr(raw, name, ctypes.c_void_p(ten.data_ptr()))
         pa = _lib.PersonArrays()
         for name, ten in pa_t.items():
@@ -331,19 +361,10 @@ class GlobalReconOptimizer:
         st = _lib.current_stream()
         _lib.check(L.glamr_init_prepare(ctypes.byref(raw), ctypes.byref(sb), ctypes.byref(pa), int(self.flag_filter_pose), _lib.ptr(ws), st))
         # motion priors on every person of every sequence in one call
-        nw = num_windows(int(lens.max()))
-        if latents is not None:
-            meps = np.zeros((n_slots, nw, NZ), np.float32)
-            teps = np.zeros((n_slots, NZ), np.float32)
-            for si in range(S):
-                for pi, idx in enumerate(ids[si]):
-                    m = np.asarray(latents[si][idx]['motion'], np.float32)
-                    meps[si * P + pi, :m.shape[0]] = m
-                    teps[si * P + pi] = np.asarray(latents[si][idx]['traj'], np.float32).reshape(-1)
-            meps, teps = torch.from_numpy(meps).to(dev), torch.from_numpy(teps).to(dev)
-        else:
-            meps, teps = torch.randn((n_slots, nw, NZ), device=dev), torch.randn((n_slots, NZ), device=dev)
-        out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], lens, meps, teps)
+        nw = num_windows(int(rin.lens.max()))
+        meps = rin.meps if rin.meps is not None else torch.randn((n_slots, nw, NZ), device=dev)
+        teps = rin.teps if rin.teps is not None else torch.randn((n_slots, NZ), device=dev)
+        out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps)
         _lib.check(L.glamr_init_scenes(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
                                        _lib.ptr(out['orient']), _lib.ptr(ws), st))
         # root-relative joints of every frame, cached for the whole optimisation
@@ -358,12 +379,17 @@ class GlobalReconOptimizer:
             _lib.check(L.glamr_init_cam_all_frames(ctypes.byref(sb), st))
             self._run(packed, self._forward_only_desc())
         packed.person_arrays = pa_t
-        packed.exists = exists
-        packed.keepalive = (g, ws, out, seq_len_dev)
-        datas = [{'seq_name': d['seq_name'], 'seq_len': Ts[si], 'gt': d.get('gt', {}), 'gt_meta': d.get('gt_meta', {}),
-                  'meta': {'algo': 'global_recon', 'num_fr': Ts[si]}, '_pending': True} for si, d in enumerate(in_dicts)]
-        self.timings.update(host_pre=t1 - t0, priors=0.0, host_init=0.0, lbs_pack_init=time.time() - t1)
+        packed.exists = rin.exists
+        packed.keepalive = (rin, ws, out)
+        datas = [dict(m, meta={'algo': 'global_recon', 'num_fr': m['seq_len']}, _pending=True) for m in rin.meta]
+        self.timings.update(priors=0.0, host_init=0.0, lbs_pack_init=time.time() - t1)
         return datas, packed
+
+    def init_data_batch(self, in_dicts, latents=None):
+        """init_data (:76-248) for a batch of host dictionaries: stage_inputs + init_resident."""
+        if self.cam_fix_frames != [(0, None)]:
+            return self.init_data_batch_host(in_dicts, latents)
+        return self.init_resident(self.stage_inputs(in_dicts, latents))
 
     def _materialise(self, datas, packed, stage_vars):
         """Builds the reference-style output dictionaries (numpy) from the device arrays: ONE device->host copy per array."""
@@ -461,12 +487,10 @@ class GlobalReconOptimizer:
         ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=self.device)
         _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, _lib.ptr(ws), _lib.current_stream()))
 
-    def optimize_batch(self, in_dicts, latents=None, max_iters=None):
-        """`max_iters` caps the iterations of every stage (tests); None = the configured schedule."""
-        datas, packed = self.init_data_batch(in_dicts, latents)
-        t0 = time.time()
+    def run_schedule(self, packed, max_iters=None):
+        """The staged optimisation (:250-262) of an initialised batch: one kernel launch per stage, asynchronous on the current
+        stream.  `max_iters` caps the iterations of every stage (tests); None = the configured schedule."""
         has_wd = False
-        last_spec = None
         events = []
         for stage, spec in self.opt_stage_specs.items():
             sd = packing.stage_desc(spec, self.specs, has_world_dheading=has_wd,
@@ -477,24 +501,42 @@ class GlobalReconOptimizer:
             ev[1].record()
             events.append(ev)
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
-            last_spec = spec
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
-        torch.cuda.synchronize(self.device)
-        self.timings['optimise'] = time.time() - t0
-        if getattr(self, 'kernel_ms', None) is not None:
-            self.kernel_ms.extend(a.elapsed_time(b) for a, b in events)
-        t0 = time.time()
         packed.has_world_dheading = has_wd
+        packed.stage_events = events
+        return packed
+
+    def optimize_resident(self, rin, max_iters=None):
+        """HBM in, HBM out: init_data + the full schedule on a ResidentInputs batch.  Returns (datas, packed) with every result
+        (optimised variables, world trajectories, projections, camera) in packed.t on the device; collect() brings them to the host."""
+        datas, packed = self.init_resident(rin)
+        self.run_schedule(packed, max_iters)
+        return datas, packed
+
+    def collect(self, datas, packed):
+        """Device arrays -> the reference's output dictionaries (numpy): one device->host copy per array."""
+        torch.cuda.synchronize(self.device)
+        if getattr(self, 'kernel_ms', None) is not None and getattr(packed, 'stage_events', None):
+            self.kernel_ms.extend(a.elapsed_time(b) for a, b in packed.stage_events)
+        t0 = time.time()
         all_vars = sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))
         if datas and datas[0].get('_pending'):
             self._materialise(datas, packed, all_vars)
         else:
-            packed.unpack_into(datas, {'opt_variables': all_vars} if last_spec else None, self.specs, as_torch=False)
+            packed.unpack_into(datas, {'opt_variables': all_vars} if self.opt_stage_specs else None, self.specs, as_torch=False)
         self.last_losses = packed.t['losses'].cpu().numpy()
-        outs = datas
         self.timings['unpack'] = time.time() - t0
-        return outs
+        return datas
+
+    def optimize_batch(self, in_dicts, latents=None, max_iters=None):
+        """Host dictionaries in, host dictionaries out (optimize() of the reference for a batch of independent sequences)."""
+        datas, packed = self.init_data_batch(in_dicts, latents)
+        t0 = time.time()
+        self.run_schedule(packed, max_iters)
+        torch.cuda.synchronize(self.device)
+        self.timings['optimise'] = time.time() - t0
+        return self.collect(datas, packed)
 
     @staticmethod
     def _to_numpy(x):
