@@ -38,24 +38,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 }  // namespace glamr
 
-struct glamr_smpl {
-  int V, Vpad, num_betas, n_extra, n_picked, n_out, n_tiles, n_levels;
-  int n_extra_used;
-  // device constants
+// One tiling of a vertex set for the LBS kernel: 32-vertex tiles with their direction matrices, skinning weights, extra-joint
+// regressor columns and the picked vertices that fall into each tile.
+struct glamr_tileset {
+  int n_verts, n_tiles, Vpad;
   float* dirs_tiled;      // [n_tiles][3][32][KSTRIDE]
   float* w_tiled;         // [Vpad][24]
   float* jx_used;         // [n_extra_used][Vpad]
+  int32_t* pick_row;      // [n_picked] row inside the tile
+  int32_t* tile_pick_start;  // [n_tiles+1] CSR over picks sorted by tile
+  int32_t* tile_pick_ids;    // [n_picked] pick slot ids sorted by tile
+};
+
+struct glamr_smpl {
+  int V, num_betas, n_extra, n_picked, n_out, n_levels;
+  int n_extra_used;
+  glamr_tileset full;      // every vertex (vertices requested)
+  glamr_tileset joints;    // only the vertices the mapped joints depend on: picked vertices + the support of the used extra-regressor
+                           // rows (n_tiles == 0 when that is not a saving); used when only joints are requested
+  // device constants
   float* j_template;      // [24][3]
   float* j_shapedirs;     // [24][3][num_betas]
-  float* j_template_unshaped;  // [24][3]  (= j_template; kept separate for clarity of get_joints)
   int32_t* parents;       // [24]
   int32_t* level;         // [24]
   int32_t* joint_map;     // [n_out]
   int32_t* extra_slot;    // [MAX_EXTRA] -> slot in jx_used or -1
-  int32_t* pick_tile;     // [n_picked] tile index of each picked vertex
-  int32_t* pick_row;      // [n_picked] row inside the tile
-  int32_t* tile_pick_start;  // [n_tiles+1] CSR over picks sorted by tile
-  int32_t* tile_pick_ids;    // [n_picked] pick slot ids sorted by tile
 };
 
 namespace glamr {
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
 
   const float* myDirs = sDirs + (size_t)col * KSTRIDE + half * KH;
 
-  for (int ft = wave; ft < a.n_ftiles; ft += 4) {
+  for (int ft = blockIdx.y * 4 + wave; ft < a.n_ftiles; ft += 4 * gridDim.y) {
     const int b = ft * TILE_F + col;            // Bpad is a multiple of 32: always a readable row
     const float* frow = a.feat + (size_t)b * KTOT + half * KH;
     f32x16 px = {0}, py = {0}, pz = {0};
@@ -484,8 +491,6 @@ extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const f
   if (!h) return fail(GLAMR_E_NOMEM, "out of host memory");
   std::memset(h, 0, sizeof(*h));
   h->V = V; h->num_betas = num_betas; h->n_extra = n_extra; h->n_picked = n_picked; h->n_out = n_out;
-  h->n_tiles = (V + TILE_V - 1) / TILE_V;
-  h->Vpad = h->n_tiles * TILE_V;
 
   // tree levels
   std::vector<int32_t> level(NJ, 0);
@@ -510,23 +515,69 @@ extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const f
   h->n_extra_used = n_used;
   GLAMR_REQUIRE(n_used == 0 || J_regressor_extra, "joint_map references extra joints but J_regressor_extra is null");
 
-  // direction matrix, tiled: [tile][plane][row][KSTRIDE]; k: 0..9 shapedirs, 10..216 posedirs, 217 v_template
-  std::vector<float> dirs((size_t)h->n_tiles * 3 * TILE_V * KSTRIDE, 0.0f);
-  for (int v = 0; v < V; ++v) {
-    const int tile = v / TILE_V, row = v % TILE_V;
-    for (int r = 0; r < 3; ++r) {
-      float* d = &dirs[(((size_t)tile * 3 + r) * TILE_V + row) * KSTRIDE];
-      for (int l = 0; l < num_betas; ++l) d[l] = shapedirs[((size_t)v * 3 + r) * num_betas + l];
-      for (int k = 0; k < 207; ++k) d[10 + k] = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + r];
-      d[K_ONE] = v_template[(size_t)v * 3 + r];
+  // tilings: [tile][plane][row][KSTRIDE]; k: 0..9 shapedirs, 10..216 posedirs, 217 v_template
+  auto build_tileset = [&](glamr_tileset* ts, const std::vector<int32_t>& vids) -> int {
+    const int n = (int)vids.size();
+    ts->n_verts = n;
+    ts->n_tiles = (n + TILE_V - 1) / TILE_V;
+    ts->Vpad = ts->n_tiles * TILE_V;
+    std::vector<int32_t> pos(V, -1);
+    std::vector<float> dirs((size_t)ts->n_tiles * 3 * TILE_V * KSTRIDE, 0.0f);
+    std::vector<float> w((size_t)ts->Vpad * NJ, 0.0f);
+    std::vector<float> jx((size_t)std::max(1, n_used) * ts->Vpad, 0.0f);
+    for (int i = 0; i < n; ++i) {
+      const int v = vids[i], tile = i / TILE_V, row = i % TILE_V;
+      pos[v] = i;
+      for (int r = 0; r < 3; ++r) {
+        float* d = &dirs[(((size_t)tile * 3 + r) * TILE_V + row) * KSTRIDE];
+        for (int l = 0; l < num_betas; ++l) d[l] = shapedirs[((size_t)v * 3 + r) * num_betas + l];
+        for (int k = 0; k < 207; ++k) d[10 + k] = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + r];
+        d[K_ONE] = v_template[(size_t)v * 3 + r];
+      }
+      for (int j = 0; j < NJ; ++j) w[(size_t)i * NJ + j] = lbs_weights[(size_t)v * NJ + j];
+      for (int e = 0; e < n_extra; ++e)
+        if (extra_slot[e] >= 0) jx[(size_t)extra_slot[e] * ts->Vpad + i] = J_regressor_extra[(size_t)e * V + v];
+    }
+    // picked vertices sorted by tile (CSR)
+    std::vector<int32_t> pick_row(std::max(1, n_picked)), tstart(ts->n_tiles + 1, 0), tids(std::max(1, n_picked));
+    for (int p = 0; p < n_picked; ++p) {
+      const int i = pos[extra_vertex_ids[p]];
+      pick_row[p] = i % TILE_V;
+      tstart[i / TILE_V + 1]++;
+    }
+    for (int t = 0; t < ts->n_tiles; ++t) tstart[t + 1] += tstart[t];
+    {
+      std::vector<int32_t> cur(tstart.begin(), tstart.end() - 1);
+      for (int p = 0; p < n_picked; ++p) tids[cur[pos[extra_vertex_ids[p]] / TILE_V]++] = p;
+    }
+    int rc;
+    if ((rc = upload(&ts->dirs_tiled, dirs.data(), dirs.size()))) return rc;
+    if ((rc = upload(&ts->w_tiled, w.data(), w.size()))) return rc;
+    if ((rc = upload(&ts->jx_used, jx.data(), jx.size()))) return rc;
+    if ((rc = upload(&ts->pick_row, pick_row.data(), pick_row.size()))) return rc;
+    if ((rc = upload(&ts->tile_pick_start, tstart.data(), tstart.size()))) return rc;
+    if ((rc = upload(&ts->tile_pick_ids, tids.data(), tids.size()))) return rc;
+    return GLAMR_OK;
+  };
+  for (int p = 0; p < n_picked; ++p)
+    GLAMR_REQUIRE(extra_vertex_ids[p] >= 0 && extra_vertex_ids[p] < V, "extra_vertex_ids[%d] out of range", p);
+  int rc;
+  {
+    std::vector<int32_t> all(V);
+    for (int v = 0; v < V; ++v) all[v] = v;
+    if ((rc = build_tileset(&h->full, all))) return rc;
+    // vertices the mapped joints depend on
+    std::vector<char> need(V, 0);
+    for (int p = 0; p < n_picked; ++p) need[extra_vertex_ids[p]] = 1;
+    for (int e = 0; e < n_extra; ++e)
+      if (extra_slot[e] >= 0)
+        for (int v = 0; v < V; ++v) if (J_regressor_extra[(size_t)e * V + v] != 0.0f) need[v] = 1;
+    std::vector<int32_t> sub;
+    for (int v = 0; v < V; ++v) if (need[v]) sub.push_back(v);
+    if (!sub.empty() && sub.size() * 2 <= (size_t)V) {
+      if ((rc = build_tileset(&h->joints, sub))) return rc;
     }
   }
-  std::vector<float> w((size_t)h->Vpad * NJ, 0.0f);
-  for (int v = 0; v < V; ++v) for (int j = 0; j < NJ; ++j) w[(size_t)v * NJ + j] = lbs_weights[(size_t)v * NJ + j];
-  std::vector<float> jx((size_t)std::max(1, n_used) * h->Vpad, 0.0f);
-  for (int e = 0; e < n_extra; ++e)
-    if (extra_slot[e] >= 0)
-      for (int v = 0; v < V; ++v) jx[(size_t)extra_slot[e] * h->Vpad + v] = J_regressor_extra[(size_t)e * V + v];
   // rest joints and their shape derivatives (J = J_regressor (v_template + shapedirs beta) is linear in beta)
   std::vector<float> jt(NJ * 3), js((size_t)NJ * 3 * num_betas);
   for (int j = 0; j < NJ; ++j)
@@ -540,40 +591,23 @@ extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const f
         js[((size_t)j * 3 + c) * num_betas + l] = (float)q;
       }
     }
-  // picked vertices sorted by tile (CSR)
-  std::vector<int32_t> pick_row(std::max(1, n_picked)), tstart(h->n_tiles + 1, 0), tids(std::max(1, n_picked));
-  for (int p = 0; p < n_picked; ++p) {
-    GLAMR_REQUIRE(extra_vertex_ids[p] >= 0 && extra_vertex_ids[p] < V, "extra_vertex_ids[%d] out of range", p);
-    pick_row[p] = extra_vertex_ids[p] % TILE_V;
-    tstart[extra_vertex_ids[p] / TILE_V + 1]++;
-  }
-  for (int t = 0; t < h->n_tiles; ++t) tstart[t + 1] += tstart[t];
-  {
-    std::vector<int32_t> cur(tstart.begin(), tstart.end() - 1);
-    for (int p = 0; p < n_picked; ++p) tids[cur[extra_vertex_ids[p] / TILE_V]++] = p;
-  }
 
-  int rc;
-  if ((rc = upload(&h->dirs_tiled, dirs.data(), dirs.size()))) return rc;
-  if ((rc = upload(&h->w_tiled, w.data(), w.size()))) return rc;
-  if ((rc = upload(&h->jx_used, jx.data(), jx.size()))) return rc;
   if ((rc = upload(&h->j_template, jt.data(), jt.size()))) return rc;
   if ((rc = upload(&h->j_shapedirs, js.data(), js.size()))) return rc;
   if ((rc = upload(&h->parents, parents, (size_t)NJ))) return rc;
   if ((rc = upload(&h->level, level.data(), level.size()))) return rc;
   if ((rc = upload(&h->joint_map, joint_map, (size_t)n_out))) return rc;
   if ((rc = upload(&h->extra_slot, extra_slot.data(), extra_slot.size()))) return rc;
-  if ((rc = upload(&h->pick_row, pick_row.data(), pick_row.size()))) return rc;
-  if ((rc = upload(&h->tile_pick_start, tstart.data(), tstart.size()))) return rc;
-  if ((rc = upload(&h->tile_pick_ids, tids.data(), tids.size()))) return rc;
   *out = h;
   return GLAMR_OK;
 }
 
 extern "C" int glamr_smpl_destroy(glamr_smpl* h) {
   if (!h) return GLAMR_OK;
-  void* ptrs[] = {h->dirs_tiled, h->w_tiled, h->jx_used, h->j_template, h->j_shapedirs, h->parents, h->level, h->joint_map,
-                  h->extra_slot, h->pick_row, h->tile_pick_start, h->tile_pick_ids};
+  void* ptrs[] = {h->j_template, h->j_shapedirs, h->parents, h->level, h->joint_map, h->extra_slot,
+                  h->full.dirs_tiled, h->full.w_tiled, h->full.jx_used, h->full.pick_row, h->full.tile_pick_start, h->full.tile_pick_ids,
+                  h->joints.dirs_tiled, h->joints.w_tiled, h->joints.jx_used, h->joints.pick_row, h->joints.tile_pick_start,
+                  h->joints.tile_pick_ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return GLAMR_OK;
@@ -590,7 +624,7 @@ SmplWs smpl_ws_layout(const glamr_smpl* h, int B, char* base) {
   w.askin = take((size_t)w.Bpad * 12 * NJ);
   w.chain = take((size_t)w.Bpad * NJ * 3);
   w.picked = take((size_t)w.Bpad * std::max(1, h->n_picked) * 3);
-  w.partial = take((size_t)h->n_tiles * w.Bpad * std::max(1, h->n_extra_used) * 3);
+  w.partial = take((size_t)h->full.n_tiles * w.Bpad * std::max(1, h->n_extra_used) * 3);
   w.pivot = take((size_t)w.Bpad * 3);
   w.total = off;
   return w;
@@ -615,16 +649,22 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   }
   PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, w.askin, w.chain};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
-  LbsArgs la{B, h->V, h->n_tiles, w.Bpad / TILE_F, h->n_extra_used, h->n_picked, h->dirs_tiled, h->w_tiled, h->jx_used,
-             h->tile_pick_start, h->tile_pick_ids, h->pick_row, w.feat, w.askin, verts, w.picked, w.partial, w.Bpad};
+  const bool orig = (flags & GLAMR_SMPL_ORIG_JOINTS) != 0;
+  const glamr_tileset& ts = (!verts && h->joints.n_tiles > 0) ? h->joints : h->full;
+  const int n_ftiles = w.Bpad / TILE_F;
+  LbsArgs la{B, h->V, ts.n_tiles, n_ftiles, h->n_extra_used, h->n_picked, ts.dirs_tiled, ts.w_tiled, ts.jx_used,
+             ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, w.askin, verts, w.picked, w.partial, w.Bpad};
   const size_t lds = (size_t)(3 * TILE_V * KSTRIDE + (verts ? 4 * TILE_F * OUT_STRIDE : 0)) * sizeof(float);
+  // frame tiles are split over gridDim.y so that a launch has ~4 workgroups per CU even with few vertex tiles; every workgroup
+  // re-stages its 87 KB direction tile, so a chunk keeps >= 8 frame tiles per wave
+  int gy = std::max(1, std::min((1024 + ts.n_tiles - 1) / ts.n_tiles, n_ftiles / 32));
   auto launch = [&](auto kern) -> int {
     GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(h->n_tiles), dim3(256), lds, stream, la);
+    hipLaunchKernelGGL(kern, dim3(ts.n_tiles, gy), dim3(256), lds, stream, la);
     return GLAMR_OK;
   };
   int rc = GLAMR_OK;
-  switch (h->n_extra_used) {
+  if (verts || !orig) switch (h->n_extra_used) {
     case 0: rc = launch(smpl_lbs_kernel<0>); break;
     case 1: rc = launch(smpl_lbs_kernel<1>); break;
     case 2: rc = launch(smpl_lbs_kernel<2>); break;
@@ -633,7 +673,7 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
     default: return fail(GLAMR_E_UNSUPPORTED, "joint_map references %d extra-regressed joints (max 4 supported)", h->n_extra_used);
   }
   if (rc) return rc;
-  FinishArgs fa{B, w.Bpad, h->n_tiles, h->n_extra_used, h->n_picked, h->n_out, (flags & GLAMR_SMPL_ORIG_JOINTS) ? 1 : 0,
+  FinishArgs fa{B, w.Bpad, (verts || !orig) ? ts.n_tiles : 0, h->n_extra_used, h->n_picked, h->n_out, orig ? 1 : 0,
                 w.chain, w.picked, w.partial, h->joint_map, h->extra_slot, root_trans, root_scale, joints, w.pivot};
   hipLaunchKernelGGL(smpl_finish_kernel, dim3(B), dim3(64), 0, stream, fa);
   if (verts && root_trans)

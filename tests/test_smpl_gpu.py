@@ -56,11 +56,13 @@ def test_smpl_matches_oracle_full_mesh(models, B):
     assert out.vertices.shape == (B, 6890, 3) and out.joints.shape == (B, 26, 3)
     assert _err(out.joints, ref.joints) < TOL
     assert _err(out.vertices, ref.vertices) < TOL
-    # joints-only call (no vertex write-out) must give the same joints
+    # joints-only call: skins only the vertices the mapped joints depend on (a different summation grouping of the regressed
+    # joints, hence last-bit differences from the full-mesh call)
     j_only = mine(global_orient=pose[:, :3].to(dev), body_pose=pose[:, 3:].to(dev), betas=betas.to(dev), root_trans=trans.to(dev),
                   return_verts=False)
     assert j_only.vertices is None
-    assert _err(j_only.joints, out.joints) == 0.0
+    assert _err(j_only.joints, out.joints) < 2e-6
+    assert _err(j_only.joints, ref.joints) < TOL
 
 
 def test_smpl_rigid_root_identity_full_size(models):
