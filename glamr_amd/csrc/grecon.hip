@@ -99,3 +99,12 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }
+
+#ifdef GLAMR_PHASE_TIMING
+// development builds only: per-phase time of workgroup 0 in the last stage launch, in 10 ns ticks
+extern "C" int glamr_debug_phase_ticks(unsigned long long* out9) {
+  GLAMR_HIP_CHECK(hipDeviceSynchronize());
+  GLAMR_HIP_CHECK(hipMemcpyFromSymbol(out9, HIP_SYMBOL(glamr::g_phase_ticks), 9 * sizeof(unsigned long long)));
+  return GLAMR_OK;
+}
+#endif

@@ -22,6 +22,17 @@
 #include "rotmath.hpp"
 #include "../../include/glamr_hip.h"
 
+// phase timing (development builds only: -DGLAMR_PHASE_TIMING; tools/grecon_phases.py)
+#ifdef GLAMR_PHASE_TIMING
+#define GLAMR_MARK_BEGIN(rt) (rt).mark_begin()
+#define GLAMR_MARK(rt, k) (rt).template mark<k>()
+#define GLAMR_MARK_END(rt) (rt).mark_end()
+#else
+#define GLAMR_MARK_BEGIN(rt)
+#define GLAMR_MARK(rt, k)
+#define GLAMR_MARK_END(rt)
+#endif
+
 namespace glamr {
 namespace grecon {
 
@@ -48,9 +59,10 @@ struct PersonState {
   float* p;                           // parameter block of this person (glamr_param_layout offsets)
   float* m; float* v; float* g;       // Adam moments, gradient (same layout)
   float* theta; float* xy;            // [T], [T][2] scan buffers
-  float* d6;                          // [T][6]
-  float* orient_world; float* trans_world;  // [T][3] outputs
-  float* g_ow; float* g_tw;           // [T][3]
+  float* d6;                          // [T][6] first two columns c1, c2 of the world rotation (the third is c1 x c2)
+  float* tw;                          // [T][3] world translation
+  float* g_d6; float* g_tw;           // [T][6], [T][3] gradients of the above (the third column's gradient folded onto c1, c2)
+  float* orient_world; float* trans_world;  // [T][3] outputs, written by the last evaluation
   float* g_theta; float* g_xy;        // [T], [T][2]
   float* kp_2d_pred; float* orient_cam_in_world;   // outputs
   float* kp_wsum;                     // [NJ] sum over visible frames of thresholded score^2
@@ -182,42 +194,29 @@ GLAMR_HD void adam_block(float* p, float* m, float* v, float* gstore, int base, 
   if (gstore) for (int k = 0; k < N; ++k) gstore[base + k] = g[k];
 }
 
-// orientation chain of frame e: q = hq(theta) (x) R2q(6d->R(r6)) (x) base ; aa = q2aa(q)
-struct OrientFwd { float hq[4], lq[4], q1[4], q[4], aa[3]; float R6[9]; };
-GLAMR_HD void orient_base_fwd(float theta, const float r6[6], OrientFwd& o) {
-  const float base[4] = {0.5f, 0.5f, 0.5f, 0.5f};
-  rm::heading_quat(theta, o.hq);
-  rm::rot6d_to_rotmat(r6, o.R6);
-  rm::rotmat_to_quat(o.R6, o.lq);
-  rm::quat_mul(o.hq, o.lq, o.q1);
-  rm::quat_mul(o.q1, base, o.q);
-  rm::quat_to_aa(o.q, o.aa);
+// World orientation as a rotation MATRIX.  The reference composes quaternions and goes through axis-angle at every step
+// (traj_local2global_heading: hq(theta) (x) R2q(6d->R(r6)) (x) (.5,.5,.5,.5), :459-465 world heading offset, then angle_axis ->
+// rotation matrix again for the joints, :517 and the losses); as rotations these are
+//     R_w = Rz(theta + world_dheading) . [b2 b3 b1],      (b1, b2, b3) = columns of 6d->R(r6),
+// because (.5,.5,.5,.5) is the cyclic permutation x->y->z->x.  Working on the matrix removes every atan2/sqrt/sin/cos of the
+// conversions from the iteration; values and gradients agree with the chain up to rounding (all Jacobians along the chain map
+// onto the tangent space of SO(3), where R(aa(R)) is the identity).  Only the first two columns (c1, c2) are kept: c3 = c1 x c2.
+GLAMR_HD void rotz2(float cs, float sn, const float a[3], float o[3]) { o[0] = cs * a[0] - sn * a[1]; o[1] = sn * a[0] + cs * a[1]; o[2] = a[2]; }
+GLAMR_HD void rotz2T(float cs, float sn, const float a[3], float o[3]) { o[0] = cs * a[0] + sn * a[1]; o[1] = -sn * a[0] + cs * a[1]; o[2] = a[2]; }
+GLAMR_HD void cols_to_R(const float* d6, float R[9]) {
+  const float c1[3] = {d6[0], d6[1], d6[2]}, c2[3] = {d6[3], d6[4], d6[5]};
+  float c3[3];
+  rm::cross3(c1, c2, c3);
+  for (int r = 0; r < 3; ++r) { R[r * 3 + 0] = c1[r]; R[r * 3 + 1] = c2[r]; R[r * 3 + 2] = c3[r]; }
 }
-GLAMR_HD void orient_base_bwd(float theta, const float r6[6], const OrientFwd& o, const float gaa[3], float& gtheta, float gr6[6]) {
-  const float base[4] = {0.5f, 0.5f, 0.5f, 0.5f};
-  float gq[4] = {0, 0, 0, 0}, gq1[4] = {0, 0, 0, 0}, ghq[4] = {0, 0, 0, 0}, glq[4] = {0, 0, 0, 0}, gR[9] = {0};
-  rm::quat_to_aa_bwd(o.q, gaa, gq);
-  rm::quat_mul_bwd(o.q1, base, gq, gq1, nullptr);
-  rm::quat_mul_bwd(o.hq, o.lq, gq1, ghq, glq);
-  gtheta += rm::heading_quat_bwd(theta, ghq);
-  rm::rotmat_to_quat_bwd(o.R6, glq, gR);
-  rm::rot6d_to_rotmat_bwd(r6, gR, gr6);
-}
-
-// world heading offset: ow = q2aa( aa2q((0,0,w)) (x) aa2q(ob) )   (:459-465)
-struct WorldFwd { float wq[4], bq[4], q[4]; };
-GLAMR_HD void world_dheading_fwd(float w, const float ob[3], WorldFwd& f, float ow[3]) {
-  rm::heading_quat(w, f.wq);
-  rm::aa_to_quat(ob, f.bq);
-  rm::quat_mul(f.wq, f.bq, f.q);
-  rm::quat_to_aa(f.q, ow);
-}
-GLAMR_HD void world_dheading_bwd(float w, const float ob[3], const WorldFwd& f, const float gow[3], float& gw, float gob[3]) {
-  float gq[4] = {0, 0, 0, 0}, gwq[4] = {0, 0, 0, 0}, gbq[4] = {0, 0, 0, 0};
-  rm::quat_to_aa_bwd(f.q, gow, gq);
-  rm::quat_mul_bwd(f.wq, f.bq, gq, gwq, gbq);
-  gw += rm::heading_quat_bwd(w, gwq);
-  rm::aa_to_quat_bwd(ob, gbq, gob);
+// gradient of a full 3x3 matrix -> gradient of (c1, c2) with c3 = c1 x c2 folded in
+GLAMR_HD void fold_R_grad(const float* d6, const float gR[9], float g6[6]) {
+  const float c1[3] = {d6[0], d6[1], d6[2]}, c2[3] = {d6[3], d6[4], d6[5]};
+  const float g3[3] = {gR[2], gR[5], gR[8]};
+  float a[3], b[3];
+  rm::cross3(c2, g3, a);          // d(c1 x c2)/dc1 ^T g3
+  rm::cross3(g3, c1, b);          // d(c1 x c2)/dc2 ^T g3
+  for (int r = 0; r < 3; ++r) { g6[r] = gR[r * 3 + 0] + a[r]; g6[3 + r] = gR[r * 3 + 1] + b[r]; }
 }
 
 
@@ -241,14 +240,14 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
   l.scene_stride = l.person0 + max_persons * l.person_stride;
 }
 
-GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(12 + 30 * max_persons) * max_len; }
+GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(12 + 36 * max_persons) * max_len; }
 
 GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
   glamr_param_layout l;
   param_layout(max_persons, max_len, l);
   const size_t T = (size_t)max_len;
   size_t n = 3 * (size_t)l.person0 + 4 * 12 * T + 2 * T + 64;                       // cm cv cg | cam_inv g_cam g_caminv g_avg | fill_src n_vis | pair_first
-  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 6 + 3 + 3 + 1 + 2 + 12 + 6 * NJ + 1 + 1 + 6) * T + 32);   // m v g | theta xy d6 g_ow g_tw g_theta g_xy vis_rank | kp_wsum
+  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 6 + 3 + 6 + 3 + 1 + 2 + 12 + 6 * NJ + 1 + 1 + 6) * T + 32);   // m v g | theta xy d6 tw g_d6 g_tw g_theta g_xy Lc | kpc vis_rank h_prior oc6 | kp_wsum
   return n;
 }
 
@@ -282,7 +281,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     s.m = take(l.person_stride); s.v = take(l.person_stride);
     float* g_ws = take(l.person_stride);
     s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
-    s.theta = takef(TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.g_ow = takef(3 * TM); s.g_tw = takef(3 * TM);
+    s.theta = takef(TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef(3 * TM); s.g_d6 = takef(6 * TM); s.g_tw = takef(3 * TM);
     s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef(12 * TM);
     s.kpc_ws = take((size_t)NJ * 6 * TM); s.kpc = s.kpc_ws; s.njc = 0;
     c.vis_rank = reinterpret_cast<int*>(take(TM));
@@ -451,6 +450,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     float lsum[GLAMR_NUM_LOSSES];
     for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) lsum[i] = 0.f;
     float kp_dist_cnt = 0.f;
+    GLAMR_MARK_BEGIN(rt);
 
     // ---- A: heading increments (arrays are indexed by VIDEO frame t and zero outside the person's existing range, so the
     //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
@@ -473,6 +473,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       rt.scan_multi(ch, P, T, 1, false);
     }
     rt.sync();
+    GLAMR_MARK(rt, 0);
     // ---- B: planar displacement in world axes -------------------------------------------------------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
@@ -498,32 +499,43 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       for (int p = 0; p < P; ++p) { ch[2 * p] = sc.ps[p].xy; ch[2 * p + 1] = sc.ps[p].xy + 1; }
       rt.scan_multi(ch, 2 * P, T, 2, false);
     }
+    GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads()) {
       for (int p = 0; p < P; ++p) {
         const PersonConst& c = sc.pc[p];
         PersonState& s = sc.ps[p];
-        float ob[3], tb[3];
+        float c1[3], c2[3], tb[3], phi = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const LocalRow L = load_row(s.Lc, sc.TM, t);
-          OrientFwd o;
-          orient_base_fwd(s.theta[t], L.r6, o);
-          for (int k = 0; k < 3; ++k) ob[k] = o.aa[k];
+          float Rl[9];
+          rm::rot6d_to_rotmat(L.r6, Rl);
+          for (int k = 0; k < 3; ++k) { c1[k] = Rl[k * 3 + 1]; c2[k] = Rl[k * 3 + 2]; }
+          phi = s.theta[t];
           tb[0] = s.xy[t * 2 + 0]; tb[1] = s.xy[t * 2 + 1]; tb[2] = L.z;
         } else {
-          for (int k = 0; k < 3; ++k) { ob[k] = c.base_orient[t * 3 + k]; tb[k] = c.base_trans[t * 3 + k]; }
+          float Rb[9];
+          rm::aa_to_rotmat_k(c.base_orient + t * 3, Rb);
+          for (int k = 0; k < 3; ++k) { c1[k] = Rb[k * 3 + 0]; c2[k] = Rb[k * 3 + 1]; tb[k] = c.base_trans[t * 3 + k]; }
         }
-        float ow[3] = {ob[0], ob[1], ob[2]};
-        if (has_wd) { WorldFwd wf; world_dheading_fwd(s.p[l.world_dheading + t], ob, wf, ow); }
-        float Rk[9];
-        rm::aa_to_rotmat_k(ow, Rk);
+        if (has_wd) phi += s.p[l.world_dheading + t];
+        float sn = 0.f, cs = 1.f;
+        if (has_wd || (t >= c.fr_start && t < c.fr_end)) rm::sincos_(phi, sn, cs);
+        float w1[3], w2[3];
+        rotz2(cs, sn, c1, w1);
+        rotz2(cs, sn, c2, w2);
+        s.Lc[10 * sc.TM + t] = cs;
+        s.Lc[11 * sc.TM + t] = sn;
         for (int k = 0; k < 3; ++k) {
-          s.orient_world[t * 3 + k] = ow[k];
-          s.trans_world[t * 3 + k] = tb[k];
-          s.g_ow[t * 3 + k] = 0.f;
-          s.g_tw[t * 3 + k] = 0.f;
-          s.d6[t * 6 + k] = Rk[k * 3 + 0];
-          s.d6[t * 6 + 3 + k] = Rk[k * 3 + 1];
+          s.d6[t * 6 + k] = w1[k];
+          s.d6[t * 6 + 3 + k] = w2[k];
+          s.tw[t * 3 + k] = tb[k];
+        }
+        if (last) {
+          float Rw[9], ow[3];
+          cols_to_R(s.d6 + t * 6, Rw);
+          rm::rotmat_to_aa(Rw, ow);
+          for (int k = 0; k < 3; ++k) { s.orient_world[t * 3 + k] = ow[k]; s.trans_world[t * 3 + k] = tb[k]; }
         }
       }
       // ---- D: camera of this frame, unless it is derived from the persons (needs other frames' transforms) -----------------
@@ -542,6 +554,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       }
     }
     rt.sync();
+    GLAMR_MARK(rt, 2);
     if (cam_from_person) {
       for (int t = rt.tid(); t < T; t += rt.nthreads()) {
         float M[12], Mi[12];
@@ -551,8 +564,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         for (int p = 0; p < P; ++p) {
           if (sc.pc[p].vis[src] == 0.f) continue;
           float Tw[12], Rk[9], C[12];
-          rm::aa_to_rotmat_k(sc.ps[p].orient_world + src * 3, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].trans_world[src * 3 + i]; }
+          cols_to_R(sc.ps[p].d6 + src * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].tw[src * 3 + i]; }
           mul34(Tw, sc.pc[p].person2cam + (size_t)src * 12, C);
           for (int k = 0; k < 12; ++k) avg[k] += C[k];
         }
@@ -569,6 +582,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       }
       rt.sync();
     }
+    GLAMR_MARK(rt, 3);
     // ---- E: residuals and per-frame gradients -----------------------------------------------------------------------------
     const float w_kp = active(GLAMR_LOSS_KP_2D) ? st.loss_weight[GLAMR_LOSS_KP_2D] / n_vis_total : 0.f;
     const float n_ctr = ffo(GLAMR_LOSS_CAM_TRAJ_ROT) ? (float)P : n_vis_total;
@@ -595,22 +609,23 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       for (int p = 0; p < P; ++p) {
         const PersonConst& c = sc.pc[p];
         PersonState& s = sc.ps[p];
-        const float* ow = s.orient_world + t * 3;
-        const float* tw = s.trans_world + t * 3;
-        float g_ow[3] = {0, 0, 0}, g_tw[3] = {0, 0, 0};
+        const float* tw = s.tw + t * 3;
+        float g_tw[3] = {0, 0, 0};
         float gRk[9];
         for (int k = 0; k < 9; ++k) gRk[k] = 0.f;
         float Rk[9];
-        rm::aa_to_rotmat_k(ow, Rk);
+        cols_to_R(s.d6 + t * 6, Rk);
         const bool visible = c.vis[t] != 0.f;
         // orientation seen from the camera: transform_rot(cam_pose, orient_world)  (:512)
-        float Mk[9], ociw[3];
+        float Mk[9];
         rm::mat3_mul(Rc, Rk, Mk);
-        rm::rotmat_to_aa(Mk, ociw);
-        if (last) for (int k = 0; k < 3; ++k) s.orient_cam_in_world[t * 3 + k] = ociw[k];
+        if (last) {
+          float ociw[3];
+          rm::rotmat_to_aa(Mk, ociw);
+          for (int k = 0; k < 3; ++k) s.orient_cam_in_world[t * 3 + k] = ociw[k];
+        }
         if (on(GLAMR_LOSS_CAM_TRAJ_ROT) && visible && (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) || c.vis_rank[t] == 0)) {
-          float Ra[9];
-          rm::aa_to_rotmat_k(ociw, Ra);
+          const float* Ra = Mk;             // = aa2R(R2aa(Mk)) of the reference
           const float* tgt = s.oc6 + t * 6;
           const float fw = (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) && c.vis_rank[t] == 0) ? st.first_frame_weight[GLAMR_LOSS_CAM_TRAJ_ROT] : 1.0f;
           float gRa[9];
@@ -622,10 +637,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
               gRa[r * 3 + col] = -2.0f * d * fw * w_ctr;
             }
           if (w_ctr != 0.f) {
-            float g_oc[3] = {0, 0, 0}, gMk[9];
-            for (int k = 0; k < 9; ++k) gMk[k] = 0.f;
-            rm::aa_to_rotmat_k_bwd(ociw, gRa, g_oc);
-            rm::rotmat_to_aa_bwd(Mk, g_oc, gMk);
+            const float* gMk = gRa;
             float gRc[9];
             for (int k = 0; k < 9; ++k) gRc[k] = 0.f;
             rm::mat3_mul_bwd(Rc, Rk, gMk, gRc, gRk);
@@ -636,10 +648,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         const bool kp_first = ffo(GLAMR_LOSS_KP_2D);
         const bool need_kp = last || (w_kp != 0.f && visible && (!kp_first || c.vis_rank[t] == 0));
         if (need_kp) {
-          float Rs[9];
-          rm::aa_to_rotmat_s(ow, Rs);
-          float gRs[9];
-          for (int k = 0; k < 9; ++k) gRs[k] = 0.f;
+          const float* Rs = Rk;             // smplx Rodrigues of the same rotation
+          float* gRs = gRk;
           const float* K = c.cam_K + (size_t)t * 9;
           const float rank_w = (c.vis_rank[t] >= 0 && c.vis_rank[t] < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
           const bool kp_frame = visible && (!kp_first || c.vis_rank[t] == 0);
@@ -705,7 +715,6 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
               joint(jl, o[3 * sc.TM], o[4 * sc.TM], wj, 0.f, -1);
             }
           }
-          if (w_kp != 0.f && kp_frame) rm::aa_to_rotmat_s_bwd(ow, gRs, g_ow);
         }
         // smoothness of the world orientation in 6D  (loss_func.py:117-132)
         if (on(GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS)) {
@@ -726,8 +735,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           for (int o = 0; o < P; ++o) {
             if (o == p || sc.pc[o].vis[t] == 0.f) continue;
             float To[12], Ro[9];
-            rm::aa_to_rotmat_k(sc.ps[o].orient_world + t * 3, Ro);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = sc.ps[o].trans_world[t * 3 + i]; }
+            cols_to_R(sc.ps[o].d6 + t * 6, Ro);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = sc.ps[o].tw[t * 3 + i]; }
             float Toinv[12];
             invert34(To, Toinv);
             // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
@@ -762,8 +771,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           }
           for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) gRk[i * 3 + j] += gTi[i * 4 + j]; g_tw[i] += gTi[i * 4 + 3]; }
         }
-        rm::aa_to_rotmat_k_bwd(ow, gRk, g_ow);
-        for (int k = 0; k < 3; ++k) { s.g_ow[t * 3 + k] += g_ow[k]; s.g_tw[t * 3 + k] += g_tw[k]; }
+        float g6[6];
+        fold_R_grad(s.d6 + t * 6, gRk, g6);
+        for (int k = 0; k < 6; ++k) s.g_d6[t * 6 + k] = g6[k];
+        for (int k = 0; k < 3; ++k) s.g_tw[t * 3 + k] = g_tw[k];
       }
       // camera-only terms on the camera-to-world transform  (loss_func.py:76-114)
       if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) {
@@ -805,6 +816,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
         for (int k = 0; k < 3; ++k) { const float r = sc.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
     }
+    GLAMR_MARK(rt, 4);
     if (update && var_cam && fixed_cam) {
       for (int k = 0; k < 9; ++k) gfix[k] = rt.reduce_sum(gfix[k]);
       if (rt.tid() == 0) {
@@ -827,8 +839,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           for (int p = 0; p < P; ++p) {
             if (sc.pc[p].vis[src] == 0.f) continue;
             float Tw[12], Rk[9], C[12];
-            rm::aa_to_rotmat_k(sc.ps[p].orient_world + src * 3, Rk);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].trans_world[src * 3 + i]; }
+            cols_to_R(sc.ps[p].d6 + src * 6, Rk);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].tw[src * 3 + i]; }
             mul34(Tw, sc.pc[p].person2cam + (size_t)src * 12, C);
             for (int k = 0; k < 12; ++k) avg[k] += C[k];
           }
@@ -865,16 +877,17 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           if (sc.pc[p].vis[t] == 0.f) continue;
           float Tw[12], Rk[9], gTw[12];
           for (int k = 0; k < 12; ++k) gTw[k] = 0.f;
-          rm::aa_to_rotmat_k(sc.ps[p].orient_world + t * 3, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].trans_world[t * 3 + i]; }
+          cols_to_R(sc.ps[p].d6 + t * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].tw[t * 3 + i]; }
           mul34_bwd(Tw, sc.pc[p].person2cam + (size_t)t * 12, ga, gTw, nullptr);
-          float gRk[9], g_ow[3] = {0, 0, 0};
+          float gRk[9], g6[6];
           get_R(gTw, gRk);
-          rm::aa_to_rotmat_k_bwd(sc.ps[p].orient_world + t * 3, gRk, g_ow);
-          for (int k = 0; k < 3; ++k) { sc.ps[p].g_ow[t * 3 + k] += g_ow[k]; sc.ps[p].g_tw[t * 3 + k] += gTw[k * 4 + 3]; }
+          fold_R_grad(sc.ps[p].d6 + t * 6, gRk, g6);
+          for (int k = 0; k < 6; ++k) sc.ps[p].g_d6[t * 6 + k] += g6[k];
+          for (int k = 0; k < 3; ++k) sc.ps[p].g_tw[t * 3 + k] += gTw[k * 4 + 3];
         }
       }
-      // the fold writes g_ow / g_tw of frame t from thread t only: the owner continues without a barrier
+      // the fold writes g_d6 / g_tw of frame t from thread t only: the owner continues without a barrier
     } else if (update && !var_cam && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
       // camera neither optimised nor derived from the persons: the residual only feels its own regulariser
       const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
@@ -886,6 +899,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           adam(sc.cp[i], sc.cm[i], sc.cv[i], g, ac);
         }
     }
+    GLAMR_MARK(rt, 5);
     // ---- H: reverse of the orientation chain; direct parameter gradients (own frame only) -----------------------------------
     const float w_rot = active(GLAMR_LOSS_LOCAL_ROT_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_ROT_REG] / n_exist : 0.f;
     const float w_z = active(GLAMR_LOSS_LOCAL_Z_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_Z_REG] / n_exist : 0.f;
@@ -897,33 +911,28 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         PersonState& s = sc.ps[p];
         const bool ex = t >= c.fr_start && t < c.fr_end;
         const int e = t - c.fr_start;
-        float ob[3];
-        LocalRow L;
-        OrientFwd o;
-        if (ex) {
-          L = load_row(s.Lc, sc.TM, t);
-          orient_base_fwd(s.theta[t], L.r6, o);
-          for (int k = 0; k < 3; ++k) ob[k] = o.aa[k];
-        } else {
-          for (int k = 0; k < 3; ++k) ob[k] = c.base_orient[t * 3 + k];
-        }
-        float g_ob[3] = {s.g_ow[t * 3 + 0], s.g_ow[t * 3 + 1], s.g_ow[t * 3 + 2]};
-        if (has_wd) {
-          WorldFwd wf;
-          float ow[3], gw = 0.f;
-          world_dheading_fwd(s.p[l.world_dheading + t], ob, wf, ow);
-          float g_in[3] = {g_ob[0], g_ob[1], g_ob[2]};
-          g_ob[0] = g_ob[1] = g_ob[2] = 0.f;
-          world_dheading_bwd(s.p[l.world_dheading + t], ob, wf, g_in, gw, g_ob);
-          if (update && (st.var_mask & GLAMR_VAR_WORLD_DHEADING)) {
-            const int i = l.world_dheading + t;
-            if (sc.store_grad) s.g[i] = gw;
-            adam(s.p[i], s.m[i], s.v[i], gw, ac);
-          }
+        // R_w = Rz(phi) [b2 b3 | .]:  d/dphi = J R_w with J = [[0,-1,0],[1,0,0],[0,0,0]]
+        const float* d6 = s.d6 + t * 6;
+        const float* g6 = s.g_d6 + t * 6;
+        const float gphi = (g6[1] * d6[0] - g6[0] * d6[1]) + (g6[4] * d6[3] - g6[3] * d6[4]);
+        if (has_wd && update && (st.var_mask & GLAMR_VAR_WORLD_DHEADING)) {
+          const int i = l.world_dheading + t;
+          if (sc.store_grad) s.g[i] = gphi;
+          adam(s.p[i], s.m[i], s.v[i], gphi, ac);
         }
         if (!ex) { s.g_theta[t] = 0.f; s.g_xy[t * 2 + 0] = 0.f; s.g_xy[t * 2 + 1] = 0.f; continue; }
-        float gth = 0.f, gr6[6] = {0, 0, 0, 0, 0, 0};
-        orient_base_bwd(s.theta[t], L.r6, o, g_ob, gth, gr6);
+        const LocalRow L = load_row(s.Lc, sc.TM, t);
+        const float cs = s.Lc[10 * sc.TM + t], sn = s.Lc[11 * sc.TM + t];
+        const float gth = gphi;
+        float gr6[6] = {0, 0, 0, 0, 0, 0};
+        {
+          const float g1[3] = {g6[0], g6[1], g6[2]}, g2[3] = {g6[3], g6[4], g6[5]};
+          float gb2[3], gb3[3], gRl[9];
+          rotz2T(cs, sn, g1, gb2);
+          rotz2T(cs, sn, g2, gb3);
+          for (int r = 0; r < 3; ++r) { gRl[r * 3 + 0] = 0.f; gRl[r * 3 + 1] = gb2[r]; gRl[r * 3 + 2] = gb3[r]; }
+          rm::rot6d_to_rotmat_bwd(L.r6, gRl, gr6);
+        }
         s.g_theta[t] = gth;
         s.g_xy[t * 2 + 0] = s.g_tw[t * 3 + 0];
         s.g_xy[t * 2 + 1] = s.g_tw[t * 3 + 1];
@@ -952,6 +961,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         rt.scan_multi(ch, 2 * P, T, 2, true);
       }
       rt.sync();
+      GLAMR_MARK(rt, 6);
       // ---- I: reverse of B ----------------------------------------------------------------------------------------------
       for (int t = rt.tid(); t < T; t += rt.nthreads())
         for (int p = 0; p < P; ++p) {
@@ -995,6 +1005,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         for (int p = 0; p < P; ++p) ch[p] = sc.ps[p].g_theta;
         rt.scan_multi(ch, P, T, 1, true);
       }
+      GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
       for (int t = rt.tid(); t < T; t += rt.nthreads())
         for (int p = 0; p < P; ++p) {
@@ -1047,8 +1058,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         o[GLAMR_LOSS_CAM_UP_REG] = tot[GLAMR_LOSS_CAM_UP_REG] / n_up;
       }
     }
+    GLAMR_MARK(rt, 8);
   }
   rt.sync();
+  GLAMR_MARK_END(rt);
 }
 
 }  // namespace grecon

