@@ -17,10 +17,10 @@ struct DeviceRT {
   float* red;   // LDS scratch of RT_RED_FLOATS floats
   int gen = 0;
 #ifdef GLAMR_PHASE_TIMING
-  unsigned long long t_last = 0, acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = 0, acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __device__ void mark_begin() { t_last = wall_clock64(); }
   template <int K> __device__ void mark() { const unsigned long long n = wall_clock64(); acc[K] += n - t_last; t_last = n; }
-  __device__ void mark_end() { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k = 0; k < 9; ++k) g_phase_ticks[k] = acc[k]; }
+  __device__ void mark_end() { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k = 0; k < 16; ++k) g_phase_ticks[k] = acc[k]; }
 #endif  // scan_multi alternates between two halves of `red` so consecutive calls need no barrier in between
   // In-place inclusive prefix (reverse: suffix) sums of up to RT_MAX_CH arrays ch[c][i*stride], i in [0,n).  Element i is read and
   // written by thread i mod blockDim only, so a caller whose next phase touches only its own elements needs no barrier after it;

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(MAX_THREADS) void grecon_stage_kernel(KernelArgs a)
   }
   __syncthreads();
   glamr::DeviceRT rt{red};
-  run_scene(rt, sc);
+  run_scene(rt, sc, a.st, a.lay);
 }
 
 }  // namespace grecon
@@ -102,9 +102,9 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
 
 #ifdef GLAMR_PHASE_TIMING
 // development builds only: per-phase time of workgroup 0 in the last stage launch, in 10 ns ticks
-extern "C" int glamr_debug_phase_ticks(unsigned long long* out9) {
+extern "C" int glamr_debug_phase_ticks(unsigned long long* out16) {
   GLAMR_HIP_CHECK(hipDeviceSynchronize());
-  GLAMR_HIP_CHECK(hipMemcpyFromSymbol(out9, HIP_SYMBOL(glamr::g_phase_ticks), 9 * sizeof(unsigned long long)));
+  GLAMR_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(glamr::g_phase_ticks), 16 * sizeof(unsigned long long)));
   return GLAMR_OK;
 }
 #endif

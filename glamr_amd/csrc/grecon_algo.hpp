@@ -59,6 +59,7 @@ struct PersonState {
   float* p;                           // parameter block of this person (glamr_param_layout offsets)
   float* m; float* v; float* g;       // Adam moments, gradient (same layout)
   float* theta; float* xy;            // [T], [T][2] scan buffers
+  float* csn;                         // [T][2] cos, sin of theta[t] (read by the neighbouring frame in phases B and I)
   float* d6;                          // [T][6] first two columns c1, c2 of the world rotation (the third is c1 x c2)
   float* tw;                          // [T][3] world translation
   float* g_d6; float* g_tw;           // [T][6], [T][3] gradients of the above (the third column's gradient folded onto c1, c2)
@@ -68,7 +69,8 @@ struct PersonState {
   float* kp_wsum;                     // [NJ] sum over visible frames of thresholded score^2
   float* Lc;                          // [12][T] cached trajectory row of frame t (dx dy z r6[6] h), written in phase A
   float* kpc;                         // [njc][6][T] compact keypoint data of the scored joints: j_local(3) target(2) weight(1)
-  float* kpc_ws;                      // global fallback for kpc
+  float* kpc_ws;                      // same table in the workspace, for the joints jj >= njc_fast that do not fit on chip
+  int njc_fast;
   int njc; int jidx[NJ];              // joints whose residual weight is non-zero somewhere
   float* h_prior;                     // [T] row e: heading angle of the prior row, atan2s(sin, cos)  (constant per stage)
   float* oc6;                         // [T][6] first two columns of aa2R_k(orient_cam) (cam_traj_rot target, constant)
@@ -95,6 +97,57 @@ struct Scene {
   float* fast_free; size_t fast_left; // unused tail of the on-chip arena (claimed by setup for kpc when it fits)
   int TM;                             // padded frame count (array strides)
 };
+
+// ---- wave-uniform views ------------------------------------------------------------------------------------------------------
+// The scene description lives in LDS; a plain read leaves every pointer in two VECTOR registers per lane, and the optimiser hoists
+// dozens of them out of the iteration loop.  Everything in it is uniform over the workgroup, so the device build routes the hot
+// loop's copies through readfirstlane: they end up in scalar registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ T* uni(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#else
+template <class T> inline T* uni(T* p) { return p; }
+inline int uni(int x) { return x; }
+#endif
+
+struct PersonView {      // what the iteration loop needs of PersonConst + PersonState, uniform
+  int fr_start, fr_end, njc, njc_fast;
+  const float *vis, *j_local, *kp_2d, *kp_score, *cam_K, *prior, *base_orient, *base_trans, *person2cam, *dheading_mask, *h_prior, *oc6, *kp_wsum;
+  const int* vis_rank;
+  float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc;
+  const float *kpc, *kpc_ws;
+};
+GLAMR_HD PersonView person_view(const Scene& sc, int p) {
+  const PersonConst& c = sc.pc[p];
+  const PersonState& s = sc.ps[p];
+  PersonView w;
+  w.fr_start = uni(c.fr_start); w.fr_end = uni(c.fr_end); w.njc = uni(s.njc); w.njc_fast = uni(s.njc_fast);
+  w.vis = uni(c.vis); w.j_local = uni(c.j_local); w.kp_2d = uni(c.kp_2d); w.kp_score = uni(c.kp_score); w.cam_K = uni(c.cam_K); w.prior = uni(c.prior);
+  w.base_orient = uni(c.base_orient); w.base_trans = uni(c.base_trans); w.person2cam = uni(c.person2cam); w.dheading_mask = uni(c.dheading_mask);
+  w.h_prior = uni(s.h_prior); w.oc6 = uni(s.oc6); w.kp_wsum = uni(s.kp_wsum); w.vis_rank = uni(c.vis_rank);
+  w.p = uni(s.p); w.m = uni(s.m); w.v = uni(s.v); w.g = uni(s.g); w.theta = uni(s.theta); w.csn = uni(s.csn); w.xy = uni(s.xy); w.d6 = uni(s.d6);
+  w.tw = uni(s.tw); w.g_d6 = uni(s.g_d6); w.g_tw = uni(s.g_tw); w.orient_world = uni(s.orient_world); w.trans_world = uni(s.trans_world);
+  w.g_theta = uni(s.g_theta); w.g_xy = uni(s.g_xy); w.kp_2d_pred = uni(s.kp_2d_pred); w.orient_cam_in_world = uni(s.orient_cam_in_world); w.Lc = uni(s.Lc);
+  w.kpc = uni(s.kpc); w.kpc_ws = uni(s.kpc_ws);
+  return w;
+}
+struct SceneView {
+  const float* rel_cam; const int* pair_first; const int* fill_src; const int* n_vis_persons;
+  float *cam_pose, *cam_inv, *g_cam, *g_caminv, *g_avg, *cp, *cm, *cv, *cg, *losses;
+  int store_grad, rel_stride_p, rel_stride_t, TM;
+};
+GLAMR_HD SceneView scene_view(const Scene& sc) {
+  SceneView w;
+  w.rel_cam = uni(sc.rel_cam); w.pair_first = uni(sc.pair_first); w.fill_src = uni(sc.fill_src); w.n_vis_persons = uni(sc.n_vis_persons);
+  w.cam_pose = uni(sc.cam_pose); w.cam_inv = uni(sc.cam_inv); w.g_cam = uni(sc.g_cam); w.g_caminv = uni(sc.g_caminv); w.g_avg = uni(sc.g_avg);
+  w.cp = uni(sc.cp); w.cm = uni(sc.cm); w.cv = uni(sc.cv); w.cg = uni(sc.cg); w.losses = uni(sc.losses);
+  w.store_grad = uni(sc.store_grad); w.rel_stride_p = uni(sc.rel_stride_p); w.rel_stride_t = uni(sc.rel_stride_t); w.TM = uni(sc.TM);
+  return w;
+}
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------
 
@@ -150,21 +203,18 @@ GLAMR_HD void mul34_bwd(const float A[12], const float B[12], const float gC[12]
 
 // person trajectory row L[e] from the prior and the optimisation deltas (get_pred_trajectory_base :394-419)
 struct LocalRow { float dx, dy, z, r6[6], h; };   // h = heading angle after adding the delta; (cos h, sin h) replaces cols 9,10
-template <class S>
-GLAMR_HD LocalRow local_row(const S& sc, int p, int e) {
-  const PersonConst& c = sc.pc[p];
+GLAMR_HD LocalRow local_row(const PersonView& c, const glamr_param_layout& l, int e) {
   const float* pr = c.prior + (size_t)e * 11;
-  const float* P = sc.ps[p].p;
-  const glamr_param_layout& l = *sc.lay;
+  const float* P = c.p;
   LocalRow L;
   if (e == 0) {
     L.dx = pr[0] + P[l.local_xy + 0];
     L.dy = pr[1] + P[l.local_xy + 1];
-    L.h = sc.ps[p].h_prior[e] + P[l.local_heading];
+    L.h = c.h_prior[e] + P[l.local_heading];
   } else {
     L.dx = pr[0] + P[l.local_dxy + e * 2 + 0];
     L.dy = pr[1] + P[l.local_dxy + e * 2 + 1];
-    L.h = sc.ps[p].h_prior[e] + (c.dheading_mask ? P[l.local_dheading + e] * c.dheading_mask[e] : 0.0f);
+    L.h = c.h_prior[e] + (c.dheading_mask ? P[l.local_dheading + e] * c.dheading_mask[e] : 0.0f);
   }
   L.z = pr[2] + P[l.local_z + e];
   for (int k = 0; k < 6; ++k) L.r6[k] = pr[3 + k] + P[l.local_rot + e * 6 + k];
@@ -193,6 +243,21 @@ GLAMR_HD void adam_block(float* p, float* m, float* v, float* gstore, int base, 
   for (int k = 0; k < N; ++k) { p[base + k] = P[k]; m[base + k] = M[k]; v[base + k] = V[k]; }
   if (gstore) for (int k = 0; k < N; ++k) gstore[base + k] = g[k];
 }
+
+// Adam on N consecutive parameters whose state is fetched EARLY (top of a phase) and consumed late: with one or two waves per SIMD
+// nothing else hides the workspace latency, so every phase issues all its loads first.
+template <int N>
+struct AdamRegs {
+  float P[N], M[N], V[N];
+  GLAMR_HD void load(const float* p, const float* m, const float* v, int base) {
+    for (int k = 0; k < N; ++k) { P[k] = p[base + k]; M[k] = m[base + k]; V[k] = v[base + k]; }
+  }
+  GLAMR_HD void step_store(float* p, float* m, float* v, float* gstore, int base, const float (&g)[N], const AdamCoef& c) {
+    for (int k = 0; k < N; ++k) adam(P[k], M[k], V[k], g[k], c);
+    for (int k = 0; k < N; ++k) { p[base + k] = P[k]; m[base + k] = M[k]; v[base + k] = V[k]; }
+    if (gstore) for (int k = 0; k < N; ++k) gstore[base + k] = g[k];
+  }
+};
 
 // World orientation as a rotation MATRIX.  The reference composes quaternions and goes through axis-angle at every step
 // (traj_local2global_heading: hq(theta) (x) R2q(6d->R(r6)) (x) (.5,.5,.5,.5), :459-465 world heading offset, then angle_axis ->
@@ -240,14 +305,14 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
   l.scene_stride = l.person0 + max_persons * l.person_stride;
 }
 
-GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(12 + 36 * max_persons) * max_len; }
+GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(12 + 38 * max_persons) * max_len; }
 
 GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
   glamr_param_layout l;
   param_layout(max_persons, max_len, l);
   const size_t T = (size_t)max_len;
   size_t n = 3 * (size_t)l.person0 + 4 * 12 * T + 2 * T + 64;                       // cm cv cg | cam_inv g_cam g_caminv g_avg | fill_src n_vis | pair_first
-  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 6 + 3 + 6 + 3 + 1 + 2 + 12 + 6 * NJ + 1 + 1 + 6) * T + 32);   // m v g | theta xy d6 tw g_d6 g_tw g_theta g_xy Lc | kpc vis_rank h_prior oc6 | kp_wsum
+  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 2 + 6 + 3 + 6 + 3 + 1 + 2 + 12 + 6 * NJ + 1 + 1 + 6) * T + 32);   // m v g | theta csn xy d6 tw g_d6 g_tw g_theta g_xy Lc | kpc vis_rank h_prior oc6 | kp_wsum
   return n;
 }
 
@@ -281,9 +346,9 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     s.m = take(l.person_stride); s.v = take(l.person_stride);
     float* g_ws = take(l.person_stride);
     s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
-    s.theta = takef(TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef(3 * TM); s.g_d6 = takef(6 * TM); s.g_tw = takef(3 * TM);
+    s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef(3 * TM); s.g_d6 = takef(6 * TM); s.g_tw = takef(3 * TM);
     s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef(12 * TM);
-    s.kpc_ws = take((size_t)NJ * 6 * TM); s.kpc = s.kpc_ws; s.njc = 0;
+    s.kpc_ws = take((size_t)NJ * 6 * TM); s.kpc = s.kpc_ws; s.njc = 0; s.njc_fast = 0;
     c.vis_rank = reinterpret_cast<int*>(take(TM));
     s.kp_wsum = take(32);
     s.h_prior = take(TM); s.oc6 = take(6 * TM);
@@ -346,9 +411,7 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
 // ---- the per-scene driver --------------------------------------------------------------------------------------------
 
 template <class RT>
-GLAMR_HD void run_scene(RT& rt, Scene& sc) {
-  const glamr_stage_desc& st = *sc.st;
-  const glamr_param_layout& l = *sc.lay;
+GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
   const int T = sc.T, P = sc.P;
   const bool var_cam = st.var_mask & GLAMR_VAR_CAM;
   const bool fixed_cam = st.flags & GLAMR_FLAG_FIXED_CAM;
@@ -409,8 +472,13 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       PersonState& s = sc.ps[p];
       s.njc = 0;
       if (on(GLAMR_LOSS_KP_2D)) for (int j = 0; j < NJ; ++j) if (s.kp_wsum[j] > 0.f) s.jidx[s.njc++] = j;
-      const size_t need = (size_t)s.njc * 6 * sc.TM;
-      if (sc.fast_free && need <= sc.fast_left) { s.kpc = sc.fast_free; sc.fast_free += need; sc.fast_left -= need; } else s.kpc = s.kpc_ws;
+      const size_t per_joint = (size_t)6 * sc.TM;
+      s.njc_fast = 0;
+      if (sc.fast_free) {
+        const size_t fit = sc.fast_left / per_joint;
+        s.njc_fast = (int)(fit < (size_t)s.njc ? fit : (size_t)s.njc);
+        s.kpc = sc.fast_free; sc.fast_free += s.njc_fast * per_joint; sc.fast_left -= s.njc_fast * per_joint;
+      }
     }
   rt.sync();
   for (int p = 0; p < P; ++p) {
@@ -427,7 +495,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           if (kp_first) w = s.kp_wsum[j] * rank_w;
           else { const float sj = c.kp_score[(size_t)t * NJ + j]; const float q = sj < st.kp_min_conf ? 0.f : sj; w = q * q * rank_w; }
         }
-        float* o = s.kpc + (size_t)jj * 6 * sc.TM + t;
+        float* o = (jj < s.njc_fast ? s.kpc : s.kpc_ws) + (size_t)jj * 6 * sc.TM + t;
         for (int k = 0; k < 3; ++k) o[k * sc.TM] = c.j_local[((size_t)t * NJ + j) * 3 + k];
         o[3 * sc.TM] = c.kp_2d[((size_t)t * NJ + j) * 2 + 0];
         o[4 * sc.TM] = c.kp_2d[((size_t)t * NJ + j) * 2 + 1];
@@ -440,6 +508,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
   const int niters = st.niters;
   double b1p = 1.0, b2p = 1.0;
   const int n_eval = niters > 0 ? niters : 1;
+  const SceneView sh = scene_view(sc);
   for (int it = 0; it < n_eval; ++it) {
     const bool last = (it == n_eval - 1);
     const bool update = niters > 0;
@@ -456,58 +525,63 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
-        const PersonConst& c = sc.pc[p];
+        const PersonView c = person_view(sc, p);
         float v = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
-          const LocalRow L = local_row(sc, p, t - c.fr_start);
-          store_row(sc.ps[p].Lc, sc.TM, t, L);
-          float sh, ch;
-          rm::sincos_(L.h, sh, ch);
-          v = rm::atan2s(sh, ch);
+          const LocalRow L = local_row(c, l, t - c.fr_start);
+          store_row(person_view(sc, p).Lc, sh.TM, t, L);
+          // atan2(sin h, cos h) of the reference (:401-405) only wraps h into (-pi, pi]: done arithmetically
+          v = L.h - 6.28318530717958647692f * rintf(L.h * 0.15915494309189533577f);
         }
-        sc.ps[p].theta[t] = v;
+        person_view(sc, p).theta[t] = v;
       }
     {
       float* ch[8];
-      for (int p = 0; p < P; ++p) ch[p] = sc.ps[p].theta;
+      for (int p = 0; p < P; ++p) ch[p] = person_view(sc, p).theta;
       rt.scan_multi(ch, P, T, 1, false);
     }
+    // own element of the prefix sum is final: its cos / sin serve phases B, C and I (this frame's and the next frame's)
+    for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int p = 0; p < P; ++p) {
+        float sn, cs;
+        rm::sincos_(person_view(sc, p).theta[t], sn, cs);
+        person_view(sc, p).csn[t * 2 + 0] = cs;
+        person_view(sc, p).csn[t * 2 + 1] = sn;
+      }
     rt.sync();
     GLAMR_MARK(rt, 0);
     // ---- B: planar displacement in world axes -------------------------------------------------------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
-        const PersonConst& c = sc.pc[p];
+        const PersonView c = person_view(sc, p);
         float dx = 0.f, dy = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const int e = t - c.fr_start;
-          const LocalRow L = load_row(sc.ps[p].Lc, sc.TM, t);
+          const LocalRow L = load_row(person_view(sc, p).Lc, sh.TM, t);
           dx = L.dx; dy = L.dy;
           if (e > 0) {
-            const float th = sc.ps[p].theta[t - 1];
-            float cs, sn;
-            rm::sincos_(th, sn, cs);
+            const float cs = person_view(sc, p).csn[(t - 1) * 2 + 0], sn = person_view(sc, p).csn[(t - 1) * 2 + 1];
             dx = L.dx * cs - L.dy * sn;
             dy = L.dx * sn + L.dy * cs;
           }
         }
-        sc.ps[p].xy[t * 2 + 0] = dx;
-        sc.ps[p].xy[t * 2 + 1] = dy;
+        person_view(sc, p).xy[t * 2 + 0] = dx;
+        person_view(sc, p).xy[t * 2 + 1] = dy;
       }
     {
       float* ch[16];
-      for (int p = 0; p < P; ++p) { ch[2 * p] = sc.ps[p].xy; ch[2 * p + 1] = sc.ps[p].xy + 1; }
+      for (int p = 0; p < P; ++p) { ch[2 * p] = person_view(sc, p).xy; ch[2 * p + 1] = person_view(sc, p).xy + 1; }
       rt.scan_multi(ch, 2 * P, T, 2, false);
     }
     GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads()) {
       for (int p = 0; p < P; ++p) {
-        const PersonConst& c = sc.pc[p];
-        PersonState& s = sc.ps[p];
+        const PersonView c = person_view(sc, p);
+        const PersonView& s = c;
         float c1[3], c2[3], tb[3], phi = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
-          const LocalRow L = load_row(s.Lc, sc.TM, t);
+          const LocalRow L = load_row(s.Lc, sh.TM, t);
           float Rl[9];
           rm::rot6d_to_rotmat(L.r6, Rl);
           for (int k = 0; k < 3; ++k) { c1[k] = Rl[k * 3 + 1]; c2[k] = Rl[k * 3 + 2]; }
@@ -518,14 +592,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           rm::aa_to_rotmat_k(c.base_orient + t * 3, Rb);
           for (int k = 0; k < 3; ++k) { c1[k] = Rb[k * 3 + 0]; c2[k] = Rb[k * 3 + 1]; tb[k] = c.base_trans[t * 3 + k]; }
         }
-        if (has_wd) phi += s.p[l.world_dheading + t];
         float sn = 0.f, cs = 1.f;
-        if (has_wd || (t >= c.fr_start && t < c.fr_end)) rm::sincos_(phi, sn, cs);
+        if (has_wd) { phi += s.p[l.world_dheading + t]; rm::sincos_(phi, sn, cs); }
+        else if (t >= c.fr_start && t < c.fr_end) { cs = s.csn[t * 2 + 0]; sn = s.csn[t * 2 + 1]; }
         float w1[3], w2[3];
         rotz2(cs, sn, c1, w1);
         rotz2(cs, sn, c2, w2);
-        s.Lc[10 * sc.TM + t] = cs;
-        s.Lc[11 * sc.TM + t] = sn;
+        s.Lc[10 * sh.TM + t] = cs;
+        s.Lc[11 * sh.TM + t] = sn;
         for (int k = 0; k < 3; ++k) {
           s.d6[t * 6 + k] = w1[k];
           s.d6[t * 6 + 3 + k] = w2[k];
@@ -544,13 +618,13 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         if (var_cam) {
           const int row = fixed_cam ? 0 : t;
           float R[9];
-          rm::rot6d_to_rotmat(sc.cp + l.cam_rot6d + row * 6, R);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sc.cp[l.cam_trans + row * 3 + i]; }
+          rm::rot6d_to_rotmat(sh.cp + l.cam_rot6d + row * 6, R);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sh.cp[l.cam_trans + row * 3 + i]; }
         } else {
-          for (int k = 0; k < 12; ++k) M[k] = sc.cam_pose[(size_t)t * 12 + k];
+          for (int k = 0; k < 12; ++k) M[k] = sh.cam_pose[(size_t)t * 12 + k];
         }
         invert34(M, Mi);
-        for (int k = 0; k < 12; ++k) { sc.cam_pose[(size_t)t * 12 + k] = M[k]; sc.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
+        for (int k = 0; k < 12; ++k) { sh.cam_pose[(size_t)t * 12 + k] = M[k]; sh.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
       }
     }
     rt.sync();
@@ -558,27 +632,27 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     if (cam_from_person) {
       for (int t = rt.tid(); t < T; t += rt.nthreads()) {
         float M[12], Mi[12];
-        const int src = sc.fill_src[t];
+        const int src = sh.fill_src[t];
         float avg[12];
         for (int k = 0; k < 12; ++k) avg[k] = 0.f;
         for (int p = 0; p < P; ++p) {
-          if (sc.pc[p].vis[src] == 0.f) continue;
+          if (person_view(sc, p).vis[src] == 0.f) continue;
           float Tw[12], Rk[9], C[12];
-          cols_to_R(sc.ps[p].d6 + src * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].tw[src * 3 + i]; }
-          mul34(Tw, sc.pc[p].person2cam + (size_t)src * 12, C);
+          cols_to_R(person_view(sc, p).d6 + src * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view(sc, p).tw[src * 3 + i]; }
+          mul34(Tw, person_view(sc, p).person2cam + (size_t)src * 12, C);
           for (int k = 0; k < 12; ++k) avg[k] += C[k];
         }
-        const float inv_n = 1.0f / (float)sc.n_vis_persons[src];
+        const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
         for (int k = 0; k < 12; ++k) avg[k] = avg[k] * inv_n;   // sum(...) / num_persons  (:492)
         float r6[6];
         for (int r = 0; r < 3; ++r) { r6[r] = avg[r * 4 + 0]; r6[3 + r] = avg[r * 4 + 1]; }
-        if (sc.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) r6[k] += sc.cp[l.cam_inv_rot_res + t * 6 + k];
+        if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) r6[k] += sh.cp[l.cam_inv_rot_res + t * 6 + k];
         float R[9];
         rm::rot6d_to_rotmat(r6, R);
-        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sc.cp[l.cam_inv_trans_res + t * 3 + i]; }
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sh.cp[l.cam_inv_trans_res + t * 3 + i]; }
         invert34(Mi, M);
-        for (int k = 0; k < 12; ++k) { sc.cam_pose[(size_t)t * 12 + k] = M[k]; sc.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
+        for (int k = 0; k < 12; ++k) { sh.cam_pose[(size_t)t * 12 + k] = M[k]; sh.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
       }
       rt.sync();
     }
@@ -602,20 +676,31 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     for (int t = rt.tid(); t < T; t += rt.nthreads()) {
       float gC[12], gCi[12];
       for (int k = 0; k < 12; ++k) { gC[k] = 0.f; gCi[k] = 0.f; }
-      const float* M = sc.cam_pose + (size_t)t * 12;
-      const float* Mi = sc.cam_inv + (size_t)t * 12;
+      // everything this frame needs from the workspace is requested up front
+      const bool own_cam = update && var_cam && !fixed_cam && !cam_from_person;
+      AdamRegs<6> a_rot;
+      AdamRegs<3> a_tr;
+      if (own_cam) { a_rot.load(sh.cp, sh.cm, sh.cv, l.cam_rot6d + t * 6); a_tr.load(sh.cp, sh.cm, sh.cv, l.cam_trans + t * 3); }
+      float M[12];
+      for (int k = 0; k < 12; ++k) M[k] = sh.cam_pose[(size_t)t * 12 + k];
+      const float* Mi = sh.cam_inv + (size_t)t * 12;
       float Rc[9];
       get_R(M, Rc);
       for (int p = 0; p < P; ++p) {
-        const PersonConst& c = sc.pc[p];
-        PersonState& s = sc.ps[p];
+        const PersonView c = person_view(sc, p);
+        const PersonView& s = c;
         const float* tw = s.tw + t * 3;
+        float K[9], tgt[6];
+        for (int k = 0; k < 9; ++k) K[k] = c.cam_K[(size_t)t * 9 + k];
+        for (int k = 0; k < 6; ++k) tgt[k] = s.oc6[t * 6 + k];
+        const float vis_t = c.vis[t];
+        const int rank_t = c.vis_rank[t];
         float g_tw[3] = {0, 0, 0};
         float gRk[9];
         for (int k = 0; k < 9; ++k) gRk[k] = 0.f;
         float Rk[9];
         cols_to_R(s.d6 + t * 6, Rk);
-        const bool visible = c.vis[t] != 0.f;
+        const bool visible = vis_t != 0.f;
         // orientation seen from the camera: transform_rot(cam_pose, orient_world)  (:512)
         float Mk[9];
         rm::mat3_mul(Rc, Rk, Mk);
@@ -624,16 +709,15 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           rm::rotmat_to_aa(Mk, ociw);
           for (int k = 0; k < 3; ++k) s.orient_cam_in_world[t * 3 + k] = ociw[k];
         }
-        if (on(GLAMR_LOSS_CAM_TRAJ_ROT) && visible && (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) || c.vis_rank[t] == 0)) {
+        if (on(GLAMR_LOSS_CAM_TRAJ_ROT) && visible && (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) || rank_t == 0)) {
           const float* Ra = Mk;             // = aa2R(R2aa(Mk)) of the reference
-          const float* tgt = s.oc6 + t * 6;
-          const float fw = (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) && c.vis_rank[t] == 0) ? st.first_frame_weight[GLAMR_LOSS_CAM_TRAJ_ROT] : 1.0f;
+          const float fw = (!ffo(GLAMR_LOSS_CAM_TRAJ_ROT) && rank_t == 0) ? st.first_frame_weight[GLAMR_LOSS_CAM_TRAJ_ROT] : 1.0f;
           float gRa[9];
           for (int k = 0; k < 9; ++k) gRa[k] = 0.f;
           for (int r = 0; r < 3; ++r)
             for (int col = 0; col < 2; ++col) {
               const float d = (tgt[col * 3 + r] - Ra[r * 3 + col]) * fw;
-              lsum[GLAMR_LOSS_CAM_TRAJ_ROT] += d * d;
+              if (last) lsum[GLAMR_LOSS_CAM_TRAJ_ROT] += d * d;
               gRa[r * 3 + col] = -2.0f * d * fw * w_ctr;
             }
           if (w_ctr != 0.f) {
@@ -644,15 +728,15 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gC[i * 4 + j] += gRc[i * 3 + j];
           }
         }
+        GLAMR_MARK(rt, 9);
         // joints, projection, 2-D keypoint residual  (:517-528, loss_func.py:15-57)
         const bool kp_first = ffo(GLAMR_LOSS_KP_2D);
-        const bool need_kp = last || (w_kp != 0.f && visible && (!kp_first || c.vis_rank[t] == 0));
+        const bool need_kp = last || (w_kp != 0.f && visible && (!kp_first || rank_t == 0));
         if (need_kp) {
           const float* Rs = Rk;             // smplx Rodrigues of the same rotation
           float* gRs = gRk;
-          const float* K = c.cam_K + (size_t)t * 9;
-          const float rank_w = (c.vis_rank[t] >= 0 && c.vis_rank[t] < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
-          const bool kp_frame = visible && (!kp_first || c.vis_rank[t] == 0);
+          const float rank_w = (rank_t >= 0 && rank_t < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
+          const bool kp_frame = visible && (!kp_first || rank_t == 0);
           // one joint: project, accumulate the residual value and (weight > 0) its gradient
           auto joint = [&](const float jl[3], float kx, float ky, float wj, float sc_raw, int jout) {
             float J[3], X[3];
@@ -669,12 +753,12 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
               s.kp_2d_pred[((size_t)t * NJ + jout) * 2 + 0] = u;
               s.kp_2d_pred[((size_t)t * NJ + jout) * 2 + 1] = v;
               if (on(GLAMR_LOSS_KP_2D_DIST) && sc_raw > min_conf && (!ffo(GLAMR_LOSS_KP_2D_DIST) || t == 0)) {
-                lsum[GLAMR_LOSS_KP_2D_DIST] += sqrtf(du * du + dv * dv);
-                kp_dist_cnt += 1.0f;
+                if (last) lsum[GLAMR_LOSS_KP_2D_DIST] += sqrtf(du * du + dv * dv);
+                if (last) kp_dist_cnt += 1.0f;
               }
             }
             if (wj == 0.f) return;
-            lsum[GLAMR_LOSS_KP_2D] += (gmof(du, 1e4f) + gmof(dv, 1e4f)) * wj;
+            if (last) lsum[GLAMR_LOSS_KP_2D] += (gmof(du, 1e4f) + gmof(dv, 1e4f)) * wj;
             if (w_kp == 0.f) return;
             const float gu = gmof_d(du, 1e4f) * wj * w_kp, gv = gmof_d(dv, 1e4f) * wj * w_kp;
             const float ghx = gu / hz, ghy = gv / hz, ghz = -(gu * u + gv * v) / hz;      // u = hx / hz, v = hy / hz
@@ -707,20 +791,29 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
             }
           } else {
             // only the joints that carry a score (14 of 26 for HybrIK input), from the compact table
-            for (int jj = 0; jj < s.njc; ++jj) {
-              const float* o = s.kpc + (size_t)jj * 6 * sc.TM + t;
-              const float wj = o[5 * sc.TM];
-              if (wj == 0.f) continue;
-              const float jl[3] = {o[0], o[sc.TM], o[2 * sc.TM]};
-              joint(jl, o[3 * sc.TM], o[4 * sc.TM], wj, 0.f, -1);
+            // the next joint's six values are fetched while the current one is processed (the rows that do not fit on chip come
+            // from the workspace: hundreds of cycles each with one or two waves per SIMD to hide them)
+            const int njc = s.njc, TMs = sh.TM;
+            float nx[6];
+            auto fetch = [&](int jj) {
+              const float* o = (jj < s.njc_fast ? s.kpc : s.kpc_ws) + (size_t)jj * 6 * TMs + t;
+              for (int k = 0; k < 6; ++k) nx[k] = o[k * TMs];
+            };
+            if (njc > 0) fetch(0);
+            for (int jj = 0; jj < njc; ++jj) {
+              const float cur[6] = {nx[0], nx[1], nx[2], nx[3], nx[4], nx[5]};
+              if (jj + 1 < njc) fetch(jj + 1);
+              if (cur[5] == 0.f) continue;
+              joint(cur, cur[3], cur[4], cur[5], 0.f, -1);
             }
           }
         }
+        GLAMR_MARK(rt, 10);
         // smoothness of the world orientation in 6D  (loss_func.py:117-132)
         if (on(GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS)) {
           const float* d0 = s.d6 + t * 6;
           float gd6[6] = {0, 0, 0, 0, 0, 0};
-          if (t + 1 < T) for (int k = 0; k < 6; ++k) { const float v = (s.d6[(t + 1) * 6 + k] - d0[k]) * FPS; lsum[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] += v * v; gd6[k] -= 2.0f * FPS * v * w_trs; }
+          if (t + 1 < T) for (int k = 0; k < 6; ++k) { const float v = (s.d6[(t + 1) * 6 + k] - d0[k]) * FPS; if (last) lsum[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] += v * v; gd6[k] -= 2.0f * FPS * v * w_trs; }
           if (t > 0) for (int k = 0; k < 6; ++k) { const float v = (d0[k] - s.d6[(t - 1) * 6 + k]) * FPS; gd6[k] += 2.0f * FPS * v * w_trs; }
           for (int r = 0; r < 3; ++r) { gRk[r * 3 + 0] += gd6[r]; gRk[r * 3 + 1] += gd6[3 + r]; }
         }
@@ -733,17 +826,17 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
           float gTi[12];
           for (int k = 0; k < 12; ++k) gTi[k] = 0.f;
           for (int o = 0; o < P; ++o) {
-            if (o == p || sc.pc[o].vis[t] == 0.f) continue;
+            if (o == p || person_view(sc, o).vis[t] == 0.f) continue;
             float To[12], Ro[9];
-            cols_to_R(sc.ps[o].d6 + t * 6, Ro);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = sc.ps[o].tw[t * 3 + i]; }
+            cols_to_R(person_view(sc, o).d6 + t * 6, Ro);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view(sc, o).tw[t * 3 + i]; }
             float Toinv[12];
             invert34(To, Toinv);
             // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
             for (int dir = 0; dir < 2; ++dir) {
               const int a = dir == 0 ? p : o, b = dir == 0 ? o : p;
-              const float* target = sc.rel_cam + (((size_t)a * sc.rel_stride_p + b) * sc.rel_stride_t + t) * 12;
-              const float fw = (sc.pair_first[a * 8 + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
+              const float* target = sh.rel_cam + (((size_t)a * sh.rel_stride_p + b) * sh.rel_stride_t + t) * 12;
+              const float fw = (sh.pair_first[a * 8 + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
               float rel[12];
               if (dir == 0) mul34(Tiinv, To, rel); else mul34(Toinv, Ti, rel);
               float grel[12];
@@ -751,11 +844,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
               for (int i = 0; i < 3; ++i) {
                 for (int j = 0; j < 2; ++j) {
                   const float d = (target[i * 4 + j] - rel[i * 4 + j]) * fw;
-                  if (dir == 0) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d;
+                  if (dir == 0) if (last) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d;
                   grel[i * 4 + j] = -2.0f * d * fw * w_rel;
                 }
                 const float d = (target[i * 4 + 3] - rel[i * 4 + 3]) * fw;
-                if (dir == 0) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d * st.rel_trans_weight;
+                if (dir == 0) if (last) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d * st.rel_trans_weight;
                 grel[i * 4 + 3] = -2.0f * d * fw * w_rel * st.rel_trans_weight;
               }
               if (w_rel == 0.f) continue;
@@ -776,115 +869,118 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         for (int k = 0; k < 6; ++k) s.g_d6[t * 6 + k] = g6[k];
         for (int k = 0; k < 3; ++k) s.g_tw[t * 3 + k] = g_tw[k];
       }
+      GLAMR_MARK(rt, 11);
       // camera-only terms on the camera-to-world transform  (loss_func.py:76-114)
       if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i)
           for (int j = 0; j < 2; ++j) {
-            if (t + 1 < T) { const float v = (Mi[i * 4 + j] - sc.cam_inv[(size_t)(t + 1) * 12 + i * 4 + j]) * FPS; lsum[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] += v * v; gCi[i * 4 + j] += 2.0f * FPS * v * w_crs; }
-            if (t > 0) { const float v = (sc.cam_inv[(size_t)(t - 1) * 12 + i * 4 + j] - Mi[i * 4 + j]) * FPS; gCi[i * 4 + j] -= 2.0f * FPS * v * w_crs; }
+            if (t + 1 < T) { const float v = (Mi[i * 4 + j] - sh.cam_inv[(size_t)(t + 1) * 12 + i * 4 + j]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] += v * v; gCi[i * 4 + j] += 2.0f * FPS * v * w_crs; }
+            if (t > 0) { const float v = (sh.cam_inv[(size_t)(t - 1) * 12 + i * 4 + j] - Mi[i * 4 + j]) * FPS; gCi[i * 4 + j] -= 2.0f * FPS * v * w_crs; }
           }
       }
       if (on(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i) {
-          if (t + 1 < T) { const float v = (sc.cam_inv[(size_t)(t + 1) * 12 + i * 4 + 3] - Mi[i * 4 + 3]) * FPS; lsum[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] += v * v; gCi[i * 4 + 3] -= 2.0f * FPS * v * w_cos; }
-          if (t > 0) { const float v = (Mi[i * 4 + 3] - sc.cam_inv[(size_t)(t - 1) * 12 + i * 4 + 3]) * FPS; gCi[i * 4 + 3] += 2.0f * FPS * v * w_cos; }
+          if (t + 1 < T) { const float v = (sh.cam_inv[(size_t)(t + 1) * 12 + i * 4 + 3] - Mi[i * 4 + 3]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] += v * v; gCi[i * 4 + 3] -= 2.0f * FPS * v * w_cos; }
+          if (t > 0) { const float v = (Mi[i * 4 + 3] - sh.cam_inv[(size_t)(t - 1) * 12 + i * 4 + 3]) * FPS; gCi[i * 4 + 3] += 2.0f * FPS * v * w_cos; }
         }
       }
       if (on(GLAMR_LOSS_CAM_UP_REG) && (!ffo(GLAMR_LOSS_CAM_UP_REG) || t == 0)) {
         const float fw = t < 10 ? st.first_frame_weight[GLAMR_LOSS_CAM_UP_REG] : 1.0f;
-        lsum[GLAMR_LOSS_CAM_UP_REG] += Mi[2 * 4 + 1] * fw;
+        if (last) lsum[GLAMR_LOSS_CAM_UP_REG] += Mi[2 * 4 + 1] * fw;
         gCi[2 * 4 + 1] += fw * w_up;
       }
+      GLAMR_MARK(rt, 12);
       if (cam_from_person) {
-        for (int k = 0; k < 12; ++k) { sc.g_cam[(size_t)t * 12 + k] = gC[k]; sc.g_caminv[(size_t)t * 12 + k] = gCi[k]; }
+        for (int k = 0; k < 12; ++k) { sh.g_cam[(size_t)t * 12 + k] = gC[k]; sh.g_caminv[(size_t)t * 12 + k] = gCi[k]; }
       } else if (update && var_cam) {
         // ---- G (own camera parameters): this frame's gradient is complete, no other thread contributes -------------------
         const int row = fixed_cam ? 0 : t;
         invert34_bwd(M, gCi, gC);
         float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
         get_R(gC, gR);
-        rm::rot6d_to_rotmat_bwd(sc.cp + l.cam_rot6d + row * 6, gR, g6);
         if (fixed_cam) {
+          rm::rot6d_to_rotmat_bwd(sh.cp + l.cam_rot6d + row * 6, gR, g6);
           for (int k = 0; k < 6; ++k) gfix[k] += g6[k];
           for (int k = 0; k < 3; ++k) gfix[6 + k] += gC[k * 4 + 3];
         } else {
+          rm::rot6d_to_rotmat_bwd(a_rot.P, gR, g6);
           const float gt3[3] = {gC[3], gC[7], gC[11]};
-          adam_block<6>(sc.cp, sc.cm, sc.cv, sc.store_grad ? sc.cg : nullptr, l.cam_rot6d + t * 6, g6, ac);
-          adam_block<3>(sc.cp, sc.cm, sc.cv, sc.store_grad ? sc.cg : nullptr, l.cam_trans + t * 3, gt3, ac);
+          a_rot.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, l.cam_rot6d + t * 6, g6, ac);
+          a_tr.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, l.cam_trans + t * 3, gt3, ac);
         }
       }
       if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
-        for (int k = 0; k < 3; ++k) { const float r = sc.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
+        for (int k = 0; k < 3; ++k) { const float r = sh.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
     }
     GLAMR_MARK(rt, 4);
     if (update && var_cam && fixed_cam) {
       for (int k = 0; k < 9; ++k) gfix[k] = rt.reduce_sum(gfix[k]);
       if (rt.tid() == 0) {
-        for (int k = 0; k < 6; ++k) { const int i = l.cam_rot6d + k; if (sc.store_grad) sc.cg[i] = gfix[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[k], ac); }
-        for (int k = 0; k < 3; ++k) { const int i = l.cam_trans + k; if (sc.store_grad) sc.cg[i] = gfix[6 + k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], gfix[6 + k], ac); }
+        for (int k = 0; k < 6; ++k) { const int i = l.cam_rot6d + k; if (sh.store_grad) sh.cg[i] = gfix[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[k], ac); }
+        for (int k = 0; k < 3; ++k) { const int i = l.cam_trans + k; if (sh.store_grad) sh.cg[i] = gfix[6 + k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[6 + k], ac); }
       }
     } else if (update && cam_from_person) {
       // ---- G (camera derived from the persons): gradient of every frame's averaged transform, folded onto its source frame ----
       rt.sync();
       for (int t = rt.tid(); t < T; t += rt.nthreads()) {
         float gMi[12];
-        for (int k = 0; k < 12; ++k) gMi[k] = sc.g_caminv[(size_t)t * 12 + k];
-        invert34_bwd(sc.cam_inv + (size_t)t * 12, sc.g_cam + (size_t)t * 12, gMi);     // cam_pose = invert(cam_inv)
+        for (int k = 0; k < 12; ++k) gMi[k] = sh.g_caminv[(size_t)t * 12 + k];
+        invert34_bwd(sh.cam_inv + (size_t)t * 12, sh.g_cam + (size_t)t * 12, gMi);     // cam_pose = invert(cam_inv)
         // cam_inv = [6d->R(r6) | avg_t + res]; r6 = avg cols (+ res on empty frames)
-        const int src = sc.fill_src[t];
+        const int src = sh.fill_src[t];
         float avg6[6];
         {
           float avg[12];
           for (int k = 0; k < 12; ++k) avg[k] = 0.f;
           for (int p = 0; p < P; ++p) {
-            if (sc.pc[p].vis[src] == 0.f) continue;
+            if (person_view(sc, p).vis[src] == 0.f) continue;
             float Tw[12], Rk[9], C[12];
-            cols_to_R(sc.ps[p].d6 + src * 6, Rk);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].tw[src * 3 + i]; }
-            mul34(Tw, sc.pc[p].person2cam + (size_t)src * 12, C);
+            cols_to_R(person_view(sc, p).d6 + src * 6, Rk);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view(sc, p).tw[src * 3 + i]; }
+            mul34(Tw, person_view(sc, p).person2cam + (size_t)src * 12, C);
             for (int k = 0; k < 12; ++k) avg[k] += C[k];
           }
-          const float inv_n = 1.0f / (float)sc.n_vis_persons[src];
+          const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
           for (int r = 0; r < 3; ++r) { avg6[r] = avg[r * 4 + 0] * inv_n; avg6[3 + r] = avg[r * 4 + 1] * inv_n; }
-          if (sc.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) avg6[k] += sc.cp[l.cam_inv_rot_res + t * 6 + k];
+          if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) avg6[k] += sh.cp[l.cam_inv_rot_res + t * 6 + k];
         }
         float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
         get_R(gMi, gR);
         rm::rot6d_to_rotmat_bwd(avg6, gR, g6);
-        float* ga = sc.g_avg + (size_t)t * 12;
+        float* ga = sh.g_avg + (size_t)t * 12;
         for (int r = 0; r < 3; ++r) { ga[r * 4 + 0] = g6[r]; ga[r * 4 + 1] = g6[3 + r]; ga[r * 4 + 2] = 0.f; ga[r * 4 + 3] = gMi[r * 4 + 3]; }
         float g_tres[3] = {gMi[3], gMi[7], gMi[11]};
         if (active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
           const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
-          for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sc.cp[l.cam_inv_trans_res + t * 3 + k] * wreg;
+          for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sh.cp[l.cam_inv_trans_res + t * 3 + k] * wreg;
         }
-        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k; if (sc.store_grad) sc.cg[i] = g_tres[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], g_tres[k], ac); }
-        if (sc.n_vis_persons[t] == 0)
-          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k; if (sc.store_grad) sc.cg[i] = g6[k]; adam(sc.cp[i], sc.cm[i], sc.cv[i], g6[k], ac); }
+        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k; if (sh.store_grad) sh.cg[i] = g_tres[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], g_tres[k], ac); }
+        if (sh.n_vis_persons[t] == 0)
+          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], g6[k], ac); }
       }
       rt.sync();
       for (int t = rt.tid(); t < T; t += rt.nthreads()) {
-        if (sc.n_vis_persons[t] == 0) continue;                 // only frames with persons are sources
+        if (sh.n_vis_persons[t] == 0) continue;                 // only frames with persons are sources
         float ga[12];
         for (int k = 0; k < 12; ++k) ga[k] = 0.f;
         for (int u = 0; u < T; ++u) {
-          if (sc.fill_src[u] != t) continue;
-          for (int k = 0; k < 12; ++k) ga[k] += sc.g_avg[(size_t)u * 12 + k];
+          if (sh.fill_src[u] != t) continue;
+          for (int k = 0; k < 12; ++k) ga[k] += sh.g_avg[(size_t)u * 12 + k];
         }
-        const float inv_n = 1.0f / (float)sc.n_vis_persons[t];
+        const float inv_n = 1.0f / (float)sh.n_vis_persons[t];
         for (int k = 0; k < 12; ++k) ga[k] *= inv_n;
         for (int p = 0; p < P; ++p) {
-          if (sc.pc[p].vis[t] == 0.f) continue;
+          if (person_view(sc, p).vis[t] == 0.f) continue;
           float Tw[12], Rk[9], gTw[12];
           for (int k = 0; k < 12; ++k) gTw[k] = 0.f;
-          cols_to_R(sc.ps[p].d6 + t * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = sc.ps[p].tw[t * 3 + i]; }
-          mul34_bwd(Tw, sc.pc[p].person2cam + (size_t)t * 12, ga, gTw, nullptr);
+          cols_to_R(person_view(sc, p).d6 + t * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view(sc, p).tw[t * 3 + i]; }
+          mul34_bwd(Tw, person_view(sc, p).person2cam + (size_t)t * 12, ga, gTw, nullptr);
           float gRk[9], g6[6];
           get_R(gTw, gRk);
-          fold_R_grad(sc.ps[p].d6 + t * 6, gRk, g6);
-          for (int k = 0; k < 6; ++k) sc.ps[p].g_d6[t * 6 + k] += g6[k];
-          for (int k = 0; k < 3; ++k) sc.ps[p].g_tw[t * 3 + k] += gTw[k * 4 + 3];
+          fold_R_grad(person_view(sc, p).d6 + t * 6, gRk, g6);
+          for (int k = 0; k < 6; ++k) person_view(sc, p).g_d6[t * 6 + k] += g6[k];
+          for (int k = 0; k < 3; ++k) person_view(sc, p).g_tw[t * 3 + k] += gTw[k * 4 + 3];
         }
       }
       // the fold writes g_d6 / g_tw of frame t from thread t only: the owner continues without a barrier
@@ -894,9 +990,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       for (int t = rt.tid(); t < T; t += rt.nthreads())
         for (int k = 0; k < 3; ++k) {
           const int i = l.cam_inv_trans_res + t * 3 + k;
-          const float g = 2.0f * FPS * FPS * sc.cp[i] * wreg;
-          if (sc.store_grad) sc.cg[i] = g;
-          adam(sc.cp[i], sc.cm[i], sc.cv[i], g, ac);
+          const float g = 2.0f * FPS * FPS * sh.cp[i] * wreg;
+          if (sh.store_grad) sh.cg[i] = g;
+          adam(sh.cp[i], sh.cm[i], sh.cv[i], g, ac);
         }
     }
     GLAMR_MARK(rt, 5);
@@ -907,22 +1003,28 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
-        const PersonConst& c = sc.pc[p];
-        PersonState& s = sc.ps[p];
+        const PersonView c = person_view(sc, p);
+        const PersonView& s = c;
         const bool ex = t >= c.fr_start && t < c.fr_end;
         const int e = t - c.fr_start;
+        // parameter state of this frame, requested before anything is computed
+        const bool upd_wd = has_wd && update && (st.var_mask & GLAMR_VAR_WORLD_DHEADING);
+        const bool upd_rot = ex && update && (st.var_mask & GLAMR_VAR_LOCAL_ROT);
+        const bool upd_z = ex && update && (st.var_mask & GLAMR_VAR_LOCAL_Z);
+        AdamRegs<1> a_wd;
+        AdamRegs<6> a_rot;
+        AdamRegs<1> a_z;
+        if (upd_wd) a_wd.load(s.p, s.m, s.v, l.world_dheading + t);
+        if (upd_rot) a_rot.load(s.p, s.m, s.v, l.local_rot + e * 6); else if (ex) for (int k = 0; k < 6; ++k) a_rot.P[k] = s.p[l.local_rot + e * 6 + k];
+        if (upd_z) a_z.load(s.p, s.m, s.v, l.local_z + e); else if (ex) a_z.P[0] = s.p[l.local_z + e];
         // R_w = Rz(phi) [b2 b3 | .]:  d/dphi = J R_w with J = [[0,-1,0],[1,0,0],[0,0,0]]
         const float* d6 = s.d6 + t * 6;
         const float* g6 = s.g_d6 + t * 6;
         const float gphi = (g6[1] * d6[0] - g6[0] * d6[1]) + (g6[4] * d6[3] - g6[3] * d6[4]);
-        if (has_wd && update && (st.var_mask & GLAMR_VAR_WORLD_DHEADING)) {
-          const int i = l.world_dheading + t;
-          if (sc.store_grad) s.g[i] = gphi;
-          adam(s.p[i], s.m[i], s.v[i], gphi, ac);
-        }
+        if (upd_wd) { const float gw[1] = {gphi}; a_wd.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.world_dheading + t, gw, ac); }
         if (!ex) { s.g_theta[t] = 0.f; s.g_xy[t * 2 + 0] = 0.f; s.g_xy[t * 2 + 1] = 0.f; continue; }
-        const LocalRow L = load_row(s.Lc, sc.TM, t);
-        const float cs = s.Lc[10 * sc.TM + t], sn = s.Lc[11 * sc.TM + t];
+        const LocalRow L = load_row(s.Lc, sh.TM, t);
+        const float cs = s.Lc[10 * sh.TM + t], sn = s.Lc[11 * sh.TM + t];
         const float gth = gphi;
         float gr6[6] = {0, 0, 0, 0, 0, 0};
         {
@@ -940,24 +1042,23 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
         {
           float g6r[6];
           for (int k = 0; k < 6; ++k) {
-            const float r = s.p[l.local_rot + e * 6 + k] * FPS;
-            if (on(GLAMR_LOSS_LOCAL_ROT_REG)) lsum[GLAMR_LOSS_LOCAL_ROT_REG] += r * r;
+            const float r = a_rot.P[k] * FPS;
+            if (on(GLAMR_LOSS_LOCAL_ROT_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_ROT_REG] += r * r;
             g6r[k] = gr6[k] + 2.0f * FPS * r * w_rot;
           }
-          if (update && (st.var_mask & GLAMR_VAR_LOCAL_ROT)) adam_block<6>(s.p, s.m, s.v, sc.store_grad ? s.g : nullptr, l.local_rot + e * 6, g6r, ac);
+          if (upd_rot) a_rot.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.local_rot + e * 6, g6r, ac);
         }
         {
-          const int i = l.local_z + e;
-          const float r = s.p[i] * FPS;
-          if (on(GLAMR_LOSS_LOCAL_Z_REG)) lsum[GLAMR_LOSS_LOCAL_Z_REG] += r * r;
-          const float g = s.g_tw[t * 3 + 2] + 2.0f * FPS * r * w_z;
-          if (update && (st.var_mask & GLAMR_VAR_LOCAL_Z)) { if (sc.store_grad) s.g[i] = g; adam(s.p[i], s.m[i], s.v[i], g, ac); }
+          const float r = a_z.P[0] * FPS;
+          if (on(GLAMR_LOSS_LOCAL_Z_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_Z_REG] += r * r;
+          const float gz[1] = {s.g_tw[t * 3 + 2] + 2.0f * FPS * r * w_z};
+          if (upd_z) a_z.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.local_z + e, gz, ac);
         }
       }
     if (update) {
       {
         float* ch[16];
-        for (int p = 0; p < P; ++p) { ch[2 * p] = sc.ps[p].g_xy; ch[2 * p + 1] = sc.ps[p].g_xy + 1; }
+        for (int p = 0; p < P; ++p) { ch[2 * p] = person_view(sc, p).g_xy; ch[2 * p + 1] = person_view(sc, p).g_xy + 1; }
         rt.scan_multi(ch, 2 * P, T, 2, true);
       }
       rt.sync();
@@ -965,64 +1066,63 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       // ---- I: reverse of B ----------------------------------------------------------------------------------------------
       for (int t = rt.tid(); t < T; t += rt.nthreads())
         for (int p = 0; p < P; ++p) {
-          const PersonConst& c = sc.pc[p];
-          PersonState& s = sc.ps[p];
+          const PersonView c = person_view(sc, p);
+          const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start, n = c.fr_end - c.fr_start;
+          const bool upd_dxy = e > 0 && (st.var_mask & GLAMR_VAR_LOCAL_DXY);
+          AdamRegs<2> a_dxy;
+          if (upd_dxy) a_dxy.load(s.p, s.m, s.v, l.local_dxy + e * 2); else if (e > 0) for (int k = 0; k < 2; ++k) a_dxy.P[k] = s.p[l.local_dxy + e * 2 + k];
           // contribution of d[e+1] = Rot(theta[e]) L[e+1].xy to g_theta[e]
           if (e + 1 < n) {
-            const LocalRow Ln = load_row(s.Lc, sc.TM, t + 1);
-            const float th = s.theta[t];
-            float cs, sn;
-            rm::sincos_(th, sn, cs);
+            const LocalRow Ln = load_row(s.Lc, sh.TM, t + 1);
+            const float cs = s.csn[t * 2 + 0], sn = s.csn[t * 2 + 1];
             const float gdx = s.g_xy[(t + 1) * 2 + 0], gdy = s.g_xy[(t + 1) * 2 + 1];
             s.g_theta[t] += gdx * (-Ln.dx * sn - Ln.dy * cs) + gdy * (Ln.dx * cs - Ln.dy * sn);
           }
           float gx = s.g_xy[t * 2 + 0], gy = s.g_xy[t * 2 + 1];
           if (e > 0) {
-            const float th = s.theta[t - 1];
-            float cs, sn;
-            rm::sincos_(th, sn, cs);
+            const float cs = s.csn[(t - 1) * 2 + 0], sn = s.csn[(t - 1) * 2 + 1];
             const float a = gx * cs + gy * sn, b = -gx * sn + gy * cs;
             gx = a; gy = b;
           }
           const float g[2] = {gx, gy};
           if (e == 0) {
             if (st.var_mask & GLAMR_VAR_LOCAL_XY)
-              for (int k = 0; k < 2; ++k) { const int i = l.local_xy + k; if (sc.store_grad) s.g[i] = g[k]; adam(s.p[i], s.m[i], s.v[i], g[k], ac); }
+              for (int k = 0; k < 2; ++k) { const int i = l.local_xy + k; if (sh.store_grad) s.g[i] = g[k]; adam(s.p[i], s.m[i], s.v[i], g[k], ac); }
           } else {
             float g2[2];
             for (int k = 0; k < 2; ++k) {
-              const float r = s.p[l.local_dxy + e * 2 + k] * FPS;
-              if (on(GLAMR_LOSS_LOCAL_DXY_REG)) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r;
+              const float r = a_dxy.P[k] * FPS;
+              if (on(GLAMR_LOSS_LOCAL_DXY_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r;
               g2[k] = g[k] + 2.0f * FPS * r * w_dxy;
             }
-            if (st.var_mask & GLAMR_VAR_LOCAL_DXY) adam_block<2>(s.p, s.m, s.v, sc.store_grad ? s.g : nullptr, l.local_dxy + e * 2, g2, ac);
+            if (upd_dxy) a_dxy.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.local_dxy + e * 2, g2, ac);
           }
         }
       {
         float* ch[8];
-        for (int p = 0; p < P; ++p) ch[p] = sc.ps[p].g_theta;
+        for (int p = 0; p < P; ++p) ch[p] = person_view(sc, p).g_theta;
         rt.scan_multi(ch, P, T, 1, true);
       }
       GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
       for (int t = rt.tid(); t < T; t += rt.nthreads())
         for (int p = 0; p < P; ++p) {
-          const PersonConst& c = sc.pc[p];
-          PersonState& s = sc.ps[p];
+          const PersonView c = person_view(sc, p);
+          const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start;
           const float gh = s.g_theta[t];
           if (e == 0) {
-            if (st.var_mask & GLAMR_VAR_LOCAL_HEADING) { const int i = l.local_heading; if (sc.store_grad) s.g[i] = gh; adam(s.p[i], s.m[i], s.v[i], gh, ac); }
+            if (st.var_mask & GLAMR_VAR_LOCAL_HEADING) { const int i = l.local_heading; if (sh.store_grad) s.g[i] = gh; adam(s.p[i], s.m[i], s.v[i], gh, ac); }
           } else {
             const int i = l.local_dheading + e;
             const float v = s.p[i];
-            if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
+            if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
             if (!(st.var_mask & GLAMR_VAR_LOCAL_DHEADING)) continue;
             const float g = (c.dheading_mask ? gh * c.dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cosf(v) - 1.0f) * (-sinf(v)) + sinf(v) * cosf(v)) * w_dh;
-            if (sc.store_grad) s.g[i] = g;
+            if (sh.store_grad) s.g[i] = g;
             adam(s.p[i], s.m[i], s.v[i], g, ac);
           }
         }
@@ -1030,11 +1130,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
     // regulariser values that do not depend on being optimised (reported every evaluation)
     if (last) {
       for (int p = 0; p < P && !update; ++p) {
-        PersonState& s = sc.ps[p];
-        const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
+        const PersonView s = person_view(sc, p);
+        const int n = person_view(sc, p).fr_end - person_view(sc, p).fr_start;
         for (int e = rt.tid() + 1; e < n; e += rt.nthreads()) {
-          if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[l.local_dxy + e * 2 + k] * FPS; lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
-          if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float v = s.p[l.local_dheading + e]; const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
+          if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[l.local_dxy + e * 2 + k] * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
+          if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float v = s.p[l.local_dheading + e]; const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
         }
       }
       // block-reduce and normalise the reported (unweighted) loss values
@@ -1042,7 +1142,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc) {
       for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) tot[i] = rt.reduce_sum(lsum[i]);
       const float cnt = rt.reduce_sum(kp_dist_cnt);
       if (rt.tid() == 0) {
-        float* o = sc.losses;
+        float* o = sh.losses;
         o[GLAMR_LOSS_KP_2D] = tot[GLAMR_LOSS_KP_2D] / n_vis_total;
         o[GLAMR_LOSS_KP_2D_DIST] = tot[GLAMR_LOSS_KP_2D_DIST] / cnt;
         o[GLAMR_LOSS_REL_TRANSFORM] = P > 1 ? tot[GLAMR_LOSS_REL_TRANSFORM] / n_rel : 0.f;

@@ -14,8 +14,9 @@ from oracle.port import build
 from oracle import make_golden as mg
 from tests.grecon_common import j_local_from_oracle
 
-NAMES = ['A heading + scan + barrier', 'B displacement + scan', 'C/D world pose, camera + barrier', 'camera from persons', 'E residuals + own-camera Adam',
-         'G shared-camera gradients', 'H orientation reverse + scan + barrier', 'I displacement reverse + scan', 'J heading reverse (+ loss reduce)']
+NAMES = ['A heading + scan + barrier', 'B displacement + scan', 'C/D world pose, camera + barrier', 'camera from persons', 'E5 own-camera backward + Adam',
+         'G shared-camera gradients', 'H orientation reverse + scan + barrier', 'I displacement reverse + scan', 'J heading reverse (+ loss reduce)',
+         'E1 loads, camera-relative orientation', 'E2 keypoints', 'E3 smoothness, relative transforms, fold', 'E4 camera smoothness terms', '-', '-', '-']
 dev = torch.device('cuda:0')
 root = build.ensure_synthetic_assets('/tmp/glamr_bench_assets')
 cfg_id = sys.argv[2] if len(sys.argv) > 2 else 'glamr_dynamic'
@@ -36,7 +37,7 @@ ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), d
 for rep in range(2):
     _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, _lib.ptr(ws), _lib.current_stream()))
     torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 9)()
+out = (ctypes.c_ulonglong * 16)()
 assert fn(out) == 0
 tot = sum(out)
 print('%s, %d scenes, %d iterations: %.1f us/iteration in the loop' % (cfg_id, S, sd.niters, tot * 0.01 / sd.niters))
