@@ -25,6 +25,8 @@ struct DeviceRT {
   // In-place inclusive prefix (reverse: suffix) sums of up to RT_MAX_CH arrays ch[c][i*stride], i in [0,n).  Element i is read and
   // written by thread i mod blockDim only, so a caller whose next phase touches only its own elements needs no barrier after it;
   // one barrier per chunk of blockDim elements happens inside.
+  // LDS: the arrays are known to be in LDS (ds_read / ds_write instead of flat accesses), else in global memory
+  template <bool LDS = false>
   __device__ void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = (blockDim.x + 63) >> 6;
@@ -39,7 +41,7 @@ struct DeviceRT {
       gen++;
       float x[RT_MAX_CH];
       for (int c = 0; c < nch; ++c) {
-        float v = (i < n) ? ch[c][idx] : 0.f;
+        float v = (i < n) ? elem<LDS>(ch[c], idx) : 0.f;
         if (!reverse) {
           for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_up(v, off); if (lane >= off) v += y; }
           if (lane == 63) r[c * 16 + wave] = v;
@@ -53,10 +55,14 @@ struct DeviceRT {
       for (int c = 0; c < nch; ++c) {
         float pre = carry[c], tot = 0.f;
         for (int w = 0; w < nw; ++w) { const float t = r[c * 16 + w]; tot += t; if (reverse ? (w > wave) : (w < wave)) pre += t; }
-        if (i < n) ch[c][idx] = x[c] + pre;
+        if (i < n) elem<LDS>(ch[c], idx) = x[c] + pre;
         carry[c] += tot;
       }
     }
+  }
+  template <bool LDS> static __device__ __forceinline__ float& elem(float* base, size_t idx) {
+    if (LDS) return *(float*)((__attribute__((address_space(3))) float*)base + idx);
+    return *(float*)((__attribute__((address_space(1))) float*)base + idx);
   }
   __device__ __forceinline__ int tid() const { return threadIdx.x; }
   __device__ __forceinline__ int nthreads() const { return blockDim.x; }

@@ -28,6 +28,7 @@ struct KernelArgs {
   unsigned fast_floats;
 };
 
+template <bool FAST>
 __global__ __launch_bounds__(MAX_THREADS) void grecon_stage_kernel(KernelArgs a) {
   __shared__ float red[RT_RED_FLOATS];
   __shared__ Scene sc;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(MAX_THREADS) void grecon_stage_kernel(KernelArgs a)
   }
   __syncthreads();
   glamr::DeviceRT rt{red};
-  run_scene(rt, sc, a.st, a.lay);
+  run_scene<FAST>(rt, sc, a.st, a.lay);
 }
 
 }  // namespace grecon
@@ -94,8 +95,12 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   ka.use_lds = base <= LDS_BUDGET;
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
   ka.fast_floats = (unsigned)(dyn / sizeof(float));
-  GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grecon_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-  hipLaunchKernelGGL(grecon_stage_kernel, dim3(batch->n_scenes), dim3(threads), dyn, stream, ka);
+  if (ka.use_lds) {
+    GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grecon_stage_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    hipLaunchKernelGGL(grecon_stage_kernel<true>, dim3(batch->n_scenes), dim3(threads), dyn, stream, ka);
+  } else {
+    hipLaunchKernelGGL(grecon_stage_kernel<false>, dim3(batch->n_scenes), dim3(threads), 0, stream, ka);
+  }
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }

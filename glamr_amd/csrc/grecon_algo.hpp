@@ -102,6 +102,9 @@ struct Scene {
 // The scene description lives in LDS; a plain read leaves every pointer in two VECTOR registers per lane, and the optimiser hoists
 // dozens of them out of the iteration loop.  Everything in it is uniform over the workgroup, so the device build routes the hot
 // loop's copies through readfirstlane: they end up in scalar registers.
+// They also come out of LDS as GENERIC pointers (flat_load / flat_store with a 64-bit address per lane); the views say which memory
+// each array lives in -- workspace and batch arrays are global, the exchange arrays are LDS when the arena is on chip (FAST) --
+// so the loop runs on global_load with a scalar base and ds_read.
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class T> __device__ __forceinline__ T* uni(T* p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -109,9 +112,25 @@ template <class T> __device__ __forceinline__ T* uni(T* p) {
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// (the empty asm keeps the optimiser from folding the cast pair away, and pins the value to scalar registers)
+template <class T> __device__ __forceinline__ T* glob(T* p) {
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)uni(p);
+  asm("" : "+s"(g));
+  return (T*)g;
+}
+template <bool FAST, class T> __device__ __forceinline__ T* fastp(T* p) {
+  if (FAST) {
+    __attribute__((address_space(3))) T* g = (__attribute__((address_space(3))) T*)uni(p);
+    asm("" : "+s"(g));
+    return (T*)g;
+  }
+  return glob(p);
+}
 #else
 template <class T> inline T* uni(T* p) { return p; }
 inline int uni(int x) { return x; }
+template <class T> inline T* glob(T* p) { return p; }
+template <bool FAST, class T> inline T* fastp(T* p) { return p; }
 #endif
 
 struct PersonView {      // what the iteration loop needs of PersonConst + PersonState, uniform
@@ -121,18 +140,20 @@ struct PersonView {      // what the iteration loop needs of PersonConst + Perso
   float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc;
   const float *kpc, *kpc_ws;
 };
+template <bool FAST>
 GLAMR_HD PersonView person_view(const Scene& sc, int p) {
   const PersonConst& c = sc.pc[p];
   const PersonState& s = sc.ps[p];
   PersonView w;
   w.fr_start = uni(c.fr_start); w.fr_end = uni(c.fr_end); w.njc = uni(s.njc); w.njc_fast = uni(s.njc_fast);
-  w.vis = uni(c.vis); w.j_local = uni(c.j_local); w.kp_2d = uni(c.kp_2d); w.kp_score = uni(c.kp_score); w.cam_K = uni(c.cam_K); w.prior = uni(c.prior);
-  w.base_orient = uni(c.base_orient); w.base_trans = uni(c.base_trans); w.person2cam = uni(c.person2cam); w.dheading_mask = uni(c.dheading_mask);
-  w.h_prior = uni(s.h_prior); w.oc6 = uni(s.oc6); w.kp_wsum = uni(s.kp_wsum); w.vis_rank = uni(c.vis_rank);
-  w.p = uni(s.p); w.m = uni(s.m); w.v = uni(s.v); w.g = uni(s.g); w.theta = uni(s.theta); w.csn = uni(s.csn); w.xy = uni(s.xy); w.d6 = uni(s.d6);
-  w.tw = uni(s.tw); w.g_d6 = uni(s.g_d6); w.g_tw = uni(s.g_tw); w.orient_world = uni(s.orient_world); w.trans_world = uni(s.trans_world);
-  w.g_theta = uni(s.g_theta); w.g_xy = uni(s.g_xy); w.kp_2d_pred = uni(s.kp_2d_pred); w.orient_cam_in_world = uni(s.orient_cam_in_world); w.Lc = uni(s.Lc);
-  w.kpc = uni(s.kpc); w.kpc_ws = uni(s.kpc_ws);
+  w.vis = glob(c.vis); w.j_local = glob(c.j_local); w.kp_2d = glob(c.kp_2d); w.kp_score = glob(c.kp_score); w.cam_K = glob(c.cam_K); w.prior = glob(c.prior);
+  w.base_orient = glob(c.base_orient); w.base_trans = glob(c.base_trans); w.person2cam = glob(c.person2cam); w.dheading_mask = glob(c.dheading_mask);
+  w.h_prior = glob(s.h_prior); w.oc6 = glob(s.oc6); w.kp_wsum = glob(s.kp_wsum); w.vis_rank = glob(c.vis_rank);
+  w.p = glob(s.p); w.m = glob(s.m); w.v = glob(s.v); w.g = glob(s.g);
+  w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.tw = fastp<FAST>(s.tw);
+  w.g_d6 = fastp<FAST>(s.g_d6); w.g_tw = fastp<FAST>(s.g_tw); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy); w.Lc = fastp<FAST>(s.Lc);
+  w.orient_world = glob(s.orient_world); w.trans_world = glob(s.trans_world); w.kp_2d_pred = glob(s.kp_2d_pred); w.orient_cam_in_world = glob(s.orient_cam_in_world);
+  w.kpc = fastp<FAST>(s.kpc); w.kpc_ws = glob(s.kpc_ws);      // kpc is only dereferenced for the njc_fast joints that are on chip
   return w;
 }
 struct SceneView {
@@ -140,11 +161,12 @@ struct SceneView {
   float *cam_pose, *cam_inv, *g_cam, *g_caminv, *g_avg, *cp, *cm, *cv, *cg, *losses;
   int store_grad, rel_stride_p, rel_stride_t, TM;
 };
+template <bool FAST>
 GLAMR_HD SceneView scene_view(const Scene& sc) {
   SceneView w;
-  w.rel_cam = uni(sc.rel_cam); w.pair_first = uni(sc.pair_first); w.fill_src = uni(sc.fill_src); w.n_vis_persons = uni(sc.n_vis_persons);
-  w.cam_pose = uni(sc.cam_pose); w.cam_inv = uni(sc.cam_inv); w.g_cam = uni(sc.g_cam); w.g_caminv = uni(sc.g_caminv); w.g_avg = uni(sc.g_avg);
-  w.cp = uni(sc.cp); w.cm = uni(sc.cm); w.cv = uni(sc.cv); w.cg = uni(sc.cg); w.losses = uni(sc.losses);
+  w.rel_cam = glob(sc.rel_cam); w.pair_first = glob(sc.pair_first); w.fill_src = glob(sc.fill_src); w.n_vis_persons = glob(sc.n_vis_persons);
+  w.cam_pose = glob(sc.cam_pose); w.cam_inv = fastp<FAST>(sc.cam_inv); w.g_cam = glob(sc.g_cam); w.g_caminv = glob(sc.g_caminv); w.g_avg = glob(sc.g_avg);
+  w.cp = glob(sc.cp); w.cm = glob(sc.cm); w.cv = glob(sc.cv); w.cg = glob(sc.cg); w.losses = glob(sc.losses);
   w.store_grad = uni(sc.store_grad); w.rel_stride_p = uni(sc.rel_stride_p); w.rel_stride_t = uni(sc.rel_stride_t); w.TM = uni(sc.TM);
   return w;
 }
@@ -410,7 +432,7 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
 
 // ---- the per-scene driver --------------------------------------------------------------------------------------------
 
-template <class RT>
+template <bool FAST, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
   const int T = sc.T, P = sc.P;
   const bool var_cam = st.var_mask & GLAMR_VAR_CAM;
@@ -508,7 +530,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   const int niters = st.niters;
   double b1p = 1.0, b2p = 1.0;
   const int n_eval = niters > 0 ? niters : 1;
-  const SceneView sh = scene_view(sc);
+  const SceneView sh = scene_view<FAST>(sc);
   for (int it = 0; it < n_eval; ++it) {
     const bool last = (it == n_eval - 1);
     const bool update = niters > 0;
@@ -525,59 +547,59 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view(sc, p);
+        const PersonView c = person_view<FAST>(sc, p);
         float v = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const LocalRow L = local_row(c, l, t - c.fr_start);
-          store_row(person_view(sc, p).Lc, sh.TM, t, L);
+          store_row(person_view<FAST>(sc, p).Lc, sh.TM, t, L);
           // atan2(sin h, cos h) of the reference (:401-405) only wraps h into (-pi, pi]: done arithmetically
           v = L.h - 6.28318530717958647692f * rintf(L.h * 0.15915494309189533577f);
         }
-        person_view(sc, p).theta[t] = v;
+        person_view<FAST>(sc, p).theta[t] = v;
       }
     {
       float* ch[8];
-      for (int p = 0; p < P; ++p) ch[p] = person_view(sc, p).theta;
-      rt.scan_multi(ch, P, T, 1, false);
+      for (int p = 0; p < P; ++p) ch[p] = person_view<FAST>(sc, p).theta;
+      rt.template scan_multi<FAST>(ch, P, T, 1, false);
     }
     // own element of the prefix sum is final: its cos / sin serve phases B, C and I (this frame's and the next frame's)
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
         float sn, cs;
-        rm::sincos_(person_view(sc, p).theta[t], sn, cs);
-        person_view(sc, p).csn[t * 2 + 0] = cs;
-        person_view(sc, p).csn[t * 2 + 1] = sn;
+        rm::sincos_(person_view<FAST>(sc, p).theta[t], sn, cs);
+        person_view<FAST>(sc, p).csn[t * 2 + 0] = cs;
+        person_view<FAST>(sc, p).csn[t * 2 + 1] = sn;
       }
     rt.sync();
     GLAMR_MARK(rt, 0);
     // ---- B: planar displacement in world axes -------------------------------------------------------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view(sc, p);
+        const PersonView c = person_view<FAST>(sc, p);
         float dx = 0.f, dy = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const int e = t - c.fr_start;
-          const LocalRow L = load_row(person_view(sc, p).Lc, sh.TM, t);
+          const LocalRow L = load_row(person_view<FAST>(sc, p).Lc, sh.TM, t);
           dx = L.dx; dy = L.dy;
           if (e > 0) {
-            const float cs = person_view(sc, p).csn[(t - 1) * 2 + 0], sn = person_view(sc, p).csn[(t - 1) * 2 + 1];
+            const float cs = person_view<FAST>(sc, p).csn[(t - 1) * 2 + 0], sn = person_view<FAST>(sc, p).csn[(t - 1) * 2 + 1];
             dx = L.dx * cs - L.dy * sn;
             dy = L.dx * sn + L.dy * cs;
           }
         }
-        person_view(sc, p).xy[t * 2 + 0] = dx;
-        person_view(sc, p).xy[t * 2 + 1] = dy;
+        person_view<FAST>(sc, p).xy[t * 2 + 0] = dx;
+        person_view<FAST>(sc, p).xy[t * 2 + 1] = dy;
       }
     {
       float* ch[16];
-      for (int p = 0; p < P; ++p) { ch[2 * p] = person_view(sc, p).xy; ch[2 * p + 1] = person_view(sc, p).xy + 1; }
-      rt.scan_multi(ch, 2 * P, T, 2, false);
+      for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST>(sc, p).xy; ch[2 * p + 1] = person_view<FAST>(sc, p).xy + 1; }
+      rt.template scan_multi<FAST>(ch, 2 * P, T, 2, false);
     }
     GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
     for (int t = rt.tid(); t < T; t += rt.nthreads()) {
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view(sc, p);
+        const PersonView c = person_view<FAST>(sc, p);
         const PersonView& s = c;
         float c1[3], c2[3], tb[3], phi = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
@@ -636,11 +658,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float avg[12];
         for (int k = 0; k < 12; ++k) avg[k] = 0.f;
         for (int p = 0; p < P; ++p) {
-          if (person_view(sc, p).vis[src] == 0.f) continue;
+          if (person_view<FAST>(sc, p).vis[src] == 0.f) continue;
           float Tw[12], Rk[9], C[12];
-          cols_to_R(person_view(sc, p).d6 + src * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view(sc, p).tw[src * 3 + i]; }
-          mul34(Tw, person_view(sc, p).person2cam + (size_t)src * 12, C);
+          cols_to_R(person_view<FAST>(sc, p).d6 + src * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST>(sc, p).tw[src * 3 + i]; }
+          mul34(Tw, person_view<FAST>(sc, p).person2cam + (size_t)src * 12, C);
           for (int k = 0; k < 12; ++k) avg[k] += C[k];
         }
         const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
@@ -687,7 +709,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       float Rc[9];
       get_R(M, Rc);
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view(sc, p);
+        const PersonView c = person_view<FAST>(sc, p);
         const PersonView& s = c;
         const float* tw = s.tw + t * 3;
         float K[9], tgt[6];
@@ -826,10 +848,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           float gTi[12];
           for (int k = 0; k < 12; ++k) gTi[k] = 0.f;
           for (int o = 0; o < P; ++o) {
-            if (o == p || person_view(sc, o).vis[t] == 0.f) continue;
+            if (o == p || person_view<FAST>(sc, o).vis[t] == 0.f) continue;
             float To[12], Ro[9];
-            cols_to_R(person_view(sc, o).d6 + t * 6, Ro);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view(sc, o).tw[t * 3 + i]; }
+            cols_to_R(person_view<FAST>(sc, o).d6 + t * 6, Ro);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view<FAST>(sc, o).tw[t * 3 + i]; }
             float Toinv[12];
             invert34(To, Toinv);
             // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
@@ -933,11 +955,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           float avg[12];
           for (int k = 0; k < 12; ++k) avg[k] = 0.f;
           for (int p = 0; p < P; ++p) {
-            if (person_view(sc, p).vis[src] == 0.f) continue;
+            if (person_view<FAST>(sc, p).vis[src] == 0.f) continue;
             float Tw[12], Rk[9], C[12];
-            cols_to_R(person_view(sc, p).d6 + src * 6, Rk);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view(sc, p).tw[src * 3 + i]; }
-            mul34(Tw, person_view(sc, p).person2cam + (size_t)src * 12, C);
+            cols_to_R(person_view<FAST>(sc, p).d6 + src * 6, Rk);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST>(sc, p).tw[src * 3 + i]; }
+            mul34(Tw, person_view<FAST>(sc, p).person2cam + (size_t)src * 12, C);
             for (int k = 0; k < 12; ++k) avg[k] += C[k];
           }
           const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
@@ -970,17 +992,17 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         const float inv_n = 1.0f / (float)sh.n_vis_persons[t];
         for (int k = 0; k < 12; ++k) ga[k] *= inv_n;
         for (int p = 0; p < P; ++p) {
-          if (person_view(sc, p).vis[t] == 0.f) continue;
+          if (person_view<FAST>(sc, p).vis[t] == 0.f) continue;
           float Tw[12], Rk[9], gTw[12];
           for (int k = 0; k < 12; ++k) gTw[k] = 0.f;
-          cols_to_R(person_view(sc, p).d6 + t * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view(sc, p).tw[t * 3 + i]; }
-          mul34_bwd(Tw, person_view(sc, p).person2cam + (size_t)t * 12, ga, gTw, nullptr);
+          cols_to_R(person_view<FAST>(sc, p).d6 + t * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST>(sc, p).tw[t * 3 + i]; }
+          mul34_bwd(Tw, person_view<FAST>(sc, p).person2cam + (size_t)t * 12, ga, gTw, nullptr);
           float gRk[9], g6[6];
           get_R(gTw, gRk);
-          fold_R_grad(person_view(sc, p).d6 + t * 6, gRk, g6);
-          for (int k = 0; k < 6; ++k) person_view(sc, p).g_d6[t * 6 + k] += g6[k];
-          for (int k = 0; k < 3; ++k) person_view(sc, p).g_tw[t * 3 + k] += gTw[k * 4 + 3];
+          fold_R_grad(person_view<FAST>(sc, p).d6 + t * 6, gRk, g6);
+          for (int k = 0; k < 6; ++k) person_view<FAST>(sc, p).g_d6[t * 6 + k] += g6[k];
+          for (int k = 0; k < 3; ++k) person_view<FAST>(sc, p).g_tw[t * 3 + k] += gTw[k * 4 + 3];
         }
       }
       // the fold writes g_d6 / g_tw of frame t from thread t only: the owner continues without a barrier
@@ -1003,7 +1025,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
     for (int t = rt.tid(); t < T; t += rt.nthreads())
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view(sc, p);
+        const PersonView c = person_view<FAST>(sc, p);
         const PersonView& s = c;
         const bool ex = t >= c.fr_start && t < c.fr_end;
         const int e = t - c.fr_start;
@@ -1058,15 +1080,15 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     if (update) {
       {
         float* ch[16];
-        for (int p = 0; p < P; ++p) { ch[2 * p] = person_view(sc, p).g_xy; ch[2 * p + 1] = person_view(sc, p).g_xy + 1; }
-        rt.scan_multi(ch, 2 * P, T, 2, true);
+        for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST>(sc, p).g_xy; ch[2 * p + 1] = person_view<FAST>(sc, p).g_xy + 1; }
+        rt.template scan_multi<FAST>(ch, 2 * P, T, 2, true);
       }
       rt.sync();
       GLAMR_MARK(rt, 6);
       // ---- I: reverse of B ----------------------------------------------------------------------------------------------
       for (int t = rt.tid(); t < T; t += rt.nthreads())
         for (int p = 0; p < P; ++p) {
-          const PersonView c = person_view(sc, p);
+          const PersonView c = person_view<FAST>(sc, p);
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start, n = c.fr_end - c.fr_start;
@@ -1102,14 +1124,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         }
       {
         float* ch[8];
-        for (int p = 0; p < P; ++p) ch[p] = person_view(sc, p).g_theta;
-        rt.scan_multi(ch, P, T, 1, true);
+        for (int p = 0; p < P; ++p) ch[p] = person_view<FAST>(sc, p).g_theta;
+        rt.template scan_multi<FAST>(ch, P, T, 1, true);
       }
       GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
       for (int t = rt.tid(); t < T; t += rt.nthreads())
         for (int p = 0; p < P; ++p) {
-          const PersonView c = person_view(sc, p);
+          const PersonView c = person_view<FAST>(sc, p);
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start;
@@ -1130,8 +1152,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     // regulariser values that do not depend on being optimised (reported every evaluation)
     if (last) {
       for (int p = 0; p < P && !update; ++p) {
-        const PersonView s = person_view(sc, p);
-        const int n = person_view(sc, p).fr_end - person_view(sc, p).fr_start;
+        const PersonView s = person_view<FAST>(sc, p);
+        const int n = person_view<FAST>(sc, p).fr_end - person_view<FAST>(sc, p).fr_start;
         for (int e = rt.tid() + 1; e < n; e += rt.nthreads()) {
           if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[l.local_dxy + e * 2 + k] * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
           if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float v = s.p[l.local_dheading + e]; const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }

@@ -10,6 +10,7 @@ struct HostRT {
   int nthreads() const { return 1; }
   void sync() const {}
   float reduce_sum(float v) const { return v; }
+  template <bool LDS = false>
   void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) const {
     for (int c = 0; c < nch; ++c) scan(ch[c], n, stride, reverse);
   }
@@ -32,7 +33,7 @@ extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_
   for (int si = 0; si < b->n_scenes; ++si) {
     Scene sc;
     assemble_scene(*b, l, st, si, b->n_persons[si], b->seq_len[si], ws.data(), grads_out, sc);
-    run_scene(rt, sc, *st, l);
+    run_scene<false>(rt, sc, *st, l);
   }
   return 0;
 }
