@@ -10,6 +10,9 @@ LIB_PATH = os.path.join(PKG_DIR, 'libglamr_hip.so')
 HEADER = os.path.join(os.path.dirname(PKG_DIR), 'include', 'glamr_hip.h')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# per-file flags.  grecon.hip: `/` and sqrtf as v_rcp / v_sqrt (+1 Newton step) instead of the correctly rounded ~10-instruction
+# sequences -- the optimiser divides ~60 times per frame and iteration; results move in the last 1-2 ulp
+FILE_FLAGS = {'grecon.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt']}
 EXTRA_FLAGS = {k: v.split() for k, v in (kv.split('=', 1) for kv in os.environ.get('GLAMR_EXTRA_FLAGS', '').split(';') if kv)}
 
 
@@ -39,7 +42,7 @@ def build_library(force=False, verbose=False):
     for src in _sources():
         obj = os.path.join(bdir, os.path.basename(src) + '.o')
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + EXTRA_FLAGS.get(os.path.basename(src), []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)

@@ -3,6 +3,8 @@
 //
 // All activations are fp32 row-major [rows][ld] with ld a multiple of 4 (16-byte rows) so tiles move as dwordx4.
 #pragma once
+#include <cstdlib>
+#include <cstdio>
 #include "common.hpp"
 
 namespace glamr {
@@ -198,6 +200,8 @@ inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, 
                        int act = ACT_NONE, const float* R = nullptr, int ldr = 0, const float* rowbias = nullptr, int rows_per_group = 1, int ldrb = 0) {
   if (M <= 0) return GLAMR_OK;
   if (K % GT_K != 0 || ldx % 4 != 0) return fail(GLAMR_E_INVALID, "gemm: K=%d must be a multiple of %d and ldx=%d of 4", K, GT_K, ldx);
+  static const bool log_shapes = std::getenv("GLAMR_GEMM_LOG") != nullptr;      // development aid (tools/gemm_profile.py)
+  if (log_shapes) std::fprintf(stderr, "GEMM %d %d %d\n", M, N, K);
   GemmArgs a{X, W, bias, rowbias, R, Y, M, N, K, ldx, ldy, ldr, rows_per_group, ldrb, act};
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M), dim3(256), 0, st, a);
   return GLAMR_OK;
