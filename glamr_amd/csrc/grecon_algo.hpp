@@ -19,6 +19,7 @@
 //   G  camera gradients -> camera parameters (Adam) or back into the persons' transforms
 //   H  reverse of C;  suffix scans of g_xy and g_theta reverse B and A;  Adam on every trajectory variable.
 #pragma once
+#include <type_traits>
 #include "rotmath.hpp"
 #include "../../include/glamr_hip.h"
 
@@ -531,8 +532,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   double b1p = 1.0, b2p = 1.0;
   const int n_eval = niters > 0 ? niters : 1;
   const SceneView sh = scene_view<FAST>(sc);
-  for (int it = 0; it < n_eval; ++it) {
-    const bool last = (it == n_eval - 1);
+  // One evaluation (+ update).  Instantiated twice: the iterations that only update (no reported values, no outputs) and the LAST
+  // evaluation, which also writes the outputs and reduces the loss values -- keeping that code (axis-angle conversions, all 26
+  // joints, 13 accumulators) out of the hot instance keeps its registers out of it too.
+  auto evaluate = [&](auto last_tag) {
+    constexpr bool last = decltype(last_tag)::value;
     const bool update = niters > 0;
     b1p *= 0.9; b2p *= 0.999;
     AdamCoef ac;
@@ -700,9 +704,6 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int k = 0; k < 12; ++k) { gC[k] = 0.f; gCi[k] = 0.f; }
       // everything this frame needs from the workspace is requested up front
       const bool own_cam = update && var_cam && !fixed_cam && !cam_from_person;
-      AdamRegs<6> a_rot;
-      AdamRegs<3> a_tr;
-      if (own_cam) { a_rot.load(sh.cp, sh.cm, sh.cv, l.cam_rot6d + t * 6); a_tr.load(sh.cp, sh.cm, sh.cv, l.cam_trans + t * 3); }
       float M[12];
       for (int k = 0; k < 12; ++k) M[k] = sh.cam_pose[(size_t)t * 12 + k];
       const float* Mi = sh.cam_inv + (size_t)t * 12;
@@ -892,6 +893,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         for (int k = 0; k < 3; ++k) s.g_tw[t * 3 + k] = g_tw[k];
       }
       GLAMR_MARK(rt, 11);
+      // the camera's parameter state is requested here: the smoothness terms below cover the latency
+      AdamRegs<6> a_rot;
+      AdamRegs<3> a_tr;
+      if (own_cam) { a_rot.load(sh.cp, sh.cm, sh.cv, l.cam_rot6d + t * 6); a_tr.load(sh.cp, sh.cm, sh.cv, l.cam_trans + t * 3); }
       // camera-only terms on the camera-to-world transform  (loss_func.py:76-114)
       if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i)
@@ -1181,7 +1186,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       }
     }
     GLAMR_MARK(rt, 8);
-  }
+  };
+  for (int it = 0; it + 1 < n_eval; ++it) evaluate(std::false_type{});
+  evaluate(std::true_type{});
   rt.sync();
   GLAMR_MARK_END(rt);
 }
