@@ -88,7 +88,8 @@ struct Scene {
   int* fill_src;                      // [T] frame whose averaged camera a frame without persons inherits (:493-498)
   int* n_vis_persons;                 // [T] fr_num_persons
   float* cam_pose;                    // [T][12]  in/out
-  float* cam_inv;                     // [T][12]  scratch
+  float* cam_inv;                     // [T][12]  camera-to-world of the current evaluation (neighbours read it)
+  float* cam_t;                       // [T][3]   translation column of cam_pose (world-to-camera)
   float* g_cam; float* g_caminv;      // [T][12]
   float* g_avg;                       // [T][12] (cam-from-person)
   float* cp; float* cm; float* cv; float* cg;   // scene-level parameter block (camera), moments, gradient
@@ -159,14 +160,14 @@ GLAMR_HD PersonView person_view(const Scene& sc, int p) {
 }
 struct SceneView {
   const float* rel_cam; const int* pair_first; const int* fill_src; const int* n_vis_persons;
-  float *cam_pose, *cam_inv, *g_cam, *g_caminv, *g_avg, *cp, *cm, *cv, *cg, *losses;
+  float *cam_pose, *cam_inv, *cam_t, *g_cam, *g_caminv, *g_avg, *cp, *cm, *cv, *cg, *losses;
   int store_grad, rel_stride_p, rel_stride_t, TM;
 };
 template <bool FAST>
 GLAMR_HD SceneView scene_view(const Scene& sc) {
   SceneView w;
   w.rel_cam = glob(sc.rel_cam); w.pair_first = glob(sc.pair_first); w.fill_src = glob(sc.fill_src); w.n_vis_persons = glob(sc.n_vis_persons);
-  w.cam_pose = glob(sc.cam_pose); w.cam_inv = fastp<FAST>(sc.cam_inv); w.g_cam = glob(sc.g_cam); w.g_caminv = glob(sc.g_caminv); w.g_avg = glob(sc.g_avg);
+  w.cam_pose = glob(sc.cam_pose); w.cam_inv = fastp<FAST>(sc.cam_inv); w.cam_t = fastp<FAST>(sc.cam_t); w.g_cam = glob(sc.g_cam); w.g_caminv = glob(sc.g_caminv); w.g_avg = glob(sc.g_avg);
   w.cp = glob(sc.cp); w.cm = glob(sc.cm); w.cv = glob(sc.cv); w.cg = glob(sc.cg); w.losses = glob(sc.losses);
   w.store_grad = uni(sc.store_grad); w.rel_stride_p = uni(sc.rel_stride_p); w.rel_stride_t = uni(sc.rel_stride_t); w.TM = uni(sc.TM);
   return w;
@@ -328,13 +329,13 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
   l.scene_stride = l.person0 + max_persons * l.person_stride;
 }
 
-GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(12 + 38 * max_persons) * max_len; }
+GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(15 + 38 * max_persons) * max_len; }
 
 GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
   glamr_param_layout l;
   param_layout(max_persons, max_len, l);
   const size_t T = (size_t)max_len;
-  size_t n = 3 * (size_t)l.person0 + 4 * 12 * T + 2 * T + 64;                       // cm cv cg | cam_inv g_cam g_caminv g_avg | fill_src n_vis | pair_first
+  size_t n = 3 * (size_t)l.person0 + 4 * 12 * T + 3 * T + 2 * T + 64;                       // cm cv cg | cam_inv g_cam g_caminv g_avg | fill_src n_vis | pair_first
   n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 2 + 6 + 3 + 6 + 3 + 1 + 2 + 12 + 6 * NJ + 1 + 1 + 6) * T + 32);   // m v g | theta csn xy d6 tw g_d6 g_tw g_theta g_xy Lc | kpc vis_rank h_prior oc6 | kp_wsum
   return n;
 }
@@ -358,7 +359,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   sc.cm = take(l.person0); sc.cv = take(l.person0);
   float* cg_ws = take(l.person0);
   sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : cg_ws;
-  sc.cam_inv = takef(12 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
+  sc.cam_inv = takef(12 * TM); sc.cam_t = takef(3 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
   sc.fill_src = reinterpret_cast<int*>(take(TM)); sc.n_vis_persons = reinterpret_cast<int*>(take(TM));
   sc.pair_first = reinterpret_cast<int*>(take(64));
   for (int p = 0; p < b.max_persons; ++p) {
@@ -650,7 +651,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           for (int k = 0; k < 12; ++k) M[k] = sh.cam_pose[(size_t)t * 12 + k];
         }
         invert34(M, Mi);
-        for (int k = 0; k < 12; ++k) { sh.cam_pose[(size_t)t * 12 + k] = M[k]; sh.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
+        for (int k = 0; k < 12; ++k) sh.cam_inv[(size_t)t * 12 + k] = Mi[k];
+        for (int k = 0; k < 3; ++k) sh.cam_t[t * 3 + k] = M[k * 4 + 3];
+        if (last && var_cam) for (int k = 0; k < 12; ++k) sh.cam_pose[(size_t)t * 12 + k] = M[k];      // in/out array: the last forward's camera
       }
     }
     rt.sync();
@@ -678,7 +681,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         rm::rot6d_to_rotmat(r6, R);
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sh.cp[l.cam_inv_trans_res + t * 3 + i]; }
         invert34(Mi, M);
-        for (int k = 0; k < 12; ++k) { sh.cam_pose[(size_t)t * 12 + k] = M[k]; sh.cam_inv[(size_t)t * 12 + k] = Mi[k]; }
+        for (int k = 0; k < 12; ++k) sh.cam_inv[(size_t)t * 12 + k] = Mi[k];
+        for (int k = 0; k < 3; ++k) sh.cam_t[t * 3 + k] = M[k * 4 + 3];
+        if (last) for (int k = 0; k < 12; ++k) sh.cam_pose[(size_t)t * 12 + k] = M[k];
       }
       rt.sync();
     }
@@ -704,10 +709,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int k = 0; k < 12; ++k) { gC[k] = 0.f; gCi[k] = 0.f; }
       // everything this frame needs from the workspace is requested up front
       const bool own_cam = update && var_cam && !fixed_cam && !cam_from_person;
-      float M[12];
-      for (int k = 0; k < 12; ++k) M[k] = sh.cam_pose[(size_t)t * 12 + k];
+      // world-to-camera [Rc | tc] from the on-chip copies: Rc is the transpose of the camera-to-world rotation
       const float* Mi = sh.cam_inv + (size_t)t * 12;
-      float Rc[9];
+      float M[12], Rc[9];
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = Mi[j * 4 + i]; M[i * 4 + 3] = sh.cam_t[t * 3 + i]; }
       get_R(M, Rc);
       for (int p = 0; p < P; ++p) {
         const PersonView c = person_view<FAST>(sc, p);
@@ -816,19 +821,22 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             // only the joints that carry a score (14 of 26 for HybrIK input), from the compact table
             // the next joint's six values are fetched while the current one is processed (the rows that do not fit on chip come
             // from the workspace: hundreds of cycles each with one or two waves per SIMD to hide them)
-            const int njc = s.njc, TMs = sh.TM;
+            const int njc = s.njc, nf = s.njc_fast, TMs = sh.TM;
             float nx[6];
             auto fetch = [&](int jj) {
-              const float* o = (jj < s.njc_fast ? s.kpc : s.kpc_ws) + (size_t)jj * 6 * TMs + t;
+              const float* o = (jj < nf ? s.kpc : s.kpc_ws) + (size_t)jj * 6 * TMs + t;
               for (int k = 0; k < 6; ++k) nx[k] = o[k * TMs];
             };
-            if (njc > 0) fetch(0);
-            for (int jj = 0; jj < njc; ++jj) {
-              const float cur[6] = {nx[0], nx[1], nx[2], nx[3], nx[4], nx[5]};
-              if (jj + 1 < njc) fetch(jj + 1);
-              if (cur[5] == 0.f) continue;
-              joint(cur, cur[3], cur[4], cur[5], 0.f, -1);
-            }
+            auto run = [&](int lo, int hi) {
+              if (lo < hi) fetch(lo);
+              for (int jj = lo; jj < hi; ++jj) {
+                const float cur[6] = {nx[0], nx[1], nx[2], nx[3], nx[4], nx[5]};
+                if (jj + 1 < hi) fetch(jj + 1);
+                if (cur[5] == 0.f) continue;
+                joint(cur, cur[3], cur[4], cur[5], 0.f, -1);
+              }
+            };
+            run(0, njc);
           }
         }
         GLAMR_MARK(rt, 10);

@@ -20,13 +20,14 @@ def main():
     root = build.ensure_synthetic_assets('/tmp/glamr_bench_assets')
     cfg = get_config('glamr_dynamic')
     md = synth.make_smpl_model()
-    in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=md)
+    T = int(os.environ.get('GLAMR_MB_FRAMES', '300'))
+    in_dict = synth.make_in_dict(seed=0, num_frames=T, num_persons=1, smpl_model=md)
     ora = build.load_optimizer(root, cfg)
     data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 0))
     jl = j_local_from_oracle(ora.smpl, data)
     L = _lib.lib()
     spec = cfg['opt_stage_specs']['init_opt']
-    for S in (1, 64, 256, 1024):
+    for S in (1, 256) if 'GLAMR_MB_FRAMES' in os.environ else (1, 64, 256, 1024):
         packed = packing.PackedScenes([data] * S, [jl] * S, dev)
         sd = packing.stage_desc(spec, cfg['grecon_model_specs'], False)
         sb = packed.struct()
@@ -37,7 +38,9 @@ def main():
             _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, _lib.ptr(ws), _lib.current_stream()))
             torch.cuda.synchronize()
             dt = time.time() - t0
-        print('grecon stage: scenes=%4d  T=300  iters=%d  %.2f ms  (%.2f us/iter, %.1f scenes/s)' % (S, sd.niters, dt * 1e3, dt * 1e6 / sd.niters, S / dt))
+        print('grecon stage: scenes=%4d  T=%d  iters=%d  %.2f ms  (%.2f us/iter, %.1f scenes/s)' % (S, T, sd.niters, dt * 1e3, dt * 1e6 / sd.niters, S / dt))
+    if 'GLAMR_MB_FRAMES' in os.environ:
+        return
     # SMPL LBS
     from glamr_amd.lib.models.smpl import SMPL
     smpl = SMPL(os.path.join(root, 'data', 'body_models', 'smpl'), pose_type='body26fk', extra_regressor_path=os.path.join(root, 'data', 'J_regressor_extra.npy')).to(dev)
