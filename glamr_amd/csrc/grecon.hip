@@ -16,6 +16,12 @@ namespace grecon {
 #define GLAMR_GRECON_MAX_THREADS 512
 #endif
 constexpr int MAX_THREADS = GLAMR_GRECON_MAX_THREADS;
+#ifndef GLAMR_GRECON_WAVES_PER_EU
+#define GLAMR_GRECON_WAVES_PER_EU 2
+#endif
+#ifndef GLAMR_GRECON_LDS_KB
+#define GLAMR_GRECON_LDS_KB 150
+#endif
 
 struct KernelArgs {
   glamr_scene_batch b;
@@ -29,7 +35,7 @@ struct KernelArgs {
 };
 
 template <bool FAST>
-__global__ __launch_bounds__(MAX_THREADS) void grecon_stage_kernel(KernelArgs a) {
+__global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon_stage_kernel(KernelArgs a) {
   __shared__ float red[RT_RED_FLOATS];
   __shared__ Scene sc;
   __shared__ glamr_stage_desc s_st;        // the scene keeps POINTERS to these: they must live in LDS, not in a thread's private copy
@@ -89,7 +95,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   int threads = (batch->max_len + 63) / 64 * 64;
   if (threads > MAX_THREADS) threads = MAX_THREADS;
   // on-chip arena: prefix-sum / neighbour-exchange arrays first, then as much of the compact keypoint table as fits
-  constexpr size_t LDS_BUDGET = 150 * 1024;
+  constexpr size_t LDS_BUDGET = GLAMR_GRECON_LDS_KB * 1024;
   const size_t base = scene_fast_floats(batch->max_persons, batch->max_len) * sizeof(float);
   const size_t want = base + (size_t)NJ * 6 * batch->max_persons * batch->max_len * sizeof(float);
   ka.use_lds = base <= LDS_BUDGET;
