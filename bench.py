@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=256, help='independent sequences per GPU per step')
+    ap.add_argument('--batch', type=int, default=1024, help='independent sequences per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
