@@ -99,7 +99,7 @@ def write_smpl_assets(root, seed=1234):
     mdir = os.path.join(root, 'data', 'body_models', 'smpl')
     os.makedirs(mdir, exist_ok=True)
     with open(os.path.join(mdir, 'SMPL_NEUTRAL.pkl'), 'wb') as f:
-        pickle.dump({k: v for k, v in md.items() if k != 'J_regressor_extra'}, f, protocol=2)
+        pickle.dump({k: v for k, v in md.items() if k != 'J_regressor_extra' and not k.startswith('_')}, f, protocol=2)
     np.save(os.path.join(root, 'data', 'J_regressor_extra.npy'), md['J_regressor_extra'])
     return md
 
@@ -171,8 +171,12 @@ def _rodrigues(r):
 
 def _fk_joints(md, betas, rotmats):
     """Chain joints of the synthetic model.  betas (T,10), rotmats (T,24,3,3) -> (T,24,3) with the root at its rest place."""
-    v_shaped = md['v_template'][None].astype(np.float64) + np.einsum('vkl,tl->tvk', md['shapedirs'].astype(np.float64), betas)
-    J = np.einsum('jv,tvk->tjk', md['J_regressor'].astype(np.float64), v_shaped)
+    # rest joints are linear in the shape: J = J_regressor (v_template + shapedirs beta); the two regressed factors are cached
+    if '_J_template64' not in md:
+        Jr = md['J_regressor'].astype(np.float64)
+        md['_J_template64'] = Jr @ md['v_template'].astype(np.float64)
+        md['_J_shapedirs64'] = np.einsum('jv,vkl->jkl', Jr, md['shapedirs'].astype(np.float64))
+    J = md['_J_template64'][None] + np.einsum('jkl,tl->tjk', md['_J_shapedirs64'], betas)
     G = [None] * 24
     pos = np.zeros_like(J)
     for j in range(24):
