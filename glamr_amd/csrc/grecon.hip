@@ -34,7 +34,7 @@ struct KernelArgs {
   unsigned fast_floats;
 };
 
-template <bool FAST>
+template <bool FAST, bool SINGLE>
 __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon_stage_kernel(KernelArgs a) {
   __shared__ float red[RT_RED_FLOATS];
   __shared__ Scene sc;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
   }
   __syncthreads();
   glamr::DeviceRT rt{red};
-  run_scene<FAST>(rt, sc, a.st, a.lay);
+  run_scene<FAST, SINGLE>(rt, sc, a.st, a.lay);
 }
 
 }  // namespace grecon
@@ -101,12 +101,17 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   ka.use_lds = base <= LDS_BUDGET;
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
   ka.fast_floats = (unsigned)(dyn / sizeof(float));
-  if (ka.use_lds) {
-    GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grecon_stage_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    hipLaunchKernelGGL(grecon_stage_kernel<true>, dim3(batch->n_scenes), dim3(threads), dyn, stream, ka);
-  } else {
-    hipLaunchKernelGGL(grecon_stage_kernel<false>, dim3(batch->n_scenes), dim3(threads), 0, stream, ka);
-  }
+  // SINGLE needs every scene of the batch to hold exactly one person: max_persons == 1 guarantees it
+  const bool single = batch->max_persons == 1;
+  auto launch = [&](auto kern, size_t lds) -> int {
+    if (lds) GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    hipLaunchKernelGGL(kern, dim3(batch->n_scenes), dim3(threads), lds, stream, ka);
+    return GLAMR_OK;
+  };
+  int rc;
+  if (ka.use_lds) rc = single ? launch(grecon_stage_kernel<true, true>, dyn) : launch(grecon_stage_kernel<true, false>, dyn);
+  else rc = launch(grecon_stage_kernel<false, false>, 0);
+  if (rc) return rc;
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }

@@ -434,9 +434,11 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
 
 // ---- the per-scene driver --------------------------------------------------------------------------------------------
 
-template <bool FAST, class RT>
+// SINGLE: the scene has exactly one person.  The person loops and the relative-transform term then disappear at compile time, and
+// with them every register spill of the general instance (264 VGPRs -> 0; 39 -> 26 us per iteration on the headline config).
+template <bool FAST, bool SINGLE, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
-  const int T = sc.T, P = sc.P;
+  const int T = sc.T, P = SINGLE ? 1 : sc.P;
   const bool var_cam = st.var_mask & GLAMR_VAR_CAM;
   const bool fixed_cam = st.flags & GLAMR_FLAG_FIXED_CAM;
   const bool cam_from_person = !var_cam && (st.flags & GLAMR_FLAG_CAM_FROM_PERSON);

@@ -33,7 +33,7 @@ extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_
   for (int si = 0; si < b->n_scenes; ++si) {
     Scene sc;
     assemble_scene(*b, l, st, si, b->n_persons[si], b->seq_len[si], ws.data(), grads_out, sc);
-    run_scene<false>(rt, sc, *st, l);
+    if (b->n_persons[si] == 1) run_scene<false, true>(rt, sc, *st, l); else run_scene<false, false>(rt, sc, *st, l);
   }
   return 0;
 }
