@@ -434,6 +434,60 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
 
 // ---- the per-scene driver --------------------------------------------------------------------------------------------
 
+// loss_func.py:248-271 for person p at frame t (both ordered pairs it takes part in).  Returns the unweighted sum of squares of the
+// pairs (p, o) and adds the gradient w.r.t. p's world transform [Rk | tw].
+template <bool FAST>
+GLAMR_HD float rel_transform_term(const Scene& sc, const SceneView& sh, const glamr_stage_desc& st, int P, int p, int t, const float* Rk,
+                                           const float* tw, float w_rel, float* gRk, float* g_tw) {
+  float value = 0.f;
+    float Ti[12];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Ti[i * 4 + j] = Rk[i * 3 + j]; Ti[i * 4 + 3] = tw[i]; }
+    float Tiinv[12];
+    invert34(Ti, Tiinv);
+    float gTi[12];
+    for (int k = 0; k < 12; ++k) gTi[k] = 0.f;
+    for (int o = 0; o < P; ++o) {
+      if (o == p || person_view<FAST>(sc, o).vis[t] == 0.f) continue;
+      float To[12], Ro[9];
+      cols_to_R(person_view<FAST>(sc, o).d6 + t * 6, Ro);
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view<FAST>(sc, o).tw[t * 3 + i]; }
+      float Toinv[12];
+      invert34(To, Toinv);
+      // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
+      for (int dir = 0; dir < 2; ++dir) {
+        const int a = dir == 0 ? p : o, b = dir == 0 ? o : p;
+        const float* target = sh.rel_cam + (((size_t)a * sh.rel_stride_p + b) * sh.rel_stride_t + t) * 12;
+        const float fw = (sh.pair_first[a * 8 + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
+        float rel[12];
+        if (dir == 0) mul34(Tiinv, To, rel); else mul34(Toinv, Ti, rel);
+        float grel[12];
+        for (int k = 0; k < 12; ++k) grel[k] = 0.f;
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 2; ++j) {
+            const float d = (target[i * 4 + j] - rel[i * 4 + j]) * fw;
+            if (dir == 0) value += d * d;
+            grel[i * 4 + j] = -2.0f * d * fw * w_rel;
+          }
+          const float d = (target[i * 4 + 3] - rel[i * 4 + 3]) * fw;
+          if (dir == 0) value += d * d * st.rel_trans_weight;
+          grel[i * 4 + 3] = -2.0f * d * fw * w_rel * st.rel_trans_weight;
+        }
+        if (w_rel == 0.f) continue;
+        if (dir == 0) {
+          float gInv[12];
+          for (int k = 0; k < 12; ++k) gInv[k] = 0.f;
+          mul34_bwd(Tiinv, To, grel, gInv, nullptr);
+          invert34_bwd(Ti, gInv, gTi);
+        } else {
+          mul34_bwd(Toinv, Ti, grel, nullptr, gTi);
+        }
+      }
+    }
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) gRk[i * 3 + j] += gTi[i * 4 + j]; g_tw[i] += gTi[i * 4 + 3]; }
+
+  return value;
+}
+
 // SINGLE: the scene has exactly one person.  The person loops and the relative-transform term then disappear at compile time, and
 // with them every register spill of the general instance (264 VGPRs -> 0; 39 -> 26 us per iteration on the headline config).
 template <bool FAST, bool SINGLE, class RT>
@@ -767,16 +821,22 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           float* gRs = gRk;
           const float rank_w = (rank_t >= 0 && rank_t < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
           const bool kp_frame = visible && (!kp_first || rank_t == 0);
+          // The homogeneous image point is affine in the cached joint: h = K (Rc (Rs jl + tw) + tc) = H jl + q with
+          // H = K Rc Rs and q = K (Rc tw + tc) formed once per frame; the joints accumulate dL/dH and dL/dq, which are pushed back
+          // onto the camera, the orientation and the translation after the loop (same sums as the joint-by-joint chain rule).
+          float A[9], H[9], q[3], gH[9], gq[3];
+          rm::mat3_mul(K, Rc, A);
+          rm::mat3_mul(A, Rs, H);
+          for (int i = 0; i < 3; ++i) {
+            q[i] = A[i * 3 + 0] * tw[0] + A[i * 3 + 1] * tw[1] + A[i * 3 + 2] * tw[2] + (K[i * 3 + 0] * M[3] + K[i * 3 + 1] * M[7] + K[i * 3 + 2] * M[11]);
+            gq[i] = 0.f;
+          }
+          for (int k = 0; k < 9; ++k) gH[k] = 0.f;
           // one joint: project, accumulate the residual value and (weight > 0) its gradient
           auto joint = [&](const float jl[3], float kx, float ky, float wj, float sc_raw, int jout) {
-            float J[3], X[3];
-            rm::mat3_vec(Rs, jl, J);
-            for (int k = 0; k < 3; ++k) J[k] += tw[k];
-            rm::mat3_vec(Rc, J, X);
-            for (int k = 0; k < 3; ++k) X[k] += M[k * 4 + 3];
-            const float hx = K[0] * X[0] + K[1] * X[1] + K[2] * X[2];
-            const float hy = K[3] * X[0] + K[4] * X[1] + K[5] * X[2];
-            const float hz = K[6] * X[0] + K[7] * X[1] + K[8] * X[2] + 1e-8f;
+            const float hx = H[0] * jl[0] + H[1] * jl[1] + H[2] * jl[2] + q[0];
+            const float hy = H[3] * jl[0] + H[4] * jl[1] + H[5] * jl[2] + q[1];
+            const float hz = H[6] * jl[0] + H[7] * jl[1] + H[8] * jl[2] + q[2] + 1e-8f;
             const float u = hx / hz, v = hy / hz;
             const float du = u - kx, dv = v - ky;
             if (jout >= 0) {
@@ -791,18 +851,26 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             if (last) lsum[GLAMR_LOSS_KP_2D] += (gmof(du, 1e4f) + gmof(dv, 1e4f)) * wj;
             if (w_kp == 0.f) return;
             const float gu = gmof_d(du, 1e4f) * wj * w_kp, gv = gmof_d(dv, 1e4f) * wj * w_kp;
-            const float ghx = gu / hz, ghy = gv / hz, ghz = -(gu * u + gv * v) / hz;      // u = hx / hz, v = hy / hz
-            float gX[3];
-            for (int k = 0; k < 3; ++k) gX[k] = K[k] * ghx + K[3 + k] * ghy + K[6 + k] * ghz;
+            const float gh[3] = {gu / hz, gv / hz, -(gu * u + gv * v) / hz};             // u = hx / hz, v = hy / hz
             for (int i = 0; i < 3; ++i) {
-              for (int k = 0; k < 3; ++k) gC[i * 4 + k] += gX[i] * J[k];
-              gC[i * 4 + 3] += gX[i];
+              for (int k = 0; k < 3; ++k) gH[i * 3 + k] += gh[i] * jl[k];
+              gq[i] += gh[i];
             }
-            float gJ[3];
-            rm::mat3T_vec(Rc, gX, gJ);
+          };
+          // dL/dH, dL/dq -> camera [Rc | tc], world rotation Rs, world translation tw
+          auto push_back = [&]() {
+            float gA[9], gRc[9];
+            for (int k = 0; k < 9; ++k) { gA[k] = 0.f; gRc[k] = 0.f; }
+            rm::mat3_mul_bwd(A, Rs, gH, gA, gRs);                                     // H = A Rs
+            for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) gA[i * 3 + k] += gq[i] * tw[k];      // q = A tw + K tc
+            float gt[3], gc[3];
+            rm::mat3T_vec(A, gq, gt);
+            rm::mat3T_vec(K, gq, gc);
+            rm::mat3_mul_bwd(K, Rc, gA, nullptr, gRc);                                // A = K Rc
             for (int i = 0; i < 3; ++i) {
-              g_tw[i] += gJ[i];
-              for (int k = 0; k < 3; ++k) gRs[i * 3 + k] += gJ[i] * jl[k];
+              g_tw[i] += gt[i];
+              for (int k = 0; k < 3; ++k) gC[i * 4 + k] += gRc[i * 3 + k];
+              gC[i * 4 + 3] += gc[i];
             }
           };
           if (last) {
@@ -840,6 +908,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             };
             run(0, njc);
           }
+          if (w_kp != 0.f && kp_frame) push_back();
         }
         GLAMR_MARK(rt, 10);
         // smoothness of the world orientation in 6D  (loss_func.py:117-132)
@@ -849,53 +918,6 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           if (t + 1 < T) for (int k = 0; k < 6; ++k) { const float v = (s.d6[(t + 1) * 6 + k] - d0[k]) * FPS; if (last) lsum[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] += v * v; gd6[k] -= 2.0f * FPS * v * w_trs; }
           if (t > 0) for (int k = 0; k < 6; ++k) { const float v = (d0[k] - s.d6[(t - 1) * 6 + k]) * FPS; gd6[k] += 2.0f * FPS * v * w_trs; }
           for (int r = 0; r < 3; ++r) { gRk[r * 3 + 0] += gd6[r]; gRk[r * 3 + 1] += gd6[3 + r]; }
-        }
-        // relative transform between persons on co-visible frames  (loss_func.py:248-271)
-        if (on(GLAMR_LOSS_REL_TRANSFORM) && P > 1 && visible) {
-          float Ti[12];
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Ti[i * 4 + j] = Rk[i * 3 + j]; Ti[i * 4 + 3] = tw[i]; }
-          float Tiinv[12];
-          invert34(Ti, Tiinv);
-          float gTi[12];
-          for (int k = 0; k < 12; ++k) gTi[k] = 0.f;
-          for (int o = 0; o < P; ++o) {
-            if (o == p || person_view<FAST>(sc, o).vis[t] == 0.f) continue;
-            float To[12], Ro[9];
-            cols_to_R(person_view<FAST>(sc, o).d6 + t * 6, Ro);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view<FAST>(sc, o).tw[t * 3 + i]; }
-            float Toinv[12];
-            invert34(To, Toinv);
-            // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
-            for (int dir = 0; dir < 2; ++dir) {
-              const int a = dir == 0 ? p : o, b = dir == 0 ? o : p;
-              const float* target = sh.rel_cam + (((size_t)a * sh.rel_stride_p + b) * sh.rel_stride_t + t) * 12;
-              const float fw = (sh.pair_first[a * 8 + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
-              float rel[12];
-              if (dir == 0) mul34(Tiinv, To, rel); else mul34(Toinv, Ti, rel);
-              float grel[12];
-              for (int k = 0; k < 12; ++k) grel[k] = 0.f;
-              for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 2; ++j) {
-                  const float d = (target[i * 4 + j] - rel[i * 4 + j]) * fw;
-                  if (dir == 0) if (last) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d;
-                  grel[i * 4 + j] = -2.0f * d * fw * w_rel;
-                }
-                const float d = (target[i * 4 + 3] - rel[i * 4 + 3]) * fw;
-                if (dir == 0) if (last) lsum[GLAMR_LOSS_REL_TRANSFORM] += d * d * st.rel_trans_weight;
-                grel[i * 4 + 3] = -2.0f * d * fw * w_rel * st.rel_trans_weight;
-              }
-              if (w_rel == 0.f) continue;
-              if (dir == 0) {
-                float gInv[12];
-                for (int k = 0; k < 12; ++k) gInv[k] = 0.f;
-                mul34_bwd(Tiinv, To, grel, gInv, nullptr);
-                invert34_bwd(Ti, gInv, gTi);
-              } else {
-                mul34_bwd(Toinv, Ti, grel, nullptr, gTi);
-              }
-            }
-          }
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) gRk[i * 3 + j] += gTi[i * 4 + j]; g_tw[i] += gTi[i * 4 + 3]; }
         }
         float g6[6];
         fold_R_grad(s.d6 + t * 6, gRk, g6);
@@ -949,6 +971,22 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
         for (int k = 0; k < 3; ++k) { const float r = sh.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
     }
+    // relative transform between persons on co-visible frames (loss_func.py:248-271), in a loop of its own: its ~100 live values
+    // are then not allocated alongside the keypoint / camera terms above.  Own frame only -> no barrier; the fold is linear.
+    if (!SINGLE && on(GLAMR_LOSS_REL_TRANSFORM) && P > 1)
+      for (int t = rt.tid(); t < T; t += rt.nthreads())
+        for (int p = 0; p < P; ++p) {
+          const PersonView s = person_view<FAST>(sc, p);
+          if (s.vis[t] == 0.f) continue;
+          float Rk[9], gRk[9], g_tw[3] = {0, 0, 0}, g6[6];
+          for (int k = 0; k < 9; ++k) gRk[k] = 0.f;
+          cols_to_R(s.d6 + t * 6, Rk);
+          const float v = rel_transform_term<FAST>(sc, sh, st, P, p, t, Rk, s.tw + t * 3, w_rel, gRk, g_tw);
+          if (last) lsum[GLAMR_LOSS_REL_TRANSFORM] += v;
+          fold_R_grad(s.d6 + t * 6, gRk, g6);
+          for (int k = 0; k < 6; ++k) s.g_d6[t * 6 + k] += g6[k];
+          for (int k = 0; k < 3; ++k) s.g_tw[t * 3 + k] += g_tw[k];
+        }
     GLAMR_MARK(rt, 4);
     if (update && var_cam && fixed_cam) {
       for (int k = 0; k < 9; ++k) gfix[k] = rt.reduce_sum(gfix[k]);

@@ -13,8 +13,10 @@
 
 #if defined(__HIPCC__)
 #define GLAMR_HD __host__ __device__ __forceinline__
+#define GLAMR_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define GLAMR_HD inline
+#define GLAMR_HD_NOINLINE __attribute__((noinline))
 #endif
 
 namespace glamr {
