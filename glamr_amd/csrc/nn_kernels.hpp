@@ -101,12 +101,16 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* X, cons
 // key_mask[b*Lk + j] != 0 -> key j is ignored (PyTorch key_padding_mask).  A fully masked row yields zeros.
 __global__ __launch_bounds__(64) void attention_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
                                                        float* O, int ldo, int Lq, int Lk, int q_shared) {
-  __shared__ float sK[64][33], sV[64][33];
+  // rows padded to 36 floats: 16-byte aligned, so a key / value row is fetched with eight broadcast ds_read_b128
+  __shared__ __attribute__((aligned(16))) float sK[64][36], sV[64][36];
+  __shared__ float sS[64][64];                      // scores [key][query]: a private array indexed by the key would live in scratch
+  __shared__ unsigned char sM[64];                  // key-padding mask of this sequence (a global byte load per key would serialise the loop)
   const int b = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
-  for (int idx = i; idx < Lk * 32; idx += 64) {
-    const int j = idx >> 5, d = idx & 31;
-    sK[j][d] = K[(size_t)(b * Lk + j) * ldk + h * 32 + d];
-    sV[j][d] = V[(size_t)(b * Lk + j) * ldk + h * 32 + d];
+  if (i < Lk) sM[i] = key_mask ? key_mask[(size_t)b * Lk + i] : 0;
+  for (int idx = i; idx < Lk * 8; idx += 64) {
+    const int j = idx >> 3, d4 = (idx & 7) * 4;
+    *reinterpret_cast<f32x4*>(&sK[j][d4]) = *reinterpret_cast<const f32x4*>(K + (size_t)(b * Lk + j) * ldk + h * 32 + d4);
+    *reinterpret_cast<f32x4*>(&sV[j][d4]) = *reinterpret_cast<const f32x4*>(V + (size_t)(b * Lk + j) * ldk + h * 32 + d4);
   }
   __syncthreads();
   if (i >= Lq) return;
@@ -114,15 +118,22 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* Q, int ldq, 
   const float* qp = Q + (size_t)((q_shared ? 0 : b * Lq) + i) * ldq + h * 32;
   const float scale = 0.17677669529663687f;        // 1 / sqrt(32)
 #pragma unroll
-  for (int d = 0; d < 32; ++d) q[d] = qp[d] * scale;
+  for (int d = 0; d < 32; d += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(qp + d);
+    q[d] = v[0] * scale; q[d + 1] = v[1] * scale; q[d + 2] = v[2] * scale; q[d + 3] = v[3] * scale;
+  }
   float mx = -INFINITY;
-  float sc[64];
   for (int j = 0; j < Lk; ++j) {
-    float s = 0.f;
+    // four interleaved partial sums: a single accumulator would be a 32-deep dependent chain per key
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-    for (int d = 0; d < 32; ++d) s = fmaf(q[d], sK[j][d], s);
-    if (key_mask && key_mask[(size_t)b * Lk + j]) s = -INFINITY;
-    sc[j] = s;
+    for (int d = 0; d < 32; d += 4) {
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(&sK[j][d]);
+      s0 = fmaf(q[d], kv[0], s0); s1 = fmaf(q[d + 1], kv[1], s1); s2 = fmaf(q[d + 2], kv[2], s2); s3 = fmaf(q[d + 3], kv[3], s3);
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    if (sM[j]) s = -INFINITY;
+    sS[j][i] = s;
     mx = fmaxf(mx, s);
   }
   float o[32];
@@ -131,16 +142,22 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* Q, int ldq, 
   float den = 0.f;
   if (mx > -INFINITY) {
     for (int j = 0; j < Lk; ++j) {
-      const float p = expf(sc[j] - mx);
+      const float p = expf(sS[j][i] - mx);
       den += p;
 #pragma unroll
-      for (int d = 0; d < 32; ++d) o[d] = fmaf(p, sV[j][d], o[d]);
+      for (int d = 0; d < 32; d += 4) {
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(&sV[j][d]);
+        o[d] = fmaf(p, vv[0], o[d]); o[d + 1] = fmaf(p, vv[1], o[d + 1]); o[d + 2] = fmaf(p, vv[2], o[d + 2]); o[d + 3] = fmaf(p, vv[3], o[d + 3]);
+      }
     }
   }
   const float inv = den > 0.f ? 1.0f / den : 0.f;
   float* op = O + (size_t)(b * Lq + i) * ldo + h * 32;
 #pragma unroll
-  for (int d = 0; d < 32; ++d) op[d] = o[d] * inv;
+  for (int d = 0; d < 32; d += 4) {
+    const f32x4 v = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+    *reinterpret_cast<f32x4*>(op + d) = v;
+  }
 }
 
 // LSTM recurrence (nn.LSTMCell semantics, gate order i f g o, hidden 128).  The input projections
