@@ -24,7 +24,7 @@ namespace {
 
 constexpr int D = 256, FF = 512, NZ = 128, WIN = 50, PAST = 10, CUR = 30, FUT = 10, XLD = 96;
 
-struct Lin { float* W = nullptr; float* b = nullptr; int N = 0, K = 0; };       // W: [Npad][K]
+struct Lin { float* W = nullptr; float* b = nullptr; int N = 0, K = 0; unsigned short* Ws = nullptr; };   // W: [Npad][K]; Ws: its three bf16 planes
 struct LN { float* g = nullptr; float* b = nullptr; };
 struct EncLayer { Lin qkv, o, f1, f2; LN n1, n2; };
 struct DecLayer { Lin sa_qkv, sa_o, ca_q, ca_kv, ca_o, f1, f2; LN n1, n2, n3; };
@@ -82,6 +82,29 @@ int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
   for (int i = 0; i < W.r; ++i) for (int j = 0; j < W.c; ++j) f[(size_t)i * L.K + j] = (float)W.at(i, j);
   int rc = upload(&L.W, f.data(), f.size());
   if (rc) return rc;
+  {
+    // fp32 = hi + mid + lo in bf16 (round to nearest even each time; the remainders are exact in fp32)
+    auto bf16_rne = [](float x) -> unsigned short {
+      unsigned u; std::memcpy(&u, &x, 4);
+      u += 0x7FFFu + ((u >> 16) & 1u);
+      return (unsigned short)(u >> 16);
+    };
+    auto bf16_val = [](unsigned short h) -> float { unsigned u = (unsigned)h << 16; float x; std::memcpy(&x, &u, 4); return x; };
+    // fragment order of v_mfma_f32_32x32x16_bf16's B operand: [32-column block][16-deep k step][lane = column % 32 + 32 (k % 16 / 8)][k % 8]
+    std::vector<unsigned short> planes(3 * f.size());
+    const int ksteps = L.K / 16;
+    for (int n = 0; n < Np; ++n)
+      for (int k = 0; k < L.K; ++k) {
+        const float x = f[(size_t)n * L.K + k];
+        const unsigned short h = bf16_rne(x);
+        const float r1 = x - bf16_val(h);
+        const unsigned short m = bf16_rne(r1);
+        const float r2 = r1 - bf16_val(m);
+        const size_t dst = (((size_t)(n / 32) * ksteps + k / 16) * 64 + (n % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8;
+        planes[dst] = h; planes[f.size() + dst] = m; planes[2 * f.size() + dst] = bf16_rne(r2);
+      }
+    if ((rc = upload(&L.Ws, planes.data(), planes.size()))) return rc;
+  }
   if (bias) return up_vec(&L.b, *bias, Np);
   return GLAMR_OK;
 }
@@ -272,7 +295,7 @@ int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, in
 }
 int lin(hipStream_t st, const Lin& L, const float* X, int ldx, float* Y, int ldy, int M, int act = ACT_NONE, const float* R = nullptr, int ldr = 0,
         const float* rowbias = nullptr, int rpg = 1, int ldrb = 0) {
-  return launch_gemm(st, X, ldx, L.W, L.b, Y, ldy, M, L.N, L.K, act, R, ldr, rowbias, rpg, ldrb);
+  return launch_gemm(st, X, ldx, L.W, L.b, Y, ldy, M, L.N, L.K, act, R, ldr, rowbias, rpg, ldrb, L.Ws);
 }
 
 }  // namespace

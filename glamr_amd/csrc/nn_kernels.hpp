@@ -24,6 +24,8 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1 };
 struct GemmArgs {
   const float* X; const float* W; const float* bias; const float* rowbias; const float* R; float* Y;
   int M, N, K, ldx, ldy, ldr, rows_per_group, ldrb, act;
+  const unsigned short* Ws = nullptr;     // the weights split into three bf16 planes in MFMA fragment order (see gemm_split_kernel)
+  size_t ws_plane = 0;                    // elements per plane
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
@@ -75,6 +77,131 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
     if (a.R) v += a.R[(size_t)m * a.ldr + n];
     a.Y[(size_t)m * a.ldy + n] = v;
+  }
+}
+
+// ---- fp32 GEMM on the bf16 matrix cores ----------------------------------------------------------------------------------------
+// An fp32 number is the exact sum of three bf16 numbers (8 + 8 + 8 mantissa bits): x = hi + mid + lo.  The product of two such
+// numbers, dropping the terms below 2^-24 of it (mid*lo, lo*mid, lo*lo), is  hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi:
+// six v_mfma_f32_32x32x16_bf16 (32 cycles each, fp32 accumulation) do the work of eight v_mfma_f32_32x32x2_f32 (64 cycles each),
+// i.e. fp32-grade results at 2.7x the fp32 MFMA rate.  Weights are split once when the model is created; activations are split
+// while their tile is staged into LDS (v_cvt_pk_bf16_f32, 4.5 VALU instructions per element).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int BS_ROW = 80;      // bytes per LDS row of one plane: 32 bf16 + 16 pad -> conflict-free ds_read_b128 over 16 rows
+
+__device__ __forceinline__ void split3(f32x2 x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const bf16x2 h = __builtin_convertvector(x, bf16x2);
+  const f32x2 r1 = x - __builtin_convertvector(h, f32x2);          // exact
+  const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);         // exact
+  const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
+}
+
+// Workgroup tile 128 x (64 WN): 4 waves as 2 x 2, each holding 2 x WN accumulator tiles; K chunks of 32.  Only the activations go
+// through LDS (three bf16 planes, rows padded to 80 bytes: conflict-free ds_read_b128); the weight planes are stored in MFMA
+// fragment order ([plane][32-column block][16-deep k step][lane][8 bf16]) and every wave fetches its operands straight from L2 with
+// one coalesced 1 KB load each, one k step ahead.  (Measured alternatives on the B=256 step: both operands through LDS 63 TFLOP/s --
+// LDS bandwidth; no LDS at all 77 -- L1 bandwidth; this one 85; the plain fp32-MFMA kernel 76.)
+template <int WN>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
+  constexpr int TN = 64 * WN;
+  __shared__ __attribute__((aligned(16))) unsigned char sA[3][128 * BS_ROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, kh = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * TN;
+  const int ksteps = a.K / 16;
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x16){0};
+  const uint4* wfrag[3][WN];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const size_t nb = (size_t)(n0 / 32 + wn * WN + j);
+      wfrag[p][j] = reinterpret_cast<const uint4*>(a.Ws + p * a.ws_plane) + (nb * ksteps) * 64 + lane;
+    }
+  f32x4 va[4];
+  auto fetch_a = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + q * 256, row = f >> 3, c4 = (f & 7) * 4;
+      va[q] = *reinterpret_cast<const f32x4*>(a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + k0 + c4);
+    }
+  };
+  uint4 vb[2][3][WN];                               // two k steps in flight
+  auto fetch_b = [&](int buf, int kstep) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) vb[buf][p][j] = wfrag[p][j][(size_t)kstep * 64];
+  };
+  fetch_a(0);
+  fetch_b(0, 0);
+  for (int k0 = 0; k0 < a.K; k0 += 32) {
+    __syncthreads();                                 // everybody is done reading the previous chunk
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + q * 256, row = f >> 3, c4 = (f & 7) * 4;
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split3((f32x2){va[q][0], va[q][1]}, h0, m0_, l0);
+      split3((f32x2){va[q][2], va[q][3]}, h1, m1, l1);
+      const int off = row * BS_ROW + c4 * 2;
+      *reinterpret_cast<uint2*>(&sA[0][off]) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(&sA[1][off]) = make_uint2(m0_, m1);
+      *reinterpret_cast<uint2*>(&sA[2][off]) = make_uint2(l0, l1);
+    }
+    __syncthreads();
+    if (k0 + 32 < a.K) fetch_a(k0 + 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kstep = k0 / 16 + ks;
+      if (kstep + 1 < ksteps) fetch_b(ks ^ 1, kstep + 1);
+      const int kb = ks * 32 + kh * 16;            // byte offset of this lane's 8 k values
+      bf16x8 xa[3][2], xb[3][WN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xa[p][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sA[p][(wm * 64 + i * 32 + r) * BS_ROW + kb]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) xb[p][j] = __builtin_bit_cast(bf16x8, vb[ks][p][j]);
+      }
+      // six products per accumulator, smallest first; consecutive MFMAs go to DIFFERENT accumulators (a dependent MFMA waits for
+      // the previous one to drain)
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[term]][i], xb[PB[term]][j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: lane owns column n, rows (q & 3) + 8 (q >> 2) + 4 kh of each accumulator tile
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = n0 + (wn * WN + j) * 32 + r;
+    if (n >= a.N) continue;
+    const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = m0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        if (m >= a.M) continue;
+        float v = acc[i][j][q] + b;
+        if (a.rowbias) v += a.rowbias[(size_t)(m / a.rows_per_group) * a.ldrb + n];
+        if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+        if (a.R) v += a.R[(size_t)m * a.ldr + n];
+        a.Y[(size_t)m * a.ldy + n] = v;
+      }
+    }
   }
 }
 
@@ -214,12 +341,25 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
 }
 
 inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
-                       int act = ACT_NONE, const float* R = nullptr, int ldr = 0, const float* rowbias = nullptr, int rows_per_group = 1, int ldrb = 0) {
+                       int act = ACT_NONE, const float* R = nullptr, int ldr = 0, const float* rowbias = nullptr, int rows_per_group = 1, int ldrb = 0,
+                       const unsigned short* Ws = nullptr) {
   if (M <= 0) return GLAMR_OK;
   if (K % GT_K != 0 || ldx % 4 != 0) return fail(GLAMR_E_INVALID, "gemm: K=%d must be a multiple of %d and ldx=%d of 4", K, GT_K, ldx);
   static const bool log_shapes = std::getenv("GLAMR_GEMM_LOG") != nullptr;      // development aid (tools/gemm_profile.py)
   if (log_shapes) std::fprintf(stderr, "GEMM %d %d %d\n", M, N, K);
   GemmArgs a{X, W, bias, rowbias, R, Y, M, N, K, ldx, ldy, ldr, rows_per_group, ldrb, act};
+  const int npad = (N + GT_N - 1) / GT_N * GT_N;
+  static const bool no_split = std::getenv("GLAMR_GEMM_FP32_MFMA") != nullptr;      // development aid: force the plain fp32 kernel
+  if (Ws && M >= 2048 && !no_split) {
+    // tall activations: the split-bf16 kernel (small M is launch / latency bound either way)
+    a.Ws = Ws;
+    a.ws_plane = (size_t)npad * K;
+    if (npad % 128 == 0 && (size_t)(M / 128) * (npad / 128) >= 512)
+      hipLaunchKernelGGL((gemm_split_kernel<2>), dim3(npad / 128, (M + 127) / 128), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((gemm_split_kernel<1>), dim3(npad / 64, (M + 127) / 128), dim3(256), 0, st, a);
+    return GLAMR_OK;
+  }
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M), dim3(256), 0, st, a);
   return GLAMR_OK;
 }

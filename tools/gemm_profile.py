@@ -22,7 +22,7 @@ else:
     lines = open(sys.argv[2]).read().split('\n')
     k = lines.index('MARK')
     shapes = [tuple(int(x) for x in l.split()[1:]) for l in lines[k + 1:] if l.startswith('GEMM')]
-    rows = [r for r in csv.DictReader(open(sys.argv[3])) if 'gemm_kernel' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(sys.argv[3])) if 'gemm_' in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     rows = rows[len(rows) - len(shapes):]
     agg = {}
