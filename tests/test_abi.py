@@ -32,13 +32,15 @@ def test_struct_sizes_match_the_header():
     import subprocess
     import tempfile
     from glamr_amd import _lib
-    code = '#include <stdio.h>\n#include "glamr_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(glamr_tensor_desc), ' \
-           'sizeof(glamr_stage_desc), sizeof(glamr_scene_batch), sizeof(glamr_param_layout));return 0;}\n'
+    code = '#include <stdio.h>\n#include "glamr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(glamr_tensor_desc), ' \
+           'sizeof(glamr_stage_desc), sizeof(glamr_scene_batch), sizeof(glamr_param_layout), sizeof(glamr_raw_batch), ' \
+           'sizeof(glamr_person_arrays));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, 'p.c'), 'w').write(code)
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'p.c'), '-o', os.path.join(d, 'p')])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, 'p')]).split()]
-    assert sizes == [ctypes.sizeof(_lib.TensorDesc), ctypes.sizeof(_lib.StageDesc), ctypes.sizeof(_lib.SceneBatch), ctypes.sizeof(_lib.ParamLayout)]
+    assert sizes == [ctypes.sizeof(_lib.TensorDesc), ctypes.sizeof(_lib.StageDesc), ctypes.sizeof(_lib.SceneBatch), ctypes.sizeof(_lib.ParamLayout),
+                     ctypes.sizeof(_lib.RawBatch), ctypes.sizeof(_lib.PersonArrays)]
 
 
 def test_product_never_imports_the_oracle():
