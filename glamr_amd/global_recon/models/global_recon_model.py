@@ -276,11 +276,15 @@ class GlobalReconOptimizer:
     # ------------------------------------------------------------------------------------------------------------------------
     # device pipeline: the host only scatters the HybrIK arrays to their frame rows (pose_est/hybrik_demo/demo.py:317-354 layout)
     # ------------------------------------------------------------------------------------------------------------------------
-    def stage_inputs(self, in_dicts, latents=None):
-        """Host dictionaries -> HBM: scatters the per-detection HybrIK arrays to their frame rows and uploads them (the ONLY
-        host->device traffic of a batch).  Returns a ResidentInputs; everything after this runs on device arrays."""
+    def stage_inputs(self, in_dicts, latents=None, validate=True):
+        """Host dictionaries -> HBM: checks them against the wire format (glamr_amd/utils/wire.py), scatters the per-detection
+        HybrIK arrays to their frame rows and uploads them (the ONLY host->device traffic of a batch).  Returns a ResidentInputs;
+        everything after this runs on device arrays."""
         t0 = time.time()
         dev = self.device
+        if validate:
+            from glamr_amd.utils import wire
+            in_dicts = [dict(d, est=wire.normalise_est(d['est'])) for d in in_dicts]
         S = len(in_dicts)
         ids = [list(d['est'].keys()) for d in in_dicts]
         P = max(len(x) for x in ids)

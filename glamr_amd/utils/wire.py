@@ -1,0 +1,112 @@
+"""The input wire format of the global reconstruction: what `pose_est/hybrik_demo/demo.py:317-354` pickles as `pose.pkl` and
+`global_recon/run_demo.py:78-81` wraps as `in_dict = {'est': est_dict, 'gt': {}, 'gt_meta': {}, 'seq_name': ...}`.
+
+    est_dict[person_id] = {
+        'smpl_pose_quat_wroot': (Tvis, 54, 4)   24 rotation matrices per detection, flattened row-major and regrouped by 4 (demo.py:320)
+        'smpl_beta':            (Tvis, 10)
+        'root_trans':           (Tvis, 3)       camera coordinates, metres
+        'kp_2d':                (Tvis, 29, 2)   HybrIK's 29 keypoints in pixels (the first 24 are the SMPL joints)
+        'cam_K':                (Tvis, 3, 3)
+        'frames':               (Tvis,)         video frame of every detection
+        'frame2ind':            {frame: row}
+        'bboxes_dict':          {'exist': (T,) 0/1 per video frame, 'bbox', 'start', 'end', 'num_frames', 'exist_frames', 'id'}
+    }
+
+`normalise_est` checks a dictionary against this contract (the reference trusts its producer and fails later with shape errors
+deep inside `init_data`), converts the arrays to the dtypes the device path expects and returns a clean copy; nothing here
+touches the device."""
+import pickle
+
+import numpy as np
+
+REQUIRED = ('smpl_pose_quat_wroot', 'smpl_beta', 'root_trans', 'kp_2d', 'cam_K', 'bboxes_dict')
+
+
+class WireFormatError(ValueError):
+    pass
+
+
+def _fail(pid, msg):
+    raise WireFormatError('person %r: %s' % (pid, msg))
+
+
+def normalise_person(pid, src, check_rotations=True):
+    for k in REQUIRED:
+        if k not in src:
+            _fail(pid, 'missing key %r (have %s)' % (k, sorted(src.keys())))
+    bb = src['bboxes_dict']
+    if 'exist' not in bb:
+        _fail(pid, "bboxes_dict has no 'exist' mask")
+    exist = np.asarray(bb['exist'])
+    if exist.ndim != 1 or exist.size < 2:
+        _fail(pid, "bboxes_dict['exist'] must be a 1-D mask over the video frames, got shape %s" % (exist.shape,))
+    exist01 = (exist != 0)
+    if not np.array_equal(exist01.astype(exist.dtype), exist):
+        _fail(pid, "bboxes_dict['exist'] must hold 0/1 values")
+    n_vis = int(exist01.sum())
+    if n_vis < 2:
+        _fail(pid, 'needs at least two detections to interpolate between (has %d)' % n_vis)
+    rot = np.asarray(src['smpl_pose_quat_wroot'], dtype=np.float32)
+    if rot.shape[0] != n_vis or rot.size != n_vis * 24 * 9:
+        _fail(pid, "smpl_pose_quat_wroot must hold 24 rotation matrices for each of the %d detections, got shape %s" % (n_vis, rot.shape))
+    rot = rot.reshape(n_vis, 54, 4)
+    out = {'smpl_pose_quat_wroot': rot}
+    for key, tail in (('smpl_beta', (10,)), ('root_trans', (3,)), ('cam_K', (3, 3))):
+        a = np.asarray(src[key], dtype=np.float32)
+        if a.shape != (n_vis,) + tail:
+            _fail(pid, '%s must have shape %s, got %s' % (key, (n_vis,) + tail, a.shape))
+        out[key] = a
+    kp = np.asarray(src['kp_2d'])
+    if kp.ndim != 3 or kp.shape[0] != n_vis or kp.shape[1] < 24 or kp.shape[2] != 2:
+        _fail(pid, 'kp_2d must have shape (%d, >=24, 2), got %s' % (n_vis, kp.shape))
+    out['kp_2d'] = kp
+    for key, a in list(out.items()):
+        if not np.all(np.isfinite(a)):
+            _fail(pid, '%s contains non-finite values' % key)
+    if check_rotations:
+        R = rot.reshape(n_vis, 24, 3, 3).astype(np.float64)
+        err = np.abs(np.einsum('tjab,tjcb->tjac', R, R) - np.eye(3)).max()
+        if err > 1e-2:
+            _fail(pid, 'smpl_pose_quat_wroot does not hold rotation matrices (|R R^T - I| = %.3g); the field is named after quaternions but '
+                       'carries 24 x 3 x 3 matrices regrouped by 4 (demo.py:320)' % err)
+    frames = np.flatnonzero(exist01)
+    if 'frames' in src and not np.array_equal(np.asarray(src['frames']).reshape(-1), frames):
+        _fail(pid, "'frames' disagrees with bboxes_dict['exist']")
+    out['frames'] = frames
+    out['frame2ind'] = {int(f): i for i, f in enumerate(frames)}
+    nb = dict(bb)
+    nb['exist'] = exist
+    nb.setdefault('start', int(frames[0]))
+    nb.setdefault('end', int(frames[-1]))
+    nb.setdefault('num_frames', n_vis)
+    nb.setdefault('exist_frames', frames)
+    out['bboxes_dict'] = nb
+    for k, v in src.items():          # anything else the producer added travels unchanged
+        out.setdefault(k, v)
+    return out
+
+
+def normalise_est(est, check_rotations=True):
+    """Validated copy of `est_dict`.  All persons must cover the same number of video frames (global_recon_model.py:85)."""
+    if not isinstance(est, dict) or not est:
+        raise WireFormatError('est_dict must be a non-empty {person_id: dict}')
+    if len(est) > 8:
+        raise WireFormatError('at most 8 persons per sequence are supported (got %d)' % len(est))
+    out = {pid: normalise_person(pid, src, check_rotations) for pid, src in est.items()}
+    lens = {pid: len(d['bboxes_dict']['exist']) for pid, d in out.items()}
+    if len(set(lens.values())) != 1:
+        raise WireFormatError("all persons must share the video length; bboxes_dict['exist'] lengths: %s" % lens)
+    return out
+
+
+def make_in_dict(est, seq_name, gt=None, gt_meta=None, validate=True):
+    """`in_dict` of run_demo.py:80 / run_dataset.py:98-103."""
+    return {'est': normalise_est(est) if validate else est, 'gt': gt if gt is not None else {}, 'gt_meta': gt_meta if gt_meta is not None else {},
+            'seq_name': seq_name}
+
+
+def load_pose_pkl(path, seq_name=None):
+    with open(path, 'rb') as f:
+        est = pickle.load(f)
+    import os
+    return make_in_dict(est, seq_name or os.path.splitext(os.path.basename(os.path.dirname(os.path.abspath(path))))[0])

@@ -116,3 +116,23 @@ def test_full_schedule_300_frames_detection_gap_host_init(make_model, golden):
     operators and stays in the reference's solution all the way through the 500 iterations."""
     d_kp, e_root, _, _ = _full_schedule(make_model, golden, '', None, host_init=True)
     assert d_kp.max() < 1.0 and e_root < 2e-2
+
+
+def test_run_demo_entry_point(asset_root, tmp_path, monkeypatch):
+    """pose.pkl in -> grecon/<seq>_seed<k>.pkl out, with the reference's working-directory conventions (run_demo.py:44-82)."""
+    import pickle
+    from glamr_amd.global_recon import run_demo
+    est = synth.make_in_dict(seed=2, num_frames=100, num_persons=1, smpl_model=synth.make_smpl_model())['est']
+    pose_dir = tmp_path / 'out' / 'walk' / 'pose_est'
+    os.makedirs(pose_dir)
+    with open(pose_dir / 'pose.pkl', 'wb') as f:
+        pickle.dump(est, f)
+    monkeypatch.chdir(asset_root)            # data/body_models/smpl, data/J_regressor_extra.npy, results/... are found relative to cwd
+    out_file = run_demo.main(['--cfg', 'glamr_static', '--pose_est_dir', str(pose_dir), '--out_dir', str(tmp_path / 'out' / 'walk'), '--seed', '3'])
+    assert os.path.basename(out_file) == 'walk_seed3.pkl'
+    out = pickle.load(open(out_file, 'rb'))
+    assert out['seq_name'] == 'walk' and out['meta']['num_fr'] == 100 and out['cam_pose'].shape == (100, 4, 4)
+    pd = out['person_data'][0]
+    assert pd['smpl_orient_world'].shape == (100, 3) and pd['kp_2d_pred'].shape == (100, 26, 2) and np.isfinite(pd['root_trans_world']).all()
+    # cached=1: a second call returns the stored file without touching the device
+    assert run_demo.main(['--cfg', 'glamr_static', '--pose_est_dir', str(pose_dir), '--out_dir', str(tmp_path / 'out' / 'walk'), '--seed', '3']) == out_file
