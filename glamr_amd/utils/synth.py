@@ -92,6 +92,21 @@ def make_smpl_model(seed=1234):
     }
 
 
+def make_h36m_regressor(md, seed=4321):
+    """A synthetic stand-in for `data/J_regressor_h36m.npy` (17 x V; lib/models/smpl.py:29): every H36M joint regressed from the
+    vertices of one body part.  Drawn from its own generator so the SMPL model above does not change."""
+    rng = np.random.default_rng(seed)
+    V = md['v_template'].shape[0]
+    primary = np.argmax(md['weights'], axis=1)
+    # H36M order: pelvis, rhip, rknee, rankle, lhip, lknee, lankle, spine, thorax, neck/nose, head, lshoulder, lelbow, lwrist, rshoulder, relbow, rwrist
+    anchors = [0, 2, 5, 8, 1, 4, 7, 6, 9, 12, 15, 16, 18, 20, 17, 19, 21]
+    R = np.zeros((17, V))
+    for r, j in enumerate(anchors):
+        w = rng.random(V) ** 8 * (primary == j)
+        R[r] = w / w.sum()
+    return R.astype(np.float32)
+
+
 def write_smpl_assets(root, seed=1234):
     """Writes `<root>/data/body_models/smpl/SMPL_NEUTRAL.pkl` and `<root>/data/J_regressor_extra.npy`
     (the relative paths hard-wired at lib/models/smpl.py:28-31).  Returns the model dict."""
@@ -101,6 +116,7 @@ def write_smpl_assets(root, seed=1234):
     with open(os.path.join(mdir, 'SMPL_NEUTRAL.pkl'), 'wb') as f:
         pickle.dump({k: v for k, v in md.items() if k != 'J_regressor_extra' and not k.startswith('_')}, f, protocol=2)
     np.save(os.path.join(root, 'data', 'J_regressor_extra.npy'), md['J_regressor_extra'])
+    np.save(os.path.join(root, 'data', 'J_regressor_h36m.npy'), make_h36m_regressor(md))
     return md
 
 
@@ -194,7 +210,7 @@ _BASE_R = np.array([[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]])   # quaternion (0
 
 
 def make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=None, dynamic_cam=True, gap=None,
-                 kp_noise=1.5, seq_name=None):
+                 kp_noise=1.5, seq_name=None, with_gt=False):
     """One synthetic sequence in the dictionary format `GlobalReconOptimizer.optimize` consumes
     (global_recon/run_demo.py:78-81): {'est': {idx: hybrik_dict}, 'gt': {}, 'gt_meta': {}, 'seq_name': str}.
 
@@ -219,7 +235,7 @@ def make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=None, dynamic
     K[0, 0] = K[1, 1] = 1000.0
     K[0, 2], K[1, 2] = 960.0, 540.0
 
-    est = {}
+    est, gt = {}, {}
     for p in range(num_persons):
         prng = np.random.default_rng(20_000 + 97 * seed + p)
         freqs = prng.uniform(0.3, 0.8, size=(3, 69))
@@ -235,6 +251,10 @@ def make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=None, dynamic
         trans_w = np.concatenate([xy, z[:, None]], 1)
         sway = _rodrigues(0.05 * np.stack([np.sin(1.1 * t), np.sin(0.7 * t + 1.0), 0 * t], 1))
         Rw = _rodrigues(np.stack([0 * t, 0 * t, heading], 1)) @ _BASE_R[None] @ sway
+        if with_gt:      # the ground truth in the layout the evaluator reads (global_recon/utils/evaluator.py:238-262)
+            from glamr_amd.lib.utils.np_transform import rotmat_to_rotvec_nearest
+            gt[p] = {'pose': np.concatenate([rotmat_to_rotvec_nearest(Rw.astype(np.float32)), body_pose.astype(np.float32)], 1),
+                     'shape': betas[0].astype(np.float32), 'root_trans': trans_w.astype(np.float32)}
         # into the camera frame
         Rc = np.transpose(Rc2w, (0, 2, 1)) @ Rw
         tc = np.einsum('tba,tb->ta', Rc2w, trans_w - cam_pos)
@@ -265,5 +285,5 @@ def make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=None, dynamic
             'bboxes_dict': {'id': p, 'exist': exist, 'start': int(vis[0]), 'end': int(vis[-1]),
                             'num_frames': float(exist.sum()), 'exist_frames': vis},
         }
-    return {'est': est, 'gt': dict(), 'gt_meta': dict(),
+    return {'est': est, 'gt': gt, 'gt_meta': dict(),
             'seq_name': seq_name or 'synth_s%d_T%d_P%d' % (seed, T, num_persons)}

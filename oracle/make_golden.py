@@ -272,13 +272,62 @@ def gen_full(which=('gap', 'nogap')):
         print('full reference optimize() [%s]: %.1f s on %d threads' % (name, dt, torch.get_num_threads()))
 
 
+EVAL_CASES = [('glamr_dynamic', 300, 1, '3DPW'), ('glamr_static_multi', 120, 2, '')]
+
+
+def gen_eval(cases=EVAL_CASES):
+    """global_recon/utils/evaluator.py on the state init_data leaves (estimate) against the generator's ground truth.  The module
+    imports a `lib.utils.logging` that the reference does not ship: a stub with create_logger is injected."""
+    import types
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    wd = rh.setup()
+    md = synth.make_smpl_model()
+    h36m = os.path.join(wd, 'data', 'J_regressor_h36m.npy')
+    if not os.path.exists(h36m):
+        np.save(h36m, synth.make_h36m_regressor(md))
+    stub = types.ModuleType('lib.utils.logging')
+    stub.create_logger = lambda *a, **k: rh.QuietLog()
+    sys.modules['lib.utils.logging'] = stub
+    from global_recon.utils.evaluator import Evaluator
+    for cfg_id, T, P, dataset in cases:
+        model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+        in_dict = synth.make_in_dict(seed=7, num_frames=T, num_persons=P, smpl_model=md, with_gt=True)
+        data = model.init_data(in_dict)
+        # latents are not pinned here: the estimate is stored and handed to the implementation under test as is
+        out = {}
+        for idx, pd in data['person_data'].items():
+            for k in ('smpl_orient_world', 'root_trans_world', 'smpl_pose', 'smpl_beta', 'visible_orig', 'exist_frames'):
+                out['in_p%d_%s' % (idx, k)] = np.asarray(pd[k].cpu().numpy() if torch.is_tensor(pd[k]) else pd[k])
+            for k, v in in_dict['gt'][idx].items():
+                out['in_gt%d_%s' % (idx, k)] = v
+        data['gt'] = {idx: {k: torch.from_numpy(np.asarray(v)) for k, v in g.items()} for idx, g in in_dict['gt'].items()}
+        ev = Evaluator(algo='ref', dataset=dataset, device=torch.device('cpu'), align_freq=250)
+        # compute_sequence_metrics (:329-343) works on a copy; the same steps on a dictionary we keep
+        from lib.utils.torch_utils import tensor_to
+        data = tensor_to(data, ev.device)
+        ev.prepare_seq(data)
+        for name, func in ev.metrics_func.items():
+            val, info = func(data)
+            out['metric_' + name] = np.asarray(val)
+            out['count_' + name] = np.asarray(info['num_data'])
+        for idx, pd in data['person_data'].items():
+            for k in ('eval_joints_world', 'aligned_eval_joints_world', 'eval_joints_world_PA', 'aligned_trans', 'aligned_orient'):
+                out['p%d_%s' % (idx, k)] = pd[k].cpu().numpy()
+                if k in data['gt'][idx]:
+                    out['gt%d_%s' % (idx, k)] = data['gt'][idx][k].cpu().numpy()
+        out['dataset'] = np.array(dataset)
+        np.savez_compressed(os.path.join(GOLD, 'eval_%s_T%d_P%d.npz' % (cfg_id, T, P)), **out)
+        print('wrote eval', cfg_id, T, P, {k: float(np.mean(v)) for k, v in out.items() if k.startswith('metric_')})
+
+
 def main(argv):
     from oracle import ref_harness as rh
     rh.setup()
     os.makedirs(GOLD, exist_ok=True)
-    todo = argv or ['smpl', 'geom', 'nets', 'grecon', 'full']
+    todo = argv or ['smpl', 'geom', 'nets', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'grecon': gen_grecon, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',))}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'grecon': gen_grecon, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'eval': gen_eval}[name]()
         print('done', name)
 
 
