@@ -18,10 +18,11 @@ from tests.grecon_common import j_local_from_oracle
 def main():
     dev = torch.device('cuda:0')
     root = build.ensure_synthetic_assets('/tmp/glamr_bench_assets')
-    cfg = get_config('glamr_dynamic')
+    cfg = get_config(os.environ.get('GLAMR_MB_CFG', 'glamr_dynamic'))
     md = synth.make_smpl_model()
     T = int(os.environ.get('GLAMR_MB_FRAMES', '300'))
-    in_dict = synth.make_in_dict(seed=0, num_frames=T, num_persons=1, smpl_model=md)
+    NP = int(os.environ.get('GLAMR_MB_PERSONS', '1'))
+    in_dict = synth.make_in_dict(seed=0, num_frames=T, num_persons=NP, smpl_model=md)
     ora = build.load_optimizer(root, cfg)
     data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 0))
     jl = j_local_from_oracle(ora.smpl, data)
@@ -38,7 +39,7 @@ def main():
             _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, _lib.ptr(ws), _lib.current_stream()))
             torch.cuda.synchronize()
             dt = time.time() - t0
-        print('grecon stage: scenes=%4d  T=%d  iters=%d  %.2f ms  (%.2f us/iter, %.1f scenes/s)' % (S, T, sd.niters, dt * 1e3, dt * 1e6 / sd.niters, S / dt))
+        print('grecon stage: scenes=%4d  T=%d  P=%d  iters=%d  %.2f ms  (%.2f us/iter, %.1f scenes/s)' % (S, T, NP, sd.niters, dt * 1e3, dt * 1e6 / sd.niters, S / dt))
     if 'GLAMR_MB_FRAMES' in os.environ:
         return
     # SMPL LBS
