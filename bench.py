@@ -131,6 +131,7 @@ def main():
     # consecutive steps are independent batches: they are enqueued on alternating HIP streams, so the matrix-core-bound prior
     # networks of one batch can run under the latency-bound optimiser stage of the previous one (--streams 1 serialises them)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    torch.cuda.synchronize()                                       # the upload ran on the default stream; the side streams do not wait for it
     keep = []
 
     def step(i=0):
