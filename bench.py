@@ -30,6 +30,10 @@ if ROOT not in sys.path:
 # HybrIK orientation/translation 7 KB, transforms 60 KB
 ALGO_BYTES_PER_PERSON_ITER = (2 * 58 + 94 + 94 + 11 + 13 + 7 + 60) * 1024
 HBM_PEAK_GBS = 8000.0
+# memory-side traffic of the stage kernel, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on this workload
+# (profiles/r01_pmc_stage_kernel_b1024.csv: 21.1e6 KB fetched, 31.1e6 KB written by the launch of 1024 scenes x 500 iterations) and
+# corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B request: doubled); per scene-iteration
+TRAFFIC_BYTES_PER_SCENE_ITER = (2 * 21.1e6 + 31.1e6) * 1024 / (1024 * 500)
 CFG_ID, NUM_FRAMES = 'glamr_dynamic', 300
 
 
@@ -181,9 +185,10 @@ def main():
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
                        'streams_per_gpu': len(streams)},
             'roofline': {'kernel': 'grecon_stage_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': k_avg,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': TRAFFIC_BYTES_PER_SCENE_ITER * B * iters, 'avg_launch_ms': k_avg,
                          'us_per_iteration': k_avg * 1e3 / iters, 'dependent_boundary_floor_us': 1.45,
-                         'note': 'latency-bound: one workgroup per scene, state L2-resident; algorithmic bytes = %d B per person-iteration '
+                         'note': 'latency-bound: one workgroup per scene, state on chip; traffic = PMC FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/r01_pmc_stage_kernel_b1024.csv) scaled to this batch, '
+                                 'about a third of the algorithmic bytes because parameters are the only per-iteration stream; algorithmic bytes = %d B per person-iteration '
                                  '(SURVEY.md 8d K5) x %d scenes x %d iterations' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},
             'host_inclusive_sequences_per_sec': B / host_elapsed,
             'host_inclusive_stage_seconds': {k: round(v, 4) for k, v in tm.items()},

@@ -64,8 +64,10 @@ def normalise_person(pid, src, check_rotations=True):
         if not np.all(np.isfinite(a)):
             _fail(pid, '%s contains non-finite values' % key)
     if check_rotations:
-        R = rot.reshape(n_vis, 24, 3, 3).astype(np.float64)
-        err = np.abs(np.einsum('tjab,tjcb->tjac', R, R) - np.eye(3)).max()
+        R = rot.reshape(n_vis * 24, 3, 3)
+        a, b, c = R[:, 0], R[:, 1], R[:, 2]                                                # |R R^T - I| from the six row products
+        dots = [((a * a).sum(1), 1.0), ((b * b).sum(1), 1.0), ((c * c).sum(1), 1.0), ((a * b).sum(1), 0.0), ((a * c).sum(1), 0.0), ((b * c).sum(1), 0.0)]
+        err = max(float(np.abs(v - ref).max()) for v, ref in dots)
         if err > 1e-2:
             _fail(pid, 'smpl_pose_quat_wroot does not hold rotation matrices (|R R^T - I| = %.3g); the field is named after quaternions but '
                        'carries 24 x 3 x 3 matrices regrouped by 4 (demo.py:320)' % err)
