@@ -65,9 +65,9 @@ def normalise_person(pid, src, check_rotations=True):
             _fail(pid, '%s contains non-finite values' % key)
     if check_rotations:
         R = rot.reshape(n_vis * 24, 3, 3)
-        a, b, c = R[:, 0], R[:, 1], R[:, 2]                                                # |R R^T - I| from the six row products
-        dots = [((a * a).sum(1), 1.0), ((b * b).sum(1), 1.0), ((c * c).sum(1), 1.0), ((a * b).sum(1), 0.0), ((a * c).sum(1), 0.0), ((b * c).sum(1), 0.0)]
-        err = max(float(np.abs(v - ref).max()) for v, ref in dots)
+        r = np.ascontiguousarray(R.reshape(-1, 9).T)                                       # nine component vectors: |R R^T - I| from the six row products
+        dot = lambda i, j: r[3 * i] * r[3 * j] + r[3 * i + 1] * r[3 * j + 1] + r[3 * i + 2] * r[3 * j + 2]
+        err = max(float(np.abs(dot(i, j) - (1.0 if i == j else 0.0)).max()) for i in range(3) for j in range(i, 3))
         if err > 1e-2:
             _fail(pid, 'smpl_pose_quat_wroot does not hold rotation matrices (|R R^T - I| = %.3g); the field is named after quaternions but '
                        'carries 24 x 3 x 3 matrices regrouped by 4 (demo.py:320)' % err)
