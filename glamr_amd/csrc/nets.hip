@@ -548,7 +548,9 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   for (int l = 0; l < 2; ++l) {
     RC(lin(st, h->t_ih[l], w.th, D, w.tg, 1024, MT));
     LstmArgs la{w.tg, h->t_hh[l][0], h->t_hh[l][1], w.lens, w.th, max_len};
-    hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(512), 0, st, la);
+    // large batches: 16 sequences per workgroup on the matrix cores; small ones: one sequence per workgroup keeps every CU busy
+    if (B >= 512) hipLaunchKernelGGL(lstm_mfma_kernel, dim3((B + 15) / 16, 2), dim3(512), 0, st, la, B);
+    else hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(512), 0, st, la);
   }
   RC(lin(st, h->t_out1, w.th, D, w.tg, FF, MT, ACT_RELU));
   RC(lin(st, h->t_out2, w.tg, FF, w.th, D, MT, ACT_RELU));          // context [B][max_len][256]

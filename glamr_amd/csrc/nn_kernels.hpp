@@ -340,6 +340,91 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
   }
 }
 
+// The same recurrence for large batches, on the matrix cores: one 512-thread workgroup advances 16 sequences of one direction
+// together.  Per step, gates[16 x 512] = G[t] + h[16 x 128] . W_hh^T as v_mfma_f32_16x16x4_f32: wave w owns hidden units
+// [16 w, 16 w + 16) and therefore the four gate tiles {w, 8 + w, 16 + w, 24 + w}; its 4 x 32 B operands (W_hh fragments) stay in
+// 128 registers for the whole launch, the A operand (h, double-buffered in LDS) is fetched with 8 ds_read_b128 per step (lane =
+// sequence m, k quarter q reads k = 32 q + j for the j-th MFMA), and the cell update is lane-local: lane (n, q) holds the four gates
+// of hidden unit 16 w + n for sequences 4 q .. 4 q + 3.  One barrier per step.
+__global__ __launch_bounds__(512) void lstm_mfma_kernel(LstmArgs a, int n_seq) {
+  __shared__ __attribute__((aligned(16))) float sh[2][16][132];
+  const int dir = blockIdx.y, s0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int u0 = wave * 16;
+  const float* Whh = dir ? a.Whh_b : a.Whh_f;
+  float wreg[4][32];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* row = Whh + (size_t)(g * 128 + u0 + n) * 128 + q * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + j);
+      wreg[g][j] = v[0]; wreg[g][j + 1] = v[1]; wreg[g][j + 2] = v[2]; wreg[g][j + 3] = v[3];
+    }
+  }
+  int len[4], maxlen = 0;
+  const float* Gb[4];
+  float* Hb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int seq = s0 + 4 * q + r;
+    len[r] = seq < n_seq ? a.lens[seq] : 0;
+    Gb[r] = a.G + (size_t)min(seq, n_seq - 1) * a.max_len * 1024 + dir * 512 + u0 + n;
+    Hb[r] = a.H + (size_t)min(seq, n_seq - 1) * a.max_len * 256 + dir * 128 + u0 + n;
+  }
+  for (int m = 0; m < 16; ++m) { const int sq = s0 + m; if (sq < n_seq) maxlen = max(maxlen, a.lens[sq]); }
+  for (int i = tid; i < 2 * 16 * 132; i += 512) (&sh[0][0][0])[i] = 0.f;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  float gnext[4][4];
+  auto fetch_g = [&](int s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool act = s < len[r];
+      const int t = dir ? (len[r] - 1 - s) : s;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gnext[g][r] = act ? Gb[r][(size_t)t * 1024 + g * 128] : 0.f;
+    }
+  };
+  fetch_g(0);
+  __syncthreads();
+  for (int s = 0; s < maxlen; ++s) {
+    const int cur = s & 1;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){gnext[g][0], gnext[g][1], gnext[g][2], gnext[g][3]};
+    if (s + 1 < maxlen) fetch_g(s + 1);
+    const float* hrow = &sh[cur][n][q * 32];                      // A operand: sequence n (= lane & 15), k quarter q
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + jj * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i], wreg[g][jj * 4 + i], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * q + r;
+      float hnew;
+      if (s < len[r]) {
+        const float ig = 1.0f / (1.0f + expf(-acc[0][r]));
+        const float fg = 1.0f / (1.0f + expf(-acc[1][r]));
+        const float gg = tanhf(acc[2][r]);
+        const float og = 1.0f / (1.0f + expf(-acc[3][r]));
+        c[r] = fg * c[r] + ig * gg;
+        hnew = og * tanhf(c[r]);
+        const int t = dir ? (len[r] - 1 - s) : s;
+        Hb[r][(size_t)t * 256] = hnew;
+      } else {
+        hnew = sh[cur][m][u0 + n];
+      }
+      sh[cur ^ 1][m][u0 + n] = hnew;
+    }
+    __syncthreads();
+  }
+}
+
 inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
                        int act = ACT_NONE, const float* R = nullptr, int ldr = 0, const float* rowbias = nullptr, int rows_per_group = 1, int ldrb = 0,
                        const unsigned short* Ws = nullptr) {

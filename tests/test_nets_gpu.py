@@ -72,3 +72,32 @@ def test_ragged_batch_equals_single_runs(priors):
         for key in ('pose', 'local_traj', 'trans', 'orient'):
             assert _err(batch[key][i, :n].cpu(), single[key][0].cpu()) < 1e-5, (i, key)
             assert float(batch[key][i, n:].abs().max()) == 0.0 if n < T else True
+
+
+def test_large_batch_recurrence_equals_small_batch(priors):
+    """Batches of 512+ sequences run the bi-LSTM on the matrix cores (16 sequences per workgroup, lstm_mfma_kernel); smaller ones
+    one sequence per workgroup.  Same numbers up to the summation order of the recurrent product."""
+    dev = torch.device('cuda:0')
+    base = [97, 47, 120, 64, 11, 100]
+    B = 523                                          # not a multiple of 16: the last workgroup is partly empty
+    lens = [base[i % len(base)] for i in range(B)]
+    T = max(lens)
+    ins = [mg.net_inputs(n, seed=i) for i, n in enumerate(base)]
+    pose = torch.zeros(B, T, 69, device=dev)
+    vis = torch.zeros(B, T, device=dev)
+    nw = max(x['in_motion_latent'].shape[0] for x in ins)
+    meps = torch.zeros(B, nw, 128, device=dev)
+    teps = torch.zeros(B, 128, device=dev)
+    for i in range(B):
+        x = ins[i % len(base)]
+        pose[i, :lens[i]] = torch.tensor(x['in_body_pose'][0])
+        vis[i, :lens[i]] = torch.tensor(x['frame_mask'][0]).float()
+        meps[i, :x['in_motion_latent'].shape[0]] = torch.tensor(x['in_motion_latent'])
+        teps[i] = torch.tensor(x['in_traj_latent'][0])
+    big = priors.infer(pose, vis, lens, motion_eps=meps, traj_eps=teps)
+    small = priors.infer(pose[:len(base)].contiguous(), vis[:len(base)].contiguous(), lens[:len(base)], motion_eps=meps[:len(base)].contiguous(),
+                         traj_eps=teps[:len(base)].contiguous())
+    for i in (0, 1, 5, 7, 300, 517, 522):
+        j, n = i % len(base), lens[i]
+        for key in ('local_traj', 'trans', 'orient', 'pose'):
+            assert _err(big[key][i, :n].cpu(), small[key][j, :n].cpu()) < 2e-5, (i, key)
