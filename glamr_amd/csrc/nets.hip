@@ -289,6 +289,15 @@ Ws ws_layout(int B, int max_len, char* base) {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// attention with the key count known at compile time where the model fixes it (a window of 50 frames, 30 current frames)
+template <class... A>
+void launch_attention(dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldk,
+                      const unsigned char* mask, float* O, int ldo, int Lq, int Lk, int q_shared) {
+  if (Lk == WIN) hipLaunchKernelGGL(attention_kernel<WIN>, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
+  else if (Lk == CUR) hipLaunchKernelGGL(attention_kernel<CUR>, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
+  else hipLaunchKernelGGL(attention_kernel<0>, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
+}
+
 int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, int rows) {
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, R, n.g, n.b, Y, rows, D);
   return GLAMR_OK;
@@ -458,7 +467,7 @@ namespace {
 int encoder_layer(hipStream_t st, const EncLayer& E, Ws& w, float* h_in, float* h_out, int B) {
   const int M = B * WIN;
   RC(lin(st, E.qkv, h_in, D, w.qkv, 3 * D, M));
-  hipLaunchKernelGGL(attention_kernel, dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, w.mask, w.att, D, WIN, WIN, 0);
+  launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, w.mask, w.att, D, WIN, WIN, 0);
   RC(lin(st, E.o, w.att, D, w.tmp, D, M));
   RC(ln(st, w.tmp, h_in, E.n1, h_out, M));
   RC(lin(st, E.f1, h_out, D, w.ff, FF, M, ACT_RELU));
@@ -471,12 +480,12 @@ int encoder_layer(hipStream_t st, const EncLayer& E, Ws& w, float* h_in, float* 
 int decoder_layer(hipStream_t st, const DecLayer& Dl, Ws& w, float* x, const float* ctx, int B, int Lq) {
   const int M = B * Lq;
   RC(lin(st, Dl.sa_qkv, x, D, w.qkv, 3 * D, M));
-  hipLaunchKernelGGL(attention_kernel, dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, (const unsigned char*)nullptr, w.att, D, Lq, Lq, 0);
+  launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, (const unsigned char*)nullptr, w.att, D, Lq, Lq, 0);
   RC(lin(st, Dl.sa_o, w.att, D, w.tmp, D, M));
   RC(ln(st, w.tmp, x, Dl.n1, x, M));
   RC(lin(st, Dl.ca_q, x, D, w.qbuf, D, M));
   RC(lin(st, Dl.ca_kv, ctx, D, w.ctxkv, 2 * D, B * WIN));
-  hipLaunchKernelGGL(attention_kernel, dim3(B, 8), dim3(64), 0, st, w.qbuf, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, Lq, WIN, 0);
+  launch_attention( dim3(B, 8), dim3(64), 0, st, w.qbuf, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, Lq, WIN, 0);
   RC(lin(st, Dl.ca_o, w.att, D, w.tmp, D, M));
   RC(ln(st, w.tmp, x, Dl.n2, x, M));
   RC(lin(st, Dl.f1, x, D, w.ff, FF, M, ACT_RELU));
@@ -518,7 +527,7 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
     float* ctx = w.h0;
     // prior: two learned tokens attend to the context
     RC(lin(st, h->prior_kv, ctx, D, w.ctxkv, 2 * D, M));
-    hipLaunchKernelGGL(attention_kernel, dim3(B, 8), dim3(64), 0, st, h->prior_q, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, 2, WIN, 1);
+    launch_attention( dim3(B, 8), dim3(64), 0, st, h->prior_q, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, 2, WIN, 1);
     RC(lin(st, h->prior_o, w.att, D, w.tmp, D, B * 2));
     hipLaunchKernelGGL(tile_rows_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, st, w.dq, h->prior_x1, 2, B * 2 * D);
     RC(ln(st, w.tmp, w.dq, h->prior_n2, w.dq, B * 2));
