@@ -467,16 +467,6 @@ class GlobalReconOptimizer:
             d.pop('_pending', None)
         return datas
 
-    @staticmethod
-    def _to_torch(data):
-        def conv(x):
-            if isinstance(x, np.ndarray):
-                return torch.from_numpy(np.ascontiguousarray(x))
-            if isinstance(x, dict):
-                return {k: conv(v) for k, v in x.items()}
-            return x
-        return conv(data)
-
     def _forward_only_desc(self):
         first = next(iter(self.opt_stage_specs.values()))
         sd = packing.stage_desc(first, self.specs, has_world_dheading=False, niters=0)
