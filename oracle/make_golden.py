@@ -230,7 +230,8 @@ def _param_names(model, data, opt_variables):
 
 
 GRECON_CASES = [('glamr_dynamic', 120, 1, 25), ('glamr_static', 90, 1, 25), ('glamr_static_multi', 120, 2, 15),
-                ('glamr_dynamic_multi', 100, 2, 15), ('glamr_3dpw', 120, 1, 15), ('glamr_h36m', 100, 2, 10)]
+                ('glamr_dynamic_multi', 100, 2, 15), ('glamr_3dpw', 120, 1, 15), ('glamr_h36m', 100, 2, 10),
+                ('glamr_static_multi', 300, 4, 5)]          # BASELINE.json configs[3]: 4 persons, shared fixed camera, 300 frames
 
 
 def gen_grecon(cases=GRECON_CASES):
@@ -327,7 +328,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'grecon': gen_grecon, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'eval': gen_eval}[name]()
         print('done', name)
 
 
