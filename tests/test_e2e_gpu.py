@@ -203,3 +203,27 @@ def test_ragged_batch_equals_single_runs(make_model):
             assert np.abs(a['kp_2d_pred'] - b['kp_2d_pred'])[vis].max() < 0.5, 'seed %d person %d' % (s, idx)
             assert np.abs(a['root_trans_world'] - b['root_trans_world']).max() < 5e-3
             assert a['smpl_pose'].shape == (T, 69)
+
+
+def test_sequence_longer_than_a_workgroup(make_model, asset_root):
+    """700 frames: the optimiser workgroup has 512 threads, so every frame loop makes two passes and the prefix sums run in two chunks;
+    24 infiller windows.  Device path vs the CPU restatement on init_data and after 3 iterations of the stage."""
+    from oracle.port import build
+    from glamr_amd.global_recon.configs import get_config
+    T, K = 700, 3
+    cfg = get_config('glamr_dynamic')
+    in_dict = synth.make_in_dict(seed=9, num_frames=T, num_persons=1, smpl_model=synth.make_smpl_model(), gap=(300, 380))
+    lat = mg.latents_for(in_dict, 9)
+    ora = build.load_optimizer(asset_root, cfg)
+    data = ora.init_data(in_dict, latents=lat)
+    ref_init = data['person_data'][0]['kp_2d_pred'].detach().numpy().copy()
+    for stage, spec in cfg['opt_stage_specs'].items():
+        ora.optimize_main(data, spec['opt_variables'], spec['opt_lr'], min(K, spec['opt_niters']), spec['loss_cfg'], {'stage': stage})
+    model = make_model('glamr_dynamic')
+    init = model.init_data(in_dict, latents=lat)
+    out = model.optimize(in_dict, latents=lat, max_iters=K)
+    vis = np.asarray(out['person_data'][0]['vis_frames'])
+    assert vis.sum() == T - 80 and out['cam_pose'].shape == (T, 4, 4)
+    assert kp_err(init['person_data'][0]['kp_2d_pred'], ref_init, vis) < 5e-2
+    assert kp_err(out['person_data'][0]['kp_2d_pred'], data['person_data'][0]['kp_2d_pred'].detach().numpy(), vis) < 0.5
+    assert np.abs(out['person_data'][0]['root_trans_world'] - data['person_data'][0]['root_trans_world'].detach().numpy()).max() < 1e-2
