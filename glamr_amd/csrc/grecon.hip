@@ -34,7 +34,7 @@ struct KernelArgs {
   unsigned fast_floats;
 };
 
-template <bool FAST, bool SINGLE>
+template <bool FAST, bool SINGLE, int CAM>
 __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon_stage_kernel(KernelArgs a) {
   __shared__ float red[RT_RED_FLOATS];
   __shared__ Scene sc;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
   }
   __syncthreads();
   glamr::DeviceRT rt{red};
-  run_scene<FAST, SINGLE>(rt, sc, a.st, a.lay);
+  run_scene<FAST, SINGLE, CAM>(rt, sc, a.st, a.lay);
 }
 
 }  // namespace grecon
@@ -109,8 +109,15 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     return GLAMR_OK;
   };
   int rc;
-  if (ka.use_lds) rc = single ? launch(grecon_stage_kernel<true, true>, dyn) : launch(grecon_stage_kernel<true, false>, dyn);
-  else rc = launch(grecon_stage_kernel<false, false>, 0);
+  // the camera-mode instances pay off for single-person scenes (24.1 vs 26.1 us per iteration); the multi-person instances
+  // measured slower with them (53.8 vs 47.4), so those keep the general camera code
+  const int cam = single ? camera_mode(*stage) : 0;
+  if (ka.use_lds && single)
+    rc = cam == 1 ? launch(grecon_stage_kernel<true, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<true, true, 2>, dyn) : launch(grecon_stage_kernel<true, true, 0>, dyn);
+  else if (ka.use_lds)
+    rc = launch(grecon_stage_kernel<true, false, 0>, dyn);
+  else
+    rc = launch(grecon_stage_kernel<false, false, 0>, 0);
   if (rc) return rc;
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;

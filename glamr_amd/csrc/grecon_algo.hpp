@@ -490,12 +490,20 @@ GLAMR_HD float rel_transform_term(const Scene& sc, const SceneView& sh, const gl
 
 // SINGLE: the scene has exactly one person.  The person loops and the relative-transform term then disappear at compile time, and
 // with them every register spill of the general instance (264 VGPRs -> 0; 39 -> 26 us per iteration on the headline config).
-template <bool FAST, bool SINGLE, class RT>
+// CAM: how the stage treats the camera, when known at launch: 1 = optimised per frame, 2 = one optimised camera shared by all frames
+// (flag_fixed_cam), 0 = anything (constant, or derived from the persons).  Each value removes the other modes' code -- and their
+// registers -- from the instance: the general multi-person instance spills 214 VGPRs, its CAM = 1 version 58.
+inline int camera_mode(const glamr_stage_desc& st) {
+  if (!(st.var_mask & GLAMR_VAR_CAM)) return 0;
+  return (st.flags & GLAMR_FLAG_FIXED_CAM) ? 2 : 1;
+}
+
+template <bool FAST, bool SINGLE, int CAM, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
   const int T = sc.T, P = SINGLE ? 1 : sc.P;
-  const bool var_cam = st.var_mask & GLAMR_VAR_CAM;
-  const bool fixed_cam = st.flags & GLAMR_FLAG_FIXED_CAM;
-  const bool cam_from_person = !var_cam && (st.flags & GLAMR_FLAG_CAM_FROM_PERSON);
+  const bool var_cam = CAM != 0 ? true : (bool)(st.var_mask & GLAMR_VAR_CAM);
+  const bool fixed_cam = CAM == 2 ? true : (CAM == 1 ? false : (bool)(st.flags & GLAMR_FLAG_FIXED_CAM));
+  const bool cam_from_person = CAM != 0 ? false : (!var_cam && (st.flags & GLAMR_FLAG_CAM_FROM_PERSON));
   const bool has_wd = (st.flags & GLAMR_FLAG_HAS_WORLD_DHEADING) || (st.var_mask & GLAMR_VAR_WORLD_DHEADING);
   auto on = [&](int id) { return (st.loss_mask >> id) & 1u; };
   auto active = [&](int id) { return ((st.loss_mask >> id) & 1u) && !((st.monitor_mask >> id) & 1u); };
