@@ -54,8 +54,7 @@ struct glamr_smpl {
   int V, num_betas, n_extra, n_picked, n_out, n_levels;
   int n_extra_used;
   glamr_tileset full;      // every vertex (vertices requested)
-  glamr_tileset joints;    // only the vertices the mapped joints depend on: picked vertices + the support of the used extra-regressor
-                           // rows (n_tiles == 0 when that is not a saving); used when only joints are requested
+  glamr_tileset joints;    // joints only: the picked vertices + 24 VIRTUAL vertices per used extra-regressed joint (see glamr_smpl_create)
   // device constants
   float* j_template;      // [24][3]
   float* j_shapedirs;     // [24][3][num_betas]
@@ -516,39 +515,51 @@ extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const f
   GLAMR_REQUIRE(n_used == 0 || J_regressor_extra, "joint_map references extra joints but J_regressor_extra is null");
 
   // tilings: [tile][plane][row][KSTRIDE]; k: 0..9 shapedirs, 10..216 posedirs, 217 v_template
-  auto build_tileset = [&](glamr_tileset* ts, const std::vector<int32_t>& vids) -> int {
-    const int n = (int)vids.size();
+  // A (possibly virtual) vertex of a tiling: its blend directions over the feature vector [10 betas | 207 pose features | 1], its
+  // skinning weights and its weight in every used extra-joint regressor.
+  struct VirtVert { float d[3][218]; float w[NJ]; float jx[MAX_EXTRA]; };
+  auto real_vertex = [&](int v, bool with_regressors) {
+    VirtVert q;
+    std::memset(&q, 0, sizeof(q));
+    for (int r = 0; r < 3; ++r) {
+      for (int l = 0; l < num_betas; ++l) q.d[r][l] = shapedirs[((size_t)v * 3 + r) * num_betas + l];
+      for (int k = 0; k < 207; ++k) q.d[r][10 + k] = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + r];
+      q.d[r][217] = v_template[(size_t)v * 3 + r];
+    }
+    for (int j = 0; j < NJ; ++j) q.w[j] = lbs_weights[(size_t)v * NJ + j];
+    if (with_regressors)
+      for (int e = 0; e < n_extra; ++e)
+        if (extra_slot[e] >= 0) q.jx[extra_slot[e]] = J_regressor_extra[(size_t)e * V + v];
+    return q;
+  };
+  // pick_pos[p]: index in `vv` of picked vertex p
+  auto build_tileset = [&](glamr_tileset* ts, const std::vector<VirtVert>& vv, const std::vector<int32_t>& pick_pos) -> int {
+    const int n = (int)vv.size();
     ts->n_verts = n;
     ts->n_tiles = (n + TILE_V - 1) / TILE_V;
     ts->Vpad = ts->n_tiles * TILE_V;
-    std::vector<int32_t> pos(V, -1);
     std::vector<float> dirs((size_t)ts->n_tiles * 3 * TILE_V * KSTRIDE, 0.0f);
     std::vector<float> w((size_t)ts->Vpad * NJ, 0.0f);
     std::vector<float> jx((size_t)std::max(1, n_used) * ts->Vpad, 0.0f);
     for (int i = 0; i < n; ++i) {
-      const int v = vids[i], tile = i / TILE_V, row = i % TILE_V;
-      pos[v] = i;
+      const int tile = i / TILE_V, row = i % TILE_V;
       for (int r = 0; r < 3; ++r) {
         float* d = &dirs[(((size_t)tile * 3 + r) * TILE_V + row) * KSTRIDE];
-        for (int l = 0; l < num_betas; ++l) d[l] = shapedirs[((size_t)v * 3 + r) * num_betas + l];
-        for (int k = 0; k < 207; ++k) d[10 + k] = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + r];
-        d[K_ONE] = v_template[(size_t)v * 3 + r];
+        for (int k = 0; k < 218; ++k) d[k] = vv[i].d[r][k];          // d[K_ONE = 217] carries the template
       }
-      for (int j = 0; j < NJ; ++j) w[(size_t)i * NJ + j] = lbs_weights[(size_t)v * NJ + j];
-      for (int e = 0; e < n_extra; ++e)
-        if (extra_slot[e] >= 0) jx[(size_t)extra_slot[e] * ts->Vpad + i] = J_regressor_extra[(size_t)e * V + v];
+      for (int j = 0; j < NJ; ++j) w[(size_t)i * NJ + j] = vv[i].w[j];
+      for (int e = 0; e < n_used; ++e) jx[(size_t)e * ts->Vpad + i] = vv[i].jx[e];
     }
     // picked vertices sorted by tile (CSR)
     std::vector<int32_t> pick_row(std::max(1, n_picked)), tstart(ts->n_tiles + 1, 0), tids(std::max(1, n_picked));
     for (int p = 0; p < n_picked; ++p) {
-      const int i = pos[extra_vertex_ids[p]];
-      pick_row[p] = i % TILE_V;
-      tstart[i / TILE_V + 1]++;
+      pick_row[p] = pick_pos[p] % TILE_V;
+      tstart[pick_pos[p] / TILE_V + 1]++;
     }
     for (int t = 0; t < ts->n_tiles; ++t) tstart[t + 1] += tstart[t];
     {
       std::vector<int32_t> cur(tstart.begin(), tstart.end() - 1);
-      for (int p = 0; p < n_picked; ++p) tids[cur[pos[extra_vertex_ids[p]] / TILE_V]++] = p;
+      for (int p = 0; p < n_picked; ++p) tids[cur[pick_pos[p] / TILE_V]++] = p;
     }
     int rc;
     if ((rc = upload(&ts->dirs_tiled, dirs.data(), dirs.size()))) return rc;
@@ -563,20 +574,47 @@ extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const f
     GLAMR_REQUIRE(extra_vertex_ids[p] >= 0 && extra_vertex_ids[p] < V, "extra_vertex_ids[%d] out of range", p);
   int rc;
   {
-    std::vector<int32_t> all(V);
-    for (int v = 0; v < V; ++v) all[v] = v;
-    if ((rc = build_tileset(&h->full, all))) return rc;
-    // vertices the mapped joints depend on
-    std::vector<char> need(V, 0);
-    for (int p = 0; p < n_picked; ++p) need[extra_vertex_ids[p]] = 1;
-    for (int e = 0; e < n_extra; ++e)
-      if (extra_slot[e] >= 0)
-        for (int v = 0; v < V; ++v) if (J_regressor_extra[(size_t)e * V + v] != 0.0f) need[v] = 1;
-    std::vector<int32_t> sub;
-    for (int v = 0; v < V; ++v) if (need[v]) sub.push_back(v);
-    if (!sub.empty() && sub.size() * 2 <= (size_t)V) {
-      if ((rc = build_tileset(&h->joints, sub))) return rc;
+    std::vector<VirtVert> all((size_t)V);
+    std::vector<int32_t> pick_pos(std::max(1, n_picked), 0);
+    for (int v = 0; v < V; ++v) all[v] = real_vertex(v, true);
+    for (int p = 0; p < n_picked; ++p) pick_pos[p] = extra_vertex_ids[p];
+    if ((rc = build_tileset(&h->full, all, pick_pos))) return rc;
+  }
+  {
+    // Joints only.  A regressed joint is  sum_v Jx_v T_v vposed_v  with T_v = sum_k W_vk A_k, i.e.  sum_k A_k . (sum_v Jx_v W_vk vposed_v):
+    // the inner sum is linear in the feature vector, so per (joint, chain joint k) ONE virtual vertex with the weighted-average blend
+    // directions, skinning weight s_k = sum_v Jx_v W_vk on bone k and regressor weight 1 gives the same joint -- 24 virtual vertices
+    // per regressed joint instead of the hundreds in its support.  Picked vertices stay real.
+    std::vector<VirtVert> vv;
+    std::vector<int32_t> pick_pos(std::max(1, n_picked), 0);
+    for (int p = 0; p < n_picked; ++p) { pick_pos[p] = (int)vv.size(); vv.push_back(real_vertex(extra_vertex_ids[p], false)); }
+    std::vector<double> acc(3 * 218);
+    for (int e = 0; e < n_extra; ++e) {
+      if (extra_slot[e] < 0) continue;
+      for (int k = 0; k < NJ; ++k) {
+        double sk = 0.0;
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int v = 0; v < V; ++v) {
+          const double c = (double)J_regressor_extra[(size_t)e * V + v] * (double)lbs_weights[(size_t)v * NJ + k];
+          if (c == 0.0) continue;
+          sk += c;
+          for (int r = 0; r < 3; ++r) {
+            double* a = &acc[r * 218];
+            for (int l = 0; l < num_betas; ++l) a[l] += c * shapedirs[((size_t)v * 3 + r) * num_betas + l];
+            for (int q = 0; q < 207; ++q) a[10 + q] += c * posedirs[(size_t)q * V * 3 + (size_t)v * 3 + r];
+            a[217] += c * v_template[(size_t)v * 3 + r];
+          }
+        }
+        if (sk == 0.0) continue;
+        VirtVert q;
+        std::memset(&q, 0, sizeof(q));
+        for (int r = 0; r < 3; ++r) for (int i = 0; i < 218; ++i) q.d[r][i] = (float)(acc[r * 218 + i] / sk);
+        q.w[k] = (float)sk;
+        q.jx[extra_slot[e]] = 1.0f;
+        vv.push_back(q);
+      }
     }
+    if (!vv.empty() && (rc = build_tileset(&h->joints, vv, pick_pos))) return rc;
   }
   // rest joints and their shape derivatives (J = J_regressor (v_template + shapedirs beta) is linear in beta)
   std::vector<float> jt(NJ * 3), js((size_t)NJ * 3 * num_betas);
