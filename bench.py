@@ -96,8 +96,8 @@ def cpu_baseline(asset_root, iters=12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=1024, help='independent sequences per GPU per step')
     ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
