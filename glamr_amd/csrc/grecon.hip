@@ -34,7 +34,7 @@ struct KernelArgs {
   unsigned fast_floats;
 };
 
-template <bool FAST, bool SINGLE, int CAM>
+template <int FAST, bool SINGLE, int CAM>
 __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon_stage_kernel(KernelArgs a) {
   __shared__ float red[RT_RED_FLOATS];
   __shared__ Scene sc;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
     s_st = a.st;
     s_lay = a.lay;
     assemble_scene(a.b, s_lay, &s_st, si, a.b.n_persons[si], a.b.seq_len[si], a.workspace + (size_t)si * a.ws_floats_per_scene, a.grads_out, sc,
-                   a.use_lds ? arena : nullptr, a.fast_floats);
+                   a.use_lds ? arena : nullptr, a.fast_floats, a.use_lds);
   }
   __syncthreads();
   glamr::DeviceRT rt{red};
@@ -96,9 +96,11 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   if (threads > MAX_THREADS) threads = MAX_THREADS;
   // on-chip arena: prefix-sum / neighbour-exchange arrays first, then as much of the compact keypoint table as fits
   constexpr size_t LDS_BUDGET = GLAMR_GRECON_LDS_KB * 1024;
-  const size_t base = scene_fast_floats(batch->max_persons, batch->max_len) * sizeof(float);
+  const size_t full = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
+  const size_t lite = scene_fast_floats(batch->max_persons, batch->max_len, 2) * sizeof(float);
+  ka.use_lds = full <= LDS_BUDGET ? 1 : (lite <= LDS_BUDGET ? 2 : 0);              // 1 full arena, 2 lite arena, 0 everything in the workspace
+  const size_t base = ka.use_lds == 1 ? full : lite;
   const size_t want = base + (size_t)NJ * 6 * batch->max_persons * batch->max_len * sizeof(float);
-  ka.use_lds = base <= LDS_BUDGET;
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
   ka.fast_floats = (unsigned)(dyn / sizeof(float));
   // SINGLE needs every scene of the batch to hold exactly one person: max_persons == 1 guarantees it
@@ -112,12 +114,16 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // the camera-mode instances pay off for single-person scenes (24.1 vs 26.1 us per iteration); the multi-person instances
   // measured slower with them (53.8 vs 47.4), so those keep the general camera code
   const int cam = single ? camera_mode(*stage) : 0;
-  if (ka.use_lds && single)
-    rc = cam == 1 ? launch(grecon_stage_kernel<true, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<true, true, 2>, dyn) : launch(grecon_stage_kernel<true, true, 0>, dyn);
-  else if (ka.use_lds)
-    rc = launch(grecon_stage_kernel<true, false, 0>, dyn);
+  if (ka.use_lds == 1 && single)
+    rc = cam == 1 ? launch(grecon_stage_kernel<1, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, true, 2>, dyn) : launch(grecon_stage_kernel<1, true, 0>, dyn);
+  else if (ka.use_lds == 1)
+    rc = launch(grecon_stage_kernel<1, false, 0>, dyn);
+  else if (ka.use_lds == 2 && single)
+    rc = cam == 1 ? launch(grecon_stage_kernel<2, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, true, 2>, dyn) : launch(grecon_stage_kernel<2, true, 0>, dyn);
+  else if (ka.use_lds == 2)
+    rc = launch(grecon_stage_kernel<2, false, 0>, dyn);
   else
-    rc = launch(grecon_stage_kernel<false, false, 0>, 0);
+    rc = launch(grecon_stage_kernel<0, false, 0>, 0);
   if (rc) return rc;
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;

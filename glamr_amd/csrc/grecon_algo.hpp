@@ -120,19 +120,22 @@ template <class T> __device__ __forceinline__ T* glob(T* p) {
   asm("" : "+s"(g));
   return (T*)g;
 }
-template <bool FAST, class T> __device__ __forceinline__ T* fastp(T* p) {
-  if (FAST) {
+template <int FAST, class T> __device__ __forceinline__ T* fastp(T* p) {
+  if (FAST != 0) {
     __attribute__((address_space(3))) T* g = (__attribute__((address_space(3))) T*)uni(p);
     asm("" : "+s"(g));
     return (T*)g;
   }
   return glob(p);
 }
+// arrays of the second group are on chip only with the full arena (FAST == 1); with the lite arena (FAST == 2) they are global
+template <int FAST, class T> __device__ __forceinline__ T* fastp2(T* p) { return FAST == 1 ? fastp<1>(p) : glob(p); }
 #else
 template <class T> inline T* uni(T* p) { return p; }
 inline int uni(int x) { return x; }
 template <class T> inline T* glob(T* p) { return p; }
-template <bool FAST, class T> inline T* fastp(T* p) { return p; }
+template <int FAST, class T> inline T* fastp(T* p) { return p; }
+template <int FAST, class T> inline T* fastp2(T* p) { return p; }
 #endif
 
 struct PersonView {      // what the iteration loop needs of PersonConst + PersonState, uniform
@@ -142,7 +145,7 @@ struct PersonView {      // what the iteration loop needs of PersonConst + Perso
   float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc;
   const float *kpc, *kpc_ws;
 };
-template <bool FAST>
+template <int FAST>
 GLAMR_HD PersonView person_view(const Scene& sc, int p) {
   const PersonConst& c = sc.pc[p];
   const PersonState& s = sc.ps[p];
@@ -152,8 +155,9 @@ GLAMR_HD PersonView person_view(const Scene& sc, int p) {
   w.base_orient = glob(c.base_orient); w.base_trans = glob(c.base_trans); w.person2cam = glob(c.person2cam); w.dheading_mask = glob(c.dheading_mask);
   w.h_prior = glob(s.h_prior); w.oc6 = glob(s.oc6); w.kp_wsum = glob(s.kp_wsum); w.vis_rank = glob(c.vis_rank);
   w.p = glob(s.p); w.m = glob(s.m); w.v = glob(s.v); w.g = glob(s.g);
-  w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.tw = fastp<FAST>(s.tw);
-  w.g_d6 = fastp<FAST>(s.g_d6); w.g_tw = fastp<FAST>(s.g_tw); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy); w.Lc = fastp<FAST>(s.Lc);
+  // first group (prefix sums, neighbour reads): on chip with either arena; second group (own-frame hand-over arrays): full arena only
+  w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy);
+  w.tw = fastp2<FAST>(s.tw); w.g_d6 = fastp2<FAST>(s.g_d6); w.g_tw = fastp2<FAST>(s.g_tw); w.Lc = fastp2<FAST>(s.Lc);
   w.orient_world = glob(s.orient_world); w.trans_world = glob(s.trans_world); w.kp_2d_pred = glob(s.kp_2d_pred); w.orient_cam_in_world = glob(s.orient_cam_in_world);
   w.kpc = fastp<FAST>(s.kpc); w.kpc_ws = glob(s.kpc_ws);      // kpc is only dereferenced for the njc_fast joints that are on chip
   return w;
@@ -163,7 +167,7 @@ struct SceneView {
   float *cam_pose, *cam_inv, *cam_t, *g_cam, *g_caminv, *g_avg, *cp, *cm, *cv, *cg, *losses;
   int store_grad, rel_stride_p, rel_stride_t, TM;
 };
-template <bool FAST>
+template <int FAST>
 GLAMR_HD SceneView scene_view(const Scene& sc) {
   SceneView w;
   w.rel_cam = glob(sc.rel_cam); w.pair_first = glob(sc.pair_first); w.fill_src = glob(sc.fill_src); w.n_vis_persons = glob(sc.n_vis_persons);
@@ -329,7 +333,9 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
   l.scene_stride = l.person0 + max_persons * l.person_stride;
 }
 
-GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len) { return (size_t)(15 + 38 * max_persons) * max_len; }
+// on-chip arena: mode 1 (full) = every exchange / hand-over array; mode 2 (lite) = only the arrays other threads read (prefix sums,
+// cos/sin, world rotation columns, camera) -- 14 instead of 38 floats per person-frame, for scenes with many persons or frames
+GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len, int mode = 1) { return (size_t)(15 + (mode == 1 ? 38 : 14) * max_persons) * max_len; }
 
 GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
   glamr_param_layout l;
@@ -343,7 +349,7 @@ GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
 // Binds scene `si` of the batch to pointers (no computation).  `ws` = this scene's workspace slice.
 GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layout& l, const glamr_stage_desc* st, int si,
                              int n_persons, int seq_len, float* ws, float* grads_out, Scene& sc, float* fast = nullptr,
-                             size_t fast_floats = 0) {
+                             size_t fast_floats = 0, int fast_mode = 1) {
   const size_t TM = (size_t)b.max_len;
   sc.P = n_persons; sc.T = seq_len; sc.lay = &l; sc.st = st;
   sc.rel_cam = b.rel_transform_cam ? b.rel_transform_cam + (size_t)si * b.max_persons * b.max_persons * TM * 12 : nullptr;
@@ -356,6 +362,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   // arrays other threads read (neighbouring frames, prefix sums) go to the on-chip arena when the caller provides one
   float* f = fast;
   auto takef = [&](size_t n) { if (!fast) return take(n); float* r = f; f += n; return r; };
+  auto takef2 = [&](size_t n) { if (!fast || fast_mode != 1) return take(n); float* r = f; f += n; return r; };      // second group
   sc.cm = take(l.person0); sc.cv = take(l.person0);
   float* cg_ws = take(l.person0);
   sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : cg_ws;
@@ -370,8 +377,8 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     s.m = take(l.person_stride); s.v = take(l.person_stride);
     float* g_ws = take(l.person_stride);
     s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
-    s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef(3 * TM); s.g_d6 = takef(6 * TM); s.g_tw = takef(3 * TM);
-    s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef(12 * TM);
+    s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef2(3 * TM); s.g_d6 = takef2(6 * TM); s.g_tw = takef2(3 * TM);
+    s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef2(12 * TM);
     s.kpc_ws = take((size_t)NJ * 6 * TM); s.kpc = s.kpc_ws; s.njc = 0; s.njc_fast = 0;
     c.vis_rank = reinterpret_cast<int*>(take(TM));
     s.kp_wsum = take(32);
@@ -436,7 +443,7 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
 
 // loss_func.py:248-271 for person p at frame t (both ordered pairs it takes part in).  Returns the unweighted sum of squares of the
 // pairs (p, o) and adds the gradient w.r.t. p's world transform [Rk | tw].
-template <bool FAST>
+template <int FAST>
 GLAMR_HD float rel_transform_term(const Scene& sc, const SceneView& sh, const glamr_stage_desc& st, int P, int p, int t, const float* Rk,
                                            const float* tw, float w_rel, float* gRk, float* g_tw) {
   float value = 0.f;
@@ -498,7 +505,7 @@ inline int camera_mode(const glamr_stage_desc& st) {
   return (st.flags & GLAMR_FLAG_FIXED_CAM) ? 2 : 1;
 }
 
-template <bool FAST, bool SINGLE, int CAM, class RT>
+template <int FAST, bool SINGLE, int CAM, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
   const int T = sc.T, P = SINGLE ? 1 : sc.P;
   const bool var_cam = CAM != 0 ? true : (bool)(st.var_mask & GLAMR_VAR_CAM);
@@ -629,7 +636,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     {
       float* ch[8];
       for (int p = 0; p < P; ++p) ch[p] = person_view<FAST>(sc, p).theta;
-      rt.template scan_multi<FAST>(ch, P, T, 1, false);
+      rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false);
     }
     // own element of the prefix sum is final: its cos / sin serve phases B, C and I (this frame's and the next frame's)
     for (int t = rt.tid(); t < T; t += rt.nthreads())
@@ -662,7 +669,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     {
       float* ch[16];
       for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST>(sc, p).xy; ch[2 * p + 1] = person_view<FAST>(sc, p).xy + 1; }
-      rt.template scan_multi<FAST>(ch, 2 * P, T, 2, false);
+      rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, false);
     }
     GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
@@ -1142,7 +1149,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       {
         float* ch[16];
         for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST>(sc, p).g_xy; ch[2 * p + 1] = person_view<FAST>(sc, p).g_xy + 1; }
-        rt.template scan_multi<FAST>(ch, 2 * P, T, 2, true);
+        rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, true);
       }
       rt.sync();
       GLAMR_MARK(rt, 6);
@@ -1186,7 +1193,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       {
         float* ch[8];
         for (int p = 0; p < P; ++p) ch[p] = person_view<FAST>(sc, p).g_theta;
-        rt.template scan_multi<FAST>(ch, P, T, 1, true);
+        rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, true);
       }
       GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
