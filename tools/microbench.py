@@ -27,10 +27,11 @@ def main():
     data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 0))
     jl = j_local_from_oracle(ora.smpl, data)
     L = _lib.lib()
-    spec = cfg['opt_stage_specs']['init_opt']
+    spec = cfg['opt_stage_specs'][os.environ.get('GLAMR_MB_STAGE', 'init_opt')]
+    has_wd = os.environ.get('GLAMR_MB_STAGE', 'init_opt') != 'init_opt' and any('world_dheading' in s_['opt_variables'] for s_ in cfg['opt_stage_specs'].values())
     for S in (1, 256) if 'GLAMR_MB_FRAMES' in os.environ else (1, 64, 256, 1024):
         packed = packing.PackedScenes([data] * S, [jl] * S, dev)
-        sd = packing.stage_desc(spec, cfg['grecon_model_specs'], False)
+        sd = packing.stage_desc(spec, cfg['grecon_model_specs'], False, niters=min(200, spec['opt_niters']))
         sb = packed.struct()
         ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=dev)
         for rep in range(2):
