@@ -141,7 +141,7 @@ def main():
     def step(i=0):
         with torch.cuda.stream(streams[i % len(streams)]):
             _, packed = model.optimize_resident(rin)
-        stage_events.append(packed.stage_events)
+        stage_events.append(packed.stage_ws)
         keep.append(packed)                                        # results of the timed steps stay resident until the clock stops
         if len(keep) > 2 * len(streams):
             keep.pop(0)
@@ -161,7 +161,22 @@ def main():
         dist.barrier()
     elapsed = time.time() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
-    kms = [a.elapsed_time(b) for evs in stage_events for a, b in evs]      # one entry per optimiser-stage launch in the timed region
+    # one entry per optimiser-stage launch in the timed region: the kernel's own clock (earliest workgroup start to latest workgroup
+    # end, what rocprofv3 reports for the dispatch) -- HIP events around the launch would also count the time it waits behind the
+    # other stream
+    kms_timed = [model.launch_ms(ws) for wss in stage_events for ws in wss]
+    # With more than one stream the stage launches of consecutive batches share the CUs, so a launch's span says nothing about the
+    # kernel: the roofline figure comes from launches that have the GPU to themselves -- the timed ones when --streams 1, otherwise
+    # two extra single-stream steps right after the timed region.
+    if len(streams) == 1:
+        kms = kms_timed
+    else:
+        kms = []
+        for _ in range(2):
+            with torch.cuda.stream(streams[0]):
+                _, packed = model.optimize_resident(rin)
+            torch.cuda.synchronize()
+            kms.extend(model.launch_ms(ws) for ws in packed.stage_ws)
     # host dictionaries in -> host dictionaries out, for the record (never `value`)
     n_host = min(2, args.steps)
     t0 = time.time()
@@ -187,6 +202,10 @@ def main():
             'roofline': {'kernel': 'grecon_stage_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': TRAFFIC_BYTES_PER_SCENE_ITER * B * iters, 'avg_launch_ms': k_avg,
                          'us_per_iteration': k_avg * 1e3 / iters, 'dependent_boundary_floor_us': 1.45,
+                         'launch_ms_each': [round(x, 2) for x in kms], 'launch_ms_in_timed_region': [round(x, 2) for x in kms_timed],
+                         'measured': ('the launches of the timed region (one stream)' if len(streams) == 1 else
+                                      '2 single-stream steps right after the timed region: in the timed region the launches of the %d streams '
+                                      'share the CUs and each spans about twice its own duration' % len(streams)),
                          'note': 'latency-bound: one workgroup per scene, state on chip; traffic = PMC FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/r01_pmc_stage_kernel_b1024.csv) scaled to this batch, '
                                  'about a third of the algorithmic bytes because parameters are the only per-iteration stream; algorithmic bytes = %d B per person-iteration '
                                  '(SURVEY.md 8d K5) x %d scenes x %d iterations' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},

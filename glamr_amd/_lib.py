@@ -62,6 +62,7 @@ _SIGNATURES = {
     'glamr_grecon_param_layout': (c_int, [c_int, c_int, POINTER(ParamLayout)]),
     'glamr_grecon_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'glamr_grecon_run_stage': (c_int, [POINTER(SceneBatch), POINTER(StageDesc), c_void_p, c_void_p, c_void_p]),
+    'glamr_grecon_last_launch_ns': (c_int, [c_void_p, POINTER(ctypes.c_double)]),
 }
 
 

@@ -28,6 +28,7 @@ struct KernelArgs {
   glamr_stage_desc st;
   glamr_param_layout lay;
   float* workspace;
+  unsigned long long* stamps;          // {earliest workgroup start, latest workgroup end} of this launch, 100 MHz ticks
   size_t ws_floats_per_scene;
   float* grads_out;
   int use_lds;
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
   extern __shared__ __attribute__((aligned(16))) float arena[];     // prefix-sum buffers and neighbour-read arrays, when they fit
   const int si = blockIdx.x;
   if (threadIdx.x == 0) {
+    atomicMin(a.stamps, (unsigned long long)wall_clock64());
     s_st = a.st;
     s_lay = a.lay;
     assemble_scene(a.b, s_lay, &s_st, si, a.b.n_persons[si], a.b.seq_len[si], a.workspace + (size_t)si * a.ws_floats_per_scene, a.grads_out, sc,
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
   __syncthreads();
   glamr::DeviceRT rt{red};
   run_scene<FAST, SINGLE, CAM>(rt, sc, a.st, a.lay);
+  if (threadIdx.x == 0) atomicMax(a.stamps + 1, (unsigned long long)wall_clock64());
 }
 
 }  // namespace grecon
@@ -65,9 +68,11 @@ extern "C" int glamr_grecon_param_layout(int max_persons, int max_len, glamr_par
   return GLAMR_OK;
 }
 
+constexpr size_t GLAMR_GRECON_WS_HEADER = 256;
+
 extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len) {
   if (n_scenes <= 0 || max_persons < 1 || max_persons > 8 || max_len < 2) return 0;
-  return (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, max_len), 64) * sizeof(float);
+  return GLAMR_GRECON_WS_HEADER + (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, max_len), 64) * sizeof(float);
 }
 
 extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out,
@@ -89,7 +94,11 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   ka.b = *batch;
   ka.st = *stage;
   param_layout(batch->max_persons, batch->max_len, ka.lay);
-  ka.workspace = static_cast<float*>(workspace);
+  // workspace header: the launch's own clock stamps (read back with glamr_grecon_last_launch_ns)
+  ka.stamps = static_cast<unsigned long long*>(workspace);
+  GLAMR_HIP_CHECK(hipMemsetAsync(workspace, 0xFF, 8, stream));
+  GLAMR_HIP_CHECK(hipMemsetAsync(static_cast<char*>(workspace) + 8, 0, 8, stream));
+  ka.workspace = reinterpret_cast<float*>(static_cast<char*>(workspace) + GLAMR_GRECON_WS_HEADER);
   ka.ws_floats_per_scene = align_up(scene_workspace_floats(batch->max_persons, batch->max_len), 64);
   ka.grads_out = grads_out;
   int threads = (batch->max_len + 63) / 64 * 64;
@@ -135,3 +144,11 @@ extern "C" int glamr_debug_phase_ticks(unsigned long long* out16) {
   return GLAMR_OK;
 }
 #endif
+
+extern "C" int glamr_grecon_last_launch_ns(const void* workspace, double* ns) {
+  GLAMR_REQUIRE(workspace && ns, "null argument");
+  unsigned long long st[2];
+  GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));        // synchronises with the launch
+  *ns = st[1] > st[0] ? (double)(st[1] - st[0]) * 10.0 : 0.0;
+  return GLAMR_OK;
+}

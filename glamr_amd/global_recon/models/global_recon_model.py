@@ -480,6 +480,15 @@ class GlobalReconOptimizer:
         sb = packed.struct()
         ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=self.device)
         _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, _lib.ptr(ws), _lib.current_stream()))
+        return ws
+
+    @staticmethod
+    def launch_ms(ws):
+        """Duration of the stage launch that used workspace `ws`, from the kernel's own clock (blocks until it has finished)."""
+        import ctypes
+        ns = ctypes.c_double()
+        _lib.check(_lib.lib().glamr_grecon_last_launch_ns(_lib.ptr(ws), ctypes.byref(ns)))
+        return ns.value * 1e-6
 
     def run_schedule(self, packed, max_iters=None):
         """The staged optimisation (:250-262) of an initialised batch: one kernel launch per stage, asynchronous on the current
@@ -489,16 +498,12 @@ class GlobalReconOptimizer:
         for stage, spec in self.opt_stage_specs.items():
             sd = packing.stage_desc(spec, self.specs, has_world_dheading=has_wd,
                                     niters=None if max_iters is None else min(max_iters, spec['opt_niters']))
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))   # on the stream the kernel runs on
-            ev[0].record()
-            self._run(packed, sd)
-            ev[1].record()
-            events.append(ev)
+            events.append(self._run(packed, sd))               # the launch's workspace: its header carries the kernel's own clock stamps
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
         packed.has_world_dheading = has_wd
-        packed.stage_events = events
+        packed.stage_ws = events
         return packed
 
     def optimize_resident(self, rin, max_iters=None):
@@ -511,8 +516,8 @@ class GlobalReconOptimizer:
     def collect(self, datas, packed):
         """Device arrays -> the reference's output dictionaries (numpy): one device->host copy per array."""
         torch.cuda.synchronize(self.device)
-        if getattr(self, 'kernel_ms', None) is not None and getattr(packed, 'stage_events', None):
-            self.kernel_ms.extend(a.elapsed_time(b) for a, b in packed.stage_events)
+        if getattr(self, 'kernel_ms', None) is not None and getattr(packed, 'stage_ws', None):
+            self.kernel_ms.extend(self.launch_ms(ws) for ws in packed.stage_ws)
         t0 = time.time()
         all_vars = sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))
         if datas and datas[0].get('_pending'):

@@ -199,6 +199,10 @@ size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len);
  * If `grads_out` (dev, n_scenes*scene_stride) is non-NULL the gradient of the LAST evaluated iteration is stored there. */
 int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out,
                            void* workspace, void* stream);
+/* Duration of the last glamr_grecon_run_stage that used `workspace`, from the kernel's own clock (earliest workgroup start to latest
+ * workgroup end, 10 ns resolution): what a profiler reports for the dispatch, also when other streams share the GPU.  Blocks until
+ * that launch has finished. */
+int glamr_grecon_last_launch_ns(const void* workspace, double* ns);
 
 
 /* ---------------------------------------------------------------------------------------------------------------------
