@@ -11,6 +11,9 @@ scatter + PCIe both ways + building the reference's output dictionaries) is meas
 `host_inclusive_sequences_per_sec`.  Multi-GPU: one process per GPU (torch.distributed over RCCL), sequences are independent, so
 ranks share nothing on the data path (weak scaling); the only collectives are the barrier and the max-reduction of the elapsed time.
 
+Consecutive steps alternate over `--streams` HIP streams (default 2).  Kernel durations come from the kernel's own clock (stamps in
+the workspace header), and the roofline launch is measured with the GPU to itself (see main()).
+
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the fused optimiser stage), `cpu_baseline` the CPU
 oracle (a port of the reference, oracle/port) timed on a bounded sample on this box's host cores.
 """
