@@ -112,3 +112,38 @@ def load_pose_pkl(path, seq_name=None):
         est = pickle.load(f)
     import os
     return make_in_dict(est, seq_name or os.path.splitext(os.path.basename(os.path.dirname(os.path.abspath(path))))[0])
+
+
+# ---- ground truth (evaluation) ------------------------------------------------------------------------------------------------------
+
+def normalise_gt(gt_dict, num_frames=None):
+    """The ground-truth pickle `preprocess/preprocess_3dpw.py:115-153` writes: {'person_data': {pid: {'pose' (T,72), 'shape' (10,),
+    'root_trans' (T,3), 'pose_cam', 'root_trans_cam', 'visible', ...}}, 'meta': {'cam_pose', 'cam_K', ...}}.  Returns
+    (person_data, meta) as run_dataset.py:98-101 hands them to optimize(); only the fields the evaluator reads
+    (global_recon/utils/evaluator.py:238-262) are required."""
+    if not isinstance(gt_dict, dict) or 'person_data' not in gt_dict:
+        raise WireFormatError("ground truth must be {'person_data': {...}, 'meta': {...}}")
+    out = {}
+    for pid, src in gt_dict['person_data'].items():
+        for k in ('pose', 'shape', 'root_trans'):
+            if k not in src:
+                _fail(pid, 'ground truth lacks %r' % k)
+        pose = np.asarray(src['pose'], dtype=np.float32)
+        if pose.ndim != 2 or pose.shape[1] != 72:
+            _fail(pid, 'ground-truth pose must be (T, 72) axis-angle, got %s' % (pose.shape,))
+        T = pose.shape[0]
+        if num_frames is not None and T != num_frames:
+            _fail(pid, 'ground truth covers %d frames, the estimate %d' % (T, num_frames))
+        shape = np.asarray(src['shape'], dtype=np.float32).reshape(-1)
+        if shape.size < 10:
+            _fail(pid, 'ground-truth shape needs 10 coefficients, got %d' % shape.size)
+        trans = np.asarray(src['root_trans'], dtype=np.float32)
+        if trans.shape != (T, 3):
+            _fail(pid, 'ground-truth root_trans must be (%d, 3), got %s' % (T, trans.shape))
+        d = dict(src)
+        d.update(pose=pose, shape=shape[:10], root_trans=trans)
+        for k in ('pose', 'shape', 'root_trans'):
+            if not np.all(np.isfinite(d[k])):
+                _fail(pid, 'ground-truth %s contains non-finite values' % k)
+        out[pid] = d
+    return out, dict(gt_dict.get('meta', {}))

@@ -227,3 +227,24 @@ def test_sequence_longer_than_a_workgroup(make_model, asset_root):
     assert kp_err(init['person_data'][0]['kp_2d_pred'], ref_init, vis) < 5e-2
     assert kp_err(out['person_data'][0]['kp_2d_pred'], data['person_data'][0]['kp_2d_pred'].detach().numpy(), vis) < 0.5
     assert np.abs(out['person_data'][0]['root_trans_world'] - data['person_data'][0]['root_trans_world'].detach().numpy()).max() < 1e-2
+
+
+def test_run_dataset_reconstructs_and_evaluates(asset_root, tmp_path, monkeypatch):
+    """pose.pkl + ground-truth pickle per sequence -> result pickles + the metric line (run_dataset.py:60-120), two seeds, one batch."""
+    import pickle
+    from glamr_amd.global_recon import run_dataset
+    md = synth.make_smpl_model()
+    if not os.path.exists(os.path.join(asset_root, 'data', 'J_regressor_h36m.npy')):
+        np.save(os.path.join(asset_root, 'data', 'J_regressor_h36m.npy'), synth.make_h36m_regressor(md))
+    out_dir, gt_dir = tmp_path / 'out', tmp_path / 'gt'
+    os.makedirs(gt_dir)
+    for seq, seed, T in (('a', 31, 90), ('b', 32, 110)):
+        d = synth.make_in_dict(seed=seed, num_frames=T, num_persons=1, smpl_model=md, with_gt=True)
+        os.makedirs(out_dir / seq / 'pose_est')
+        pickle.dump(d['est'], open(out_dir / seq / 'pose_est' / 'pose.pkl', 'wb'))
+        pickle.dump({'person_data': d['gt'], 'meta': {}}, open(gt_dir / (seq + '.pkl'), 'wb'))
+    monkeypatch.chdir(asset_root)
+    line = run_dataset.main(['--cfg', 'glamr_static', '--dataset', '', '--seqs', 'a', 'b', '--out_dir', str(out_dir), '--gt_dir', str(gt_dir), '--seeds', '1', '2'])
+    assert 'G-MPJPE' in line and 'PA-MPJPE-invis' in line and 'sample_PA-MPJPE-invis' in line
+    out = pickle.load(open(out_dir / 'b' / 'grecon' / 'b_seed2.pkl', 'rb'))
+    assert out['seq_len'] == 110 and out['gt'][0]['pose'].shape == (110, 72)

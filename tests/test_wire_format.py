@@ -54,3 +54,14 @@ def test_pose_pkl_round_trip(est, tmp_path):
         pickle.dump(est, f)
     in_dict = wire.load_pose_pkl(str(d / 'pose.pkl'), seq_name='walk_01')
     assert in_dict['seq_name'] == 'walk_01' and in_dict['gt'] == {} and set(in_dict['est']) == {0, 1}
+
+
+def test_ground_truth_pickle_contract():
+    in_dict = synth.make_in_dict(seed=6, num_frames=80, num_persons=2, smpl_model=synth.make_smpl_model(), with_gt=True)
+    gt, meta = wire.normalise_gt({'person_data': in_dict['gt'], 'meta': {'cam_K': np.eye(3)}}, num_frames=80)
+    assert set(gt) == {0, 1} and gt[0]['pose'].shape == (80, 72) and gt[0]['shape'].shape == (10,) and 'cam_K' in meta
+    bad = {'person_data': {0: dict(in_dict['gt'][0], pose=in_dict['gt'][0]['pose'][:, :69])}}
+    with pytest.raises(wire.WireFormatError, match='72'):
+        wire.normalise_gt(bad)
+    with pytest.raises(wire.WireFormatError, match='covers 80 frames'):
+        wire.normalise_gt({'person_data': in_dict['gt']}, num_frames=81)
