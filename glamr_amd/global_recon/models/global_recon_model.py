@@ -490,10 +490,10 @@ class GlobalReconOptimizer:
         _lib.check(_lib.lib().glamr_grecon_last_launch_ns(_lib.ptr(ws), ctypes.byref(ns)))
         return ns.value * 1e-6
 
-    def run_schedule(self, packed, max_iters=None):
+    def run_schedule(self, packed, max_iters=None, has_wd=False):
         """The staged optimisation (:250-262) of an initialised batch: one kernel launch per stage, asynchronous on the current
-        stream.  `max_iters` caps the iterations of every stage (tests); None = the configured schedule."""
-        has_wd = False
+        stream.  `max_iters` caps the iterations of every stage (tests); None = the configured schedule.  `has_wd`: the scenes already
+        carry a world heading offset (a continued optimisation, :459-465 applies it whenever the variable exists)."""
         events = []
         for stage, spec in self.opt_stage_specs.items():
             sd = packing.stage_desc(spec, self.specs, has_world_dheading=has_wd,
@@ -556,5 +556,25 @@ class GlobalReconOptimizer:
 
     def optimize(self, in_dict, continue_opt=False, latents=None, max_iters=None):
         if continue_opt:
-            raise NotImplementedError('continue_opt=True (restart from a previous data dict) is not implemented')
+            return self.continue_batch([in_dict], max_iters)[0]
         return self.optimize_batch([in_dict], None if latents is None else [latents], max_iters)[0]
+
+    def continue_batch(self, datas, max_iters=None):
+        """optimize(in_dict, continue_opt=True) (:572-573): `in_dict` is the dictionary a previous optimize() returned; the schedule
+        runs again from its variables.  The inputs are not modified."""
+        import copy
+        datas = [dict(d, person_data={i: dict(pd) for i, pd in d['person_data'].items()}) for d in datas]
+        j_locals = []
+        for d in datas:
+            jl = {}
+            for idx, pd in d['person_data'].items():
+                pose = torch.as_tensor(np.asarray(pd['smpl_pose']), dtype=torch.float32, device=self.device)
+                beta = torch.as_tensor(np.asarray(pd['smpl_beta']), dtype=torch.float32, device=self.device)
+                z = torch.zeros(pose.shape[0], 3, device=self.device)
+                with torch.no_grad():
+                    jl[idx] = self.smpl(global_orient=z, body_pose=pose, betas=beta, root_trans=z, return_verts=False).joints.cpu()
+            j_locals.append(jl)
+        packed = packing.PackedScenes(datas, j_locals, self.device, self.cam_fix_frames)
+        has_wd = any('world_dheading' in pd for d in datas for pd in d['person_data'].values())
+        self.run_schedule(packed, max_iters, has_wd=has_wd)
+        return self.collect(datas, packed)

@@ -248,3 +248,29 @@ def test_run_dataset_reconstructs_and_evaluates(asset_root, tmp_path, monkeypatc
     assert 'G-MPJPE' in line and 'PA-MPJPE-invis' in line and 'sample_PA-MPJPE-invis' in line
     out = pickle.load(open(out_dir / 'b' / 'grecon' / 'b_seed2.pkl', 'rb'))
     assert out['seq_len'] == 110 and out['gt'][0]['pose'].shape == (110, 72)
+
+
+def test_continue_opt_restarts_from_a_previous_result(make_model, asset_root):
+    """optimize(out, continue_opt=True) (global_recon_model.py:572-573): the schedule runs again from the variables of a previous
+    result.  Device path vs the CPU restatement continuing from the SAME dictionary."""
+    import copy
+    from oracle.port import build
+    from oracle.port.grecon import to_torch
+    from glamr_amd.global_recon.configs import get_config
+    cfg = get_config('glamr_dynamic')
+    in_dict = synth.make_in_dict(seed=13, num_frames=80, num_persons=1, smpl_model=synth.make_smpl_model())
+    model = make_model('glamr_dynamic')
+    first = model.optimize(in_dict, latents=mg.latents_for(in_dict, 13), max_iters=4)
+    K = 3
+    again = model.optimize(copy.deepcopy(first), continue_opt=True, max_iters=K)
+    ora = build.load_optimizer(asset_root, cfg)
+    data = to_torch(copy.deepcopy(first), torch.device('cpu'))
+    for stage, spec in cfg['opt_stage_specs'].items():
+        ora.optimize_main(data, spec['opt_variables'], spec['opt_lr'], min(K, spec['opt_niters']), spec['loss_cfg'], {'stage': stage})
+    vis = np.asarray(again['person_data'][0]['vis_frames'])
+    ref_kp = data['person_data'][0]['kp_2d_pred'].detach().numpy()
+    assert kp_err(again['person_data'][0]['kp_2d_pred'], ref_kp, vis) < 0.5
+    assert np.abs(again['person_data'][0]['root_trans_world'] - data['person_data'][0]['root_trans_world'].detach().numpy()).max() < 1e-2
+    # it did move away from where it started, and the input dictionary was left alone
+    assert np.abs(again['person_data'][0]['traj_local_rot'] - first['person_data'][0]['traj_local_rot']).max() > 1e-4
+    assert 'world_dheading' in again['person_data'][0]
