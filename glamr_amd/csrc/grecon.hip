@@ -103,8 +103,27 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   ka.grads_out = grads_out;
   int threads = (batch->max_len + 63) / 64 * 64;
   if (threads > MAX_THREADS) threads = MAX_THREADS;
+  if (const char* e = std::getenv("GLAMR_GRECON_THREADS_RT")) {      // development aid: fewer threads than frames = several passes per thread
+    const int cap = std::atoi(e);
+    if (cap >= 64 && cap < threads) threads = cap / 64 * 64;
+  }
   // on-chip arena: prefix-sum / neighbour-exchange arrays first, then as much of the compact keypoint table as fits
-  constexpr size_t LDS_BUDGET = GLAMR_GRECON_LDS_KB * 1024;
+  constexpr size_t LDS_MAX = GLAMR_GRECON_LDS_KB * 1024;
+  size_t LDS_BUDGET = LDS_MAX;
+  // Occupancy: a workgroup's waves hold 256 registers each, so a CU (4 SIMDs x 512) takes 8 / waves workgroups -- if their arenas fit its
+  // 160 KB together.  When the batch has more scenes than the chip has CUs, the arena is capped at that share (the keypoint table
+  // overflows into the workspace): 1024 scenes of 256 frames 40.1 -> 27.5 ms per 500 iterations.  A 300-frame scene has 5 waves: one per CU.
+  static const int n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int wgs_per_cu = 8 / (threads / 64);
+  const size_t full_arena = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
+  if (wgs_per_cu > 1 && batch->n_scenes > n_cus) {
+    const size_t share = (size_t)160 * 1024 / wgs_per_cu - 6 * 1024;      // 5.7 KB of static LDS per workgroup
+    if (full_arena <= share) LDS_BUDGET = share;
+  }
+  if (const char* e = std::getenv("GLAMR_GRECON_LDS_KB_RT")) {      // development aid (tools/overlap_probe.py)
+    const size_t v = (size_t)std::atoi(e) * 1024;
+    LDS_BUDGET = v < 16384 ? (size_t)16384 : (v > LDS_MAX ? LDS_MAX : v);
+  }
   const size_t full = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
   const size_t lite = scene_fast_floats(batch->max_persons, batch->max_len, 2) * sizeof(float);
   ka.use_lds = full <= LDS_BUDGET ? 1 : (lite <= LDS_BUDGET ? 2 : 0);              // 1 full arena, 2 lite arena, 0 everything in the workspace
@@ -115,7 +134,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // SINGLE needs every scene of the batch to hold exactly one person: max_persons == 1 guarantees it
   const bool single = batch->max_persons == 1;
   auto launch = [&](auto kern, size_t lds) -> int {
-    if (lds) GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    if (lds) GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     hipLaunchKernelGGL(kern, dim3(batch->n_scenes), dim3(threads), lds, stream, ka);
     return GLAMR_OK;
   };

@@ -447,7 +447,8 @@ inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, 
     // tall activations: the split-bf16 kernel (small M is launch / latency bound either way)
     a.Ws = Ws;
     a.ws_plane = (size_t)npad * K;
-    if (npad % 128 == 0 && (size_t)(M / 128) * (npad / 128) >= 512)
+    const bool narrow_only = std::getenv("GLAMR_GEMM_NARROW") != nullptr;      // development aid: 128x64 tiles only (116 registers)
+    if (!narrow_only && npad % 128 == 0 && (size_t)(M / 128) * (npad / 128) >= 512)
       hipLaunchKernelGGL((gemm_split_kernel<2>), dim3(npad / 128, (M + 127) / 128), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((gemm_split_kernel<1>), dim3(npad / 64, (M + 127) / 128), dim3(256), 0, st, a);

@@ -205,6 +205,30 @@ def test_ragged_batch_equals_single_runs(make_model):
             assert a['smpl_pose'].shape == (T, 69)
 
 
+def test_shared_cu_arena_gives_the_same_values(make_model, monkeypatch):
+    """More scenes than CUs and sequences of <= 256 frames: the optimiser caps its LDS arena so that several workgroups share a CU
+    (part of the keypoint table then lives in the workspace).  Where an array lives must not change a single bit: the same batch is
+    run with the occupancy policy, with the full 150 KB arena forced and with the arena squeezed below the keypoint table."""
+    md = synth.make_smpl_model()
+    T, n, K = 120, 288, 6
+    in_dicts = [synth.make_in_dict(seed=40 + (i % 6), num_frames=T, num_persons=1, smpl_model=md) for i in range(n)]
+    lats = [mg.latents_for(in_dicts[i], 40 + (i % 6)) for i in range(n)]
+    model = make_model('glamr_dynamic')
+    policy = model.optimize_batch(in_dicts, lats, max_iters=K)
+    monkeypatch.setenv('GLAMR_GRECON_LDS_KB_RT', '150')
+    full = model.optimize_batch(in_dicts, lats, max_iters=K)
+    monkeypatch.setenv('GLAMR_GRECON_LDS_KB_RT', '26')
+    tiny = model.optimize_batch(in_dicts, lats, max_iters=K)
+    for i in (0, 5, 6, 100, 287):
+        for other in (full, tiny):
+            a, b = policy[i]['person_data'][0], other[i]['person_data'][0]
+            for key in ('kp_2d_pred', 'root_trans_world', 'smpl_orient_world'):
+                assert np.array_equal(a[key], b[key]), (i, key)
+            assert np.array_equal(policy[i]['cam_pose'], other[i]['cam_pose'])
+        # identical inputs in different slots of the batch give identical results
+        assert np.array_equal(policy[i]['person_data'][0]['kp_2d_pred'], policy[i % 6]['person_data'][0]['kp_2d_pred'])
+
+
 def test_sequence_longer_than_a_workgroup(make_model, asset_root):
     """700 frames: the optimiser workgroup has 512 threads, so every frame loop makes two passes and the prefix sums run in two chunks;
     24 infiller windows.  Device path vs the CPU restatement on init_data and after 3 iterations of the stage."""
