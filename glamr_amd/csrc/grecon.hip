@@ -110,11 +110,15 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // on-chip arena: prefix-sum / neighbour-exchange arrays first, then as much of the compact keypoint table as fits
   constexpr size_t LDS_MAX = GLAMR_GRECON_LDS_KB * 1024;
   size_t LDS_BUDGET = LDS_MAX;
-  // Occupancy: a workgroup's waves hold 256 registers each, so a CU (4 SIMDs x 512) takes 8 / waves workgroups -- if their arenas fit its
+  // Occupancy: a workgroup's waves hold 256 registers each, so a CU (4 SIMDs x 512 registers) takes 8 / waves workgroups -- if their arenas fit its
   // 160 KB together.  When the batch has more scenes than the chip has CUs, the arena is capped at that share (the keypoint table
   // overflows into the workspace): 1024 scenes of 256 frames 40.1 -> 27.5 ms per 500 iterations.  A 300-frame scene has 5 waves: one per CU.
-  static const int n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-  const int wgs_per_cu = 8 / (threads / 64);
+  static const int n_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int wgs_per_cu = 4 * GLAMR_GRECON_WAVES_PER_EU / (threads / 64);
   const size_t full_arena = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
   if (wgs_per_cu > 1 && batch->n_scenes > n_cus) {
     const size_t share = (size_t)160 * 1024 / wgs_per_cu - 6 * 1024;      // 5.7 KB of static LDS per workgroup
