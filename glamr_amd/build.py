@@ -12,7 +12,10 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # per-file flags.  grecon.hip: `/` and sqrtf as v_rcp / v_sqrt (+1 Newton step) instead of the correctly rounded ~10-instruction
 # sequences -- the optimiser divides ~60 times per frame and iteration; results move in the last 1-2 ulp
-FILE_FLAGS = {'grecon.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt']}
+# grecon.hip: approximate (2.5 ulp) division / sqrt for the few `/` left outside rotmath's rcp_/sqrt_; no SLP vectorisation -- packing
+# pairs of fp32 operations (v_pk_fma_f32) costs as many register moves as it saves instructions and 36 more spilled registers
+# (stage launch 42.3 -> 39.2 ms at 1024 scenes)
+FILE_FLAGS = {'grecon.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize']}
 EXTRA_FLAGS = {k: v.split() for k, v in (kv.split('=', 1) for kv in os.environ.get('GLAMR_EXTRA_FLAGS', '').split(';') if kv)}
 
 

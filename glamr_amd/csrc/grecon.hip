@@ -81,6 +81,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   GLAMR_REQUIRE(batch->n_scenes > 0 && batch->max_persons >= 1 && batch->max_persons <= 8 && batch->max_len >= 2,
                 "bad batch geometry: n_scenes=%d max_persons=%d max_len=%d", batch->n_scenes, batch->max_persons, batch->max_len);
   GLAMR_REQUIRE(batch->n_joints == NJ, "n_joints must be %d", NJ);
+  GLAMR_REQUIRE(batch->max_len <= GLAMR_GRECON_MAX_FRAMES, "max_len=%d exceeds %d frames", batch->max_len, GLAMR_GRECON_MAX_FRAMES);
   GLAMR_REQUIRE(batch->n_persons && batch->seq_len && batch->fr_start && batch->fr_end && batch->vis && batch->j_local && batch->kp_2d &&
                     batch->kp_score && batch->cam_K && batch->traj_local_pred && batch->orient_cam && batch->base_orient &&
                     batch->base_trans && batch->person2cam && batch->cam_pose && batch->params && batch->losses && batch->orient_world &&
@@ -122,7 +123,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   const size_t full_arena = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
   if (wgs_per_cu > 1 && batch->n_scenes > n_cus) {
     const size_t share = (size_t)160 * 1024 / wgs_per_cu - 6 * 1024;      // 5.7 KB of static LDS per workgroup
-    if (full_arena <= share) LDS_BUDGET = share;
+    if (full_arena <= share && batch->max_len <= threads) LDS_BUDGET = share;
   }
   if (const char* e = std::getenv("GLAMR_GRECON_LDS_KB_RT")) {      // development aid (tools/overlap_probe.py)
     const size_t v = (size_t)std::atoi(e) * 1024;
@@ -130,7 +131,8 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   }
   const size_t full = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
   const size_t lite = scene_fast_floats(batch->max_persons, batch->max_len, 2) * sizeof(float);
-  ka.use_lds = full <= LDS_BUDGET ? 1 : (lite <= LDS_BUDGET ? 2 : 0);              // 1 full arena, 2 lite arena, 0 everything in the workspace
+  // 1 full arena (single-pass instances: needs a thread per frame), 2 lite arena, 0 everything in the workspace
+  ka.use_lds = (full <= LDS_BUDGET && batch->max_len <= threads) ? 1 : (lite <= LDS_BUDGET ? 2 : 0);
   const size_t base = ka.use_lds == 1 ? full : lite;
   const size_t want = base + (size_t)NJ * 6 * batch->max_persons * batch->max_len * sizeof(float);
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;

@@ -138,6 +138,18 @@ template <int FAST, class T> inline T* fastp(T* p) { return p; }
 template <int FAST, class T> inline T* fastp2(T* p) { return p; }
 #endif
 
+// Frame-loop condition.  The device build also tells the compiler that a frame index is a small non-negative number (the launcher
+// rejects sequences longer than GLAMR_GRECON_MAX_FRAMES): `base[t * 6 + k]` then compiles to a global access with the SCALAR base and
+// one 32-bit lane offset instead of a 64-bit address pair per array (v_ashrrev + v_lshl_add_u64 and two registers each).
+constexpr int GLAMR_GRECON_MAX_FRAMES = 32768;
+GLAMR_HD bool frame_in(int t, int T) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_assume(t >= 0);
+  __builtin_assume(T <= GLAMR_GRECON_MAX_FRAMES);
+#endif
+  return t < T;
+}
+
 struct PersonView {      // what the iteration loop needs of PersonConst + PersonState, uniform
   int fr_start, fr_end, njc, njc_fast;
   const float *vis, *j_local, *kp_2d, *kp_score, *cam_K, *prior, *base_orient, *base_trans, *person2cam, *dheading_mask, *h_prior, *oc6, *kp_wsum;
@@ -180,16 +192,16 @@ GLAMR_HD SceneView scene_view(const Scene& sc) {
 // ---- small helpers ---------------------------------------------------------------------------------------------------
 
 GLAMR_HD float gmof(float x, float sigma2) { return sigma2 * x * x / (sigma2 + x * x); }
-GLAMR_HD float gmof_d(float x, float sigma2) { const float d = sigma2 + x * x; return 2.0f * sigma2 * sigma2 * x / (d * d); }
+GLAMR_HD float gmof_d(float x, float sigma2) { const float r = rm::rcp_(sigma2 + x * x); return 2.0f * sigma2 * sigma2 * x * r * r; }
 
-struct AdamCoef { float lr_t; float bc2_sqrt; };   // lr / (1 - beta1^t),  sqrt(1 - beta2^t)
+struct AdamCoef { float lr_t; float inv_bc2_sqrt; };   // lr / (1 - beta1^t),  1 / sqrt(1 - beta2^t)
 
 // torch.optim.Adam single-tensor update (betas 0.9/0.999, eps 1e-8, no weight decay)
 GLAMR_HD void adam(float& p, float& m, float& v, float g, const AdamCoef& c) {
   m = m + (g - m) * (1.0f - 0.9f);
   v = v * 0.999f + (1.0f - 0.999f) * g * g;
-  const float denom = sqrtf(v) / c.bc2_sqrt + 1e-8f;
-  p = p - c.lr_t * (m / denom);
+  const float denom = rm::sqrt_(v) * c.inv_bc2_sqrt + 1e-8f;
+  p = p - c.lr_t * (m * rm::rcp_(denom));
 }
 
 GLAMR_HD void invert34(const float M[12], float O[12]) {       // [R|t] -> [R^T | -R^T t]   (inverse_transform)
@@ -412,13 +424,13 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
 template <class RT>
 GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
   const int T = sc.T, P = sc.P;
-  for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+  for (int t = rt.tid(); frame_in(t, T); t += rt.nthreads()) {
     int n = 0;
     for (int p = 0; p < P; ++p) n += sc.pc[p].vis[t] != 0.f ? 1 : 0;
     sc.n_vis_persons[t] = n;
   }
   for (int p = 0; p < P; ++p)
-    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    for (int t = rt.tid(); frame_in(t, T); t += rt.nthreads()) {
       int r = -1;
       if (sc.pc[p].vis[t] != 0.f) { r = 0; for (int u = 0; u < t; ++u) r += sc.pc[p].vis[u] != 0.f ? 1 : 0; }
       sc.pc[p].vis_rank[t] = r;
@@ -430,7 +442,7 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
     sc.pair_first[a * 8 + b] = first;
   }
   rt.sync();
-  for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+  for (int t = rt.tid(); frame_in(t, T); t += rt.nthreads()) {
     int src = t;
     while (src >= 0 && sc.n_vis_persons[src] == 0) --src;
     if (src < 0) { src = 0; while (src < T - 1 && sc.n_vis_persons[src] == 0) ++src; }
@@ -507,6 +519,10 @@ inline int camera_mode(const glamr_stage_desc& st) {
 
 template <int FAST, bool SINGLE, int CAM, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
+  // Frame loops of the full-arena instances make ONE pass (the launcher only selects them when every frame has its own thread): with
+  // a step the compiler can see is larger than any sequence the loop is an `if`, and no per-array 64-bit induction pointers stay
+  // live across the whole body (two registers each, a few dozen arrays).
+  const int fstep = FAST == 1 ? (1 << 20) : rt.nthreads();
   const int T = sc.T, P = SINGLE ? 1 : sc.P;
   const bool var_cam = CAM != 0 ? true : (bool)(st.var_mask & GLAMR_VAR_CAM);
   const bool fixed_cam = CAM == 2 ? true : (CAM == 1 ? false : (bool)(st.flags & GLAMR_FLAG_FIXED_CAM));
@@ -521,7 +537,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   float n_vis_total = 0.f, n_exist = 0.f, n_exist_m1 = 0.f;
   for (int p = 0; p < P; ++p) {
     float c = 0.f;
-    for (int t = rt.tid(); t < T; t += rt.nthreads()) c += sc.pc[p].vis[t];
+    for (int t = rt.tid(); frame_in(t, T); t += fstep) c += sc.pc[p].vis[t];
     n_vis_total += rt.reduce_sum(c);
     const int n = sc.pc[p].fr_end - sc.pc[p].fr_start;
     n_exist += (float)n;
@@ -542,7 +558,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     }
   }
   for (int p = 0; p < P; ++p)
-    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    for (int t = rt.tid(); frame_in(t, T); t += fstep) {
       const PersonConst& c = sc.pc[p];
       if (t < c.fr_end - c.fr_start) sc.ps[p].h_prior[t] = rm::atan2s(c.prior[(size_t)t * 11 + 10], c.prior[(size_t)t * 11 + 9]);
       float Rb[9];
@@ -553,7 +569,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   for (int p = 0; p < P; ++p)
     for (int j = 0; j < NJ; ++j) {
       float c = 0.f;
-      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      for (int t = rt.tid(); frame_in(t, T); t += fstep) {
         const float sj = sc.pc[p].kp_score[(size_t)t * NJ + j];
         if (sc.pc[p].vis[t] != 0.f && sj >= st.kp_min_conf) c += sj * sj;
       }
@@ -580,7 +596,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const PersonConst& c = sc.pc[p];
     PersonState& s = sc.ps[p];
     const bool kp_first = ffo(GLAMR_LOSS_KP_2D);
-    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    for (int t = rt.tid(); frame_in(t, T); t += fstep) {
       const bool kp_frame = c.vis[t] != 0.f && (!kp_first || c.vis_rank[t] == 0);
       const float rank_w = (c.vis_rank[t] >= 0 && c.vis_rank[t] < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
       for (int jj = 0; jj < s.njc; ++jj) {
@@ -613,7 +629,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     b1p *= 0.9; b2p *= 0.999;
     AdamCoef ac;
     ac.lr_t = (float)((double)st.lr / (1.0 - b1p));
-    ac.bc2_sqrt = (float)sqrt(1.0 - b2p);
+    ac.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2p));
     float lsum[GLAMR_NUM_LOSSES];
     for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) lsum[i] = 0.f;
     float kp_dist_cnt = 0.f;
@@ -621,7 +637,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
 
     // ---- A: heading increments (arrays are indexed by VIDEO frame t and zero outside the person's existing range, so the
     //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
-    for (int t = rt.tid(); t < T; t += rt.nthreads())
+    for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         const PersonView c = person_view<FAST>(sc, p);
         float v = 0.f;
@@ -639,7 +655,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false);
     }
     // own element of the prefix sum is final: its cos / sin serve phases B, C and I (this frame's and the next frame's)
-    for (int t = rt.tid(); t < T; t += rt.nthreads())
+    for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         float sn, cs;
         rm::sincos_(person_view<FAST>(sc, p).theta[t], sn, cs);
@@ -649,7 +665,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     rt.sync();
     GLAMR_MARK(rt, 0);
     // ---- B: planar displacement in world axes -------------------------------------------------------------------------
-    for (int t = rt.tid(); t < T; t += rt.nthreads())
+    for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         const PersonView c = person_view<FAST>(sc, p);
         float dx = 0.f, dy = 0.f;
@@ -673,7 +689,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     }
     GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
-    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    for (int t = rt.tid(); frame_in(t, T); t += fstep) {
       for (int p = 0; p < P; ++p) {
         const PersonView c = person_view<FAST>(sc, p);
         const PersonView& s = c;
@@ -730,7 +746,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     rt.sync();
     GLAMR_MARK(rt, 2);
     if (cam_from_person) {
-      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      for (int t = rt.tid(); frame_in(t, T); t += fstep) {
         float M[12], Mi[12];
         const int src = sh.fill_src[t];
         float avg[12];
@@ -775,7 +791,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
 
     float gfix[9];
     for (int k = 0; k < 9; ++k) gfix[k] = 0.f;
-    for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+    for (int t = rt.tid(); frame_in(t, T); t += fstep) {
       float gC[12], gCi[12];
       for (int k = 0; k < 12; ++k) { gC[k] = 0.f; gCi[k] = 0.f; }
       // everything this frame needs from the workspace is requested up front
@@ -852,7 +868,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             const float hx = H[0] * jl[0] + H[1] * jl[1] + H[2] * jl[2] + q[0];
             const float hy = H[3] * jl[0] + H[4] * jl[1] + H[5] * jl[2] + q[1];
             const float hz = H[6] * jl[0] + H[7] * jl[1] + H[8] * jl[2] + q[2] + 1e-8f;
-            const float u = hx / hz, v = hy / hz;
+            const float ihz = rm::rcp_(hz);
+            const float u = hx * ihz, v = hy * ihz;
             const float du = u - kx, dv = v - ky;
             if (jout >= 0) {
               s.kp_2d_pred[((size_t)t * NJ + jout) * 2 + 0] = u;
@@ -866,7 +883,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             if (last) lsum[GLAMR_LOSS_KP_2D] += (gmof(du, 1e4f) + gmof(dv, 1e4f)) * wj;
             if (w_kp == 0.f) return;
             const float gu = gmof_d(du, 1e4f) * wj * w_kp, gv = gmof_d(dv, 1e4f) * wj * w_kp;
-            const float gh[3] = {gu / hz, gv / hz, -(gu * u + gv * v) / hz};             // u = hx / hz, v = hy / hz
+            const float gh[3] = {gu * ihz, gv * ihz, -(gu * u + gv * v) * ihz};          // u = hx / hz, v = hy / hz
             for (int i = 0; i < 3; ++i) {
               for (int k = 0; k < 3; ++k) gH[i * 3 + k] += gh[i] * jl[k];
               gq[i] += gh[i];
@@ -989,7 +1006,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     // relative transform between persons on co-visible frames (loss_func.py:248-271), in a loop of its own: its ~100 live values
     // are then not allocated alongside the keypoint / camera terms above.  Own frame only -> no barrier; the fold is linear.
     if (!SINGLE && on(GLAMR_LOSS_REL_TRANSFORM) && P > 1)
-      for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
           const PersonView s = person_view<FAST>(sc, p);
           if (s.vis[t] == 0.f) continue;
@@ -1012,7 +1029,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     } else if (update && cam_from_person) {
       // ---- G (camera derived from the persons): gradient of every frame's averaged transform, folded onto its source frame ----
       rt.sync();
-      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      for (int t = rt.tid(); frame_in(t, T); t += fstep) {
         float gMi[12];
         for (int k = 0; k < 12; ++k) gMi[k] = sh.g_caminv[(size_t)t * 12 + k];
         invert34_bwd(sh.cam_inv + (size_t)t * 12, sh.g_cam + (size_t)t * 12, gMi);     // cam_pose = invert(cam_inv)
@@ -1049,7 +1066,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], g6[k], ac); }
       }
       rt.sync();
-      for (int t = rt.tid(); t < T; t += rt.nthreads()) {
+      for (int t = rt.tid(); frame_in(t, T); t += fstep) {
         if (sh.n_vis_persons[t] == 0) continue;                 // only frames with persons are sources
         float ga[12];
         for (int k = 0; k < 12; ++k) ga[k] = 0.f;
@@ -1077,7 +1094,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     } else if (update && !var_cam && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
       // camera neither optimised nor derived from the persons: the residual only feels its own regulariser
       const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
-      for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int k = 0; k < 3; ++k) {
           const int i = l.cam_inv_trans_res + t * 3 + k;
           const float g = 2.0f * FPS * FPS * sh.cp[i] * wreg;
@@ -1091,7 +1108,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const float w_z = active(GLAMR_LOSS_LOCAL_Z_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_Z_REG] / n_exist : 0.f;
     const float w_dxy = active(GLAMR_LOSS_LOCAL_DXY_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_DXY_REG] / n_exist_m1 : 0.f;
     const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
-    for (int t = rt.tid(); t < T; t += rt.nthreads())
+    for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         const PersonView c = person_view<FAST>(sc, p);
         const PersonView& s = c;
@@ -1154,7 +1171,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       rt.sync();
       GLAMR_MARK(rt, 6);
       // ---- I: reverse of B ----------------------------------------------------------------------------------------------
-      for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
           const PersonView c = person_view<FAST>(sc, p);
           const PersonView& s = c;
@@ -1197,7 +1214,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       }
       GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
-      for (int t = rt.tid(); t < T; t += rt.nthreads())
+      for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
           const PersonView c = person_view<FAST>(sc, p);
           const PersonView& s = c;

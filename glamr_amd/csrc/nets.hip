@@ -22,7 +22,7 @@ using namespace glamr::nn;
 
 namespace {
 
-constexpr int D = 256, FF = 512, NZ = 128, WIN = 50, PAST = 10, CUR = 30, FUT = 10, XLD = 96;
+constexpr int D = 256, FF = 512, NZ = 128, WIN = 50, PAST = 10, CUR = 30, XLD = 96;
 
 struct Lin { float* W = nullptr; float* b = nullptr; int N = 0, K = 0; unsigned short* Ws = nullptr; };   // W: [Npad][K]; Ws: its three bf16 planes
 struct LN { float* g = nullptr; float* b = nullptr; };

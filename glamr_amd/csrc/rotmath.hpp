@@ -22,6 +22,18 @@
 namespace glamr {
 namespace rm {
 
+// Reciprocal and square root as ONE hardware instruction (v_rcp_f32 / v_sqrt_f32, 1 ulp).  A plain `a / b` costs eight instructions
+// on gfx950 even with approximate division enabled (frexp / ldexp range scaffolding for denormal operands); every denominator of this
+// file and of the optimiser is a clamped norm, a depth, (sigma^2 + x^2) or sqrt(v) + 1e-8: normal-range numbers.  The CPU test
+// runtime (tests/hostsim) keeps the exact operations.
+#if defined(__HIP_DEVICE_COMPILE__)
+GLAMR_HD float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+GLAMR_HD float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+GLAMR_HD float rcp_(float x) { return 1.0f / x; }
+GLAMR_HD float sqrt_(float x) { return sqrtf(x); }
+#endif
+
 // sine and cosine of the same angle (kept as two calls: the device sincosf writes through pointers and measured slower)
 GLAMR_HD void sincos_(float x, float& s, float& c) {
   s = sinf(x);
@@ -37,39 +49,41 @@ GLAMR_HD float atan2s(float y, float x, float eps = 1e-6f) {
 }
 GLAMR_HD void atan2s_bwd(float y, float x, float g, float& gy, float& gx, float eps = 1e-6f) {
   if (fabsf(y) < eps && fabsf(x) < eps) y += eps;
-  const float d = x * x + y * y;
-  gy += g * x / d;
-  gx += -g * y / d;
+  const float r = rcp_(x * x + y * y);
+  gy += g * x * r;
+  gx += -g * y * r;
 }
 
 // safe_zero_division: den += eps where |den| < eps
 GLAMR_HD float sdiv(float num, float den, float eps = 1e-6f) {
   if (fabsf(den) < eps) den += eps;
-  return num / den;
+  return num * rcp_(den);
 }
 GLAMR_HD void sdiv_bwd(float num, float den, float g, float& gnum, float& gden, float eps = 1e-6f) {
   if (fabsf(den) < eps) den += eps;
-  gnum += g / den;
-  gden += -g * num / (den * den);
+  const float r = rcp_(den);
+  gnum += g * r;
+  gden += -g * num * r * r;
 }
 
 // sqrt(clamp_min(a, eps)); torch's clamp passes the gradient where a >= eps
-GLAMR_HD float sqrt_clamped(float a, float eps) { return sqrtf(fmaxf(a, eps)); }
-GLAMR_HD float sqrt_clamped_bwd(float a, float eps, float g) { return (a >= eps) ? g / (2.0f * sqrtf(a)) : 0.0f; }
+GLAMR_HD float sqrt_clamped(float a, float eps) { return sqrt_(fmaxf(a, eps)); }
+GLAMR_HD float sqrt_clamped_bwd(float a, float eps, float g) { return (a >= eps) ? g * 0.5f * rcp_(sqrt_(a)) : 0.0f; }
 
 // normalize(): x / clamp(||x||, min=eps)   (lib/utils/torch_transform.py:6-7)
 GLAMR_HD void normalize3(const float x[3], float out[3], float eps = 1e-9f) {
-  const float n = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-  const float d = fmaxf(n, eps);
-  out[0] = x[0] / d; out[1] = x[1] / d; out[2] = x[2] / d;
+  const float n = sqrt_(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  const float r = rcp_(fmaxf(n, eps));
+  out[0] = x[0] * r; out[1] = x[1] * r; out[2] = x[2] * r;
 }
 GLAMR_HD void normalize3_bwd(const float x[3], const float g[3], float gx[3], float eps = 1e-9f) {
-  const float n = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-  const float d = fmaxf(n, eps);
-  float gd = -(g[0] * x[0] + g[1] * x[1] + g[2] * x[2]) / (d * d);      // d out / d d
-  for (int i = 0; i < 3; ++i) gx[i] += g[i] / d;
+  const float n = sqrt_(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  const float r = rcp_(fmaxf(n, eps));
+  float gd = -(g[0] * x[0] + g[1] * x[1] + g[2] * x[2]) * r * r;        // d out / d d
+  for (int i = 0; i < 3; ++i) gx[i] += g[i] * r;
   if (n >= eps && n > 0.0f) {                                            // clamp passes, norm backward = x / n (0 at 0)
-    for (int i = 0; i < 3; ++i) gx[i] += gd * x[i] / n;
+    const float rn = gd * rcp_(n);
+    for (int i = 0; i < 3; ++i) gx[i] += rn * x[i];
   }
 }
 

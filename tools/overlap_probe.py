@@ -51,7 +51,9 @@ for cfg in CONFIGS:
         os.environ['GLAMR_GRECON_THREADS_RT'] = str(cfg[3])
     else:
         os.environ.pop('GLAMR_GRECON_THREADS_RT', None)
-    os.environ['GLAMR_GRECON_LDS_KB_RT'] = str(lds)
+    os.environ.pop('GLAMR_GRECON_LDS_KB_RT', None)          # 0 = the launcher's own policy
+    if lds:
+        os.environ['GLAMR_GRECON_LDS_KB_RT'] = str(lds)
     if narrow:
         os.environ['GLAMR_GEMM_NARROW'] = '1'
     else:
