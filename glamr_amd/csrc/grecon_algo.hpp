@@ -1226,9 +1226,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           } else {
             const int i = l.local_dheading + e;
             const float v = s.p[i];
-            if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
+            float sv, cv;
+            rm::sincos_(v, sv, cv);
+            if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cv - 1.0f) * FPS, b = sv * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
             if (!(st.var_mask & GLAMR_VAR_LOCAL_DHEADING)) continue;
-            const float g = (c.dheading_mask ? gh * c.dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cosf(v) - 1.0f) * (-sinf(v)) + sinf(v) * cosf(v)) * w_dh;
+            const float g = (c.dheading_mask ? gh * c.dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cv - 1.0f) * (-sv) + sv * cv) * w_dh;
             if (sh.store_grad) s.g[i] = g;
             adam(s.p[i], s.m[i], s.v[i], g, ac);
           }
@@ -1241,7 +1243,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         const int n = person_view<FAST>(sc, p).fr_end - person_view<FAST>(sc, p).fr_start;
         for (int e = rt.tid() + 1; e < n; e += rt.nthreads()) {
           if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[l.local_dxy + e * 2 + k] * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
-          if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float v = s.p[l.local_dheading + e]; const float a = (cosf(v) - 1.0f) * FPS, b = sinf(v) * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
+          if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { float sv, cv; rm::sincos_(s.p[l.local_dheading + e], sv, cv); const float a = (cv - 1.0f) * FPS, b = sv * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
         }
       }
       // block-reduce and normalise the reported (unweighted) loss values

@@ -34,10 +34,22 @@ GLAMR_HD float rcp_(float x) { return 1.0f / x; }
 GLAMR_HD float sqrt_(float x) { return sqrtf(x); }
 #endif
 
-// sine and cosine of the same angle (kept as two calls: the device sincosf writes through pointers and measured slower)
+// Sine and cosine of the same angle in ~30 instructions: Cody-Waite reduction to [-pi/4, pi/4] (pi/2 split in three floats, the
+// products exact through fma -- good to |x| ~ 1e5, headings are prefix sums of a few hundred wrapped increments) and the cephes
+// single-precision minimax polynomials (1 ulp on the reduced range).  The device library's sinf + cosf carry a Payne-Hanek
+// large-argument path each: about 700 of the 4 600 instructions of an optimiser iteration went there.  Same code on the host runtime.
 GLAMR_HD void sincos_(float x, float& s, float& c) {
-  s = sinf(x);
-  c = cosf(x);
+  const float k = rintf(x * 0.6366197466850281f);
+  float r = fmaf(k, -1.5707963705062866f, x);
+  r = fmaf(k, 4.371138828673793e-08f, r);
+  r = fmaf(k, 1.7151245100058819e-15f, r);
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)k;
+  const float a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;          // quadrant: swap ...
+  s = (q & 2) ? -a : a;                                              // ... and change signs
+  c = ((q + 1) & 2) ? -b : b;
 }
 
 // ---- elementary pieces ---------------------------------------------------------------------------------------------

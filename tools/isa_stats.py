@@ -43,3 +43,20 @@ for k, c in enumerate(segs):
         print('%3d %5d %5d %7d %5d %6d %5d %4d %4d' % ((k,) + r))
     tot = [a + b for a, b in zip(tot, r)]
 print('all %5d %5d %7d %5d %6d %5d %4d %4d' % tuple(tot))
+
+# the iteration loop = the longest backward branch spanning exactly the update-only iteration's barriers (7 for one person)
+lines = [t.strip() for t in s[i:j].split('\n') if t.strip() and t.strip()[0] != ';']
+label_pos = {t.split(':')[0]: k for k, t in enumerate(lines) if re.match(r'^\.LBB\d+_\d+:', t)}
+bar = [k for k, t in enumerate(lines) if t.split()[0] == 's_barrier']
+NB = int(os.environ.get('GLAMR_ISA_LOOP_BARRIERS', '7'))
+best = None
+for k, t in enumerate(lines):
+    op = t.split()[0]
+    if op.startswith('s_cbranch') or op == 's_branch':
+        tgt = t.split()[-1]
+        if tgt in label_pos and label_pos[tgt] < k and sum(1 for b in bar if label_pos[tgt] < b < k) == NB:
+            if best is None or k - label_pos[tgt] > best[1] - best[0]:
+                best = (label_pos[tgt], k)
+if best:
+    c = collections.Counter(t.split()[0] for t in lines[best[0]:best[1]] if not t.startswith('.'))
+    print('iteration loop: %d instructions, %d VALU (static; the joint loop inside runs ~14 times)' % (sum(c.values()), sum(n for o, n in c.items() if o.startswith('v_'))))
