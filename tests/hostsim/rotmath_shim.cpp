@@ -26,3 +26,8 @@ BATCH(t_rotmat_to_aa, 9, 3, rotmat_to_aa(xi, oi), rotmat_to_aa_bwd(xi, go, gi))
 BATCH(t_quat_mul, 8, 4, quat_mul(xi, xi + 4, oi), quat_mul_bwd(xi, xi + 4, go, gi, gi + 4))
 BATCH(t_atan2s, 2, 1, oi[0] = atan2s(xi[0], xi[1]), atan2s_bwd(xi[0], xi[1], go[0], gi[0], gi[1]))
 BATCH(t_normalize3, 3, 3, normalize3(xi, oi), normalize3_bwd(xi, go, gi))
+
+// sine / cosine of the optimiser's heading angles (Cody-Waite + minimax polynomials): out = [sin, cos] per input
+extern "C" void t_sincos(int n, const float* x, float* out) {
+  for (int i = 0; i < n; ++i) sincos_(x[i], out[2 * i], out[2 * i + 1]);
+}

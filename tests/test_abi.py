@@ -53,3 +53,49 @@ def test_product_never_imports_the_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    """Error convention of the boundary (include/glamr_hip.h): a negative GLAMR_E_* code, never an exception or an exit, and a
+    thread-local message.  These checks run before any HIP call, so they hold on a box without a GPU."""
+    from glamr_amd import build, _lib
+    build.build_library()
+    L = _lib.lib()
+    E_INVALID = -1
+    # parameter layout / workspace size
+    lay = _lib.ParamLayout()
+    assert L.glamr_grecon_param_layout(0, 300, ctypes.byref(lay)) == E_INVALID
+    assert L.glamr_grecon_param_layout(9, 300, ctypes.byref(lay)) == E_INVALID
+    assert L.glamr_grecon_param_layout(1, 1, ctypes.byref(lay)) == E_INVALID
+    assert b'max_persons' in L.glamr_last_error()
+    assert L.glamr_grecon_param_layout(1, 300, ctypes.byref(lay)) == 0
+    # the layout holds every variable group of every stage: camera 6T + 3T, camera residuals 6T + 3T, then one block per person
+    assert lay.person0 == 18 * 300 and lay.scene_stride == lay.person0 + lay.person_stride and lay.world_dheading + 300 == lay.person_stride
+    assert L.glamr_grecon_workspace_bytes(0, 1, 300) == 0 and L.glamr_grecon_workspace_bytes(4, 9, 300) == 0
+    assert L.glamr_grecon_workspace_bytes(4, 1, 300) > 4 * 3 * lay.scene_stride * 4      # Adam moments + gradient per scene at least
+    # stage launch: null pointers, bad geometry, missing arrays, too long a sequence
+    sd, sb = _lib.StageDesc(), _lib.SceneBatch()
+    assert L.glamr_grecon_run_stage(None, ctypes.byref(sd), None, None, None) == E_INVALID
+    assert L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, ctypes.c_void_p(16), None) == E_INVALID
+    assert b'bad batch geometry' in L.glamr_last_error()
+    sb.n_scenes, sb.max_persons, sb.max_len, sb.n_joints = 1, 1, 300, 26
+    assert L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, ctypes.c_void_p(16), None) == E_INVALID
+    assert b'NULL' in L.glamr_last_error()
+    for name, _ in _lib.SceneBatch._fields_[4:]:
+        setattr(sb, name, 16)                           # any non-null value: the geometry checks come first
+    sb.n_joints = 25
+    assert L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, ctypes.c_void_p(16), None) == E_INVALID
+    assert b'n_joints' in L.glamr_last_error()
+    sb.n_joints, sb.max_len = 26, 40000
+    assert L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, ctypes.c_void_p(16), None) == E_INVALID
+    assert b'exceeds' in L.glamr_last_error()
+    sb.max_len, sd.niters = 300, -1
+    assert L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, ctypes.c_void_p(16), None) == E_INVALID
+    assert b'niters' in L.glamr_last_error()
+    # the Python wrapper turns the code into an exception carrying the message
+    try:
+        _lib.check(L.glamr_grecon_param_layout(0, 300, ctypes.byref(lay)))
+    except RuntimeError as e:
+        assert 'max_persons' in str(e)
+    else:
+        raise AssertionError('no exception')
