@@ -144,6 +144,73 @@ def gen_nets():
     np.savez_compressed(os.path.join(GOLD, 'nets.npz'), **out)
 
 
+
+def train_inputs(seed=0):
+    """Training-style batches (AMASS layout, amass_dataset.py:65-67): the infiller sees ONE 50-frame window (:478-482 runs on an
+    initialised window), the trajectory predictor a 100-frame clip with root translation and orientation."""
+    rng = np.random.default_rng(777 + seed)
+    def clip(B, T):
+        t = np.arange(T)[None, :, None] / 30.0
+        pose = 0.3 * np.sin(2 * np.pi * rng.uniform(0.2, 0.8, size=(B, 1, 72)) * t + rng.uniform(0, 6.28, size=(B, 1, 72)))
+        pose[..., 0] += np.pi / 2                     # root orientation near the AMASS "z up" convention
+        pose[..., 2] += 0.4 * t[..., 0]               # slow turn
+        return pose.astype(np.float32)
+    win = clip(2, 50)
+    fm = np.ones((2, 50), np.float32)
+    fm[0, 18:33] = 0.0
+    fm[1, 25:] = 0.0
+    pm = np.repeat(fm[..., None], 72, axis=-1)
+    traj = clip(2, 100)
+    tt = np.repeat(np.arange(100)[None, :, None] / 30.0, 2, axis=0)
+    trans = np.concatenate([0.8 * np.sin(0.7 * tt + rng.uniform(0, 3, (2, 1, 1))), 1.1 * tt + 0.1 * np.cos(1.3 * tt), 0.9 + 0.03 * np.sin(5 * tt)], axis=-1).astype(np.float32)
+    # `trans` / `shape` ride along in an AMASS batch; the one-shot inference path slices them (motion_infiller_vae.py:664-666)
+    return dict(infiller=dict(pose=win, pose_mask=pm, frame_mask=fm, trans=np.zeros((2, 50, 3), np.float32), shape=np.zeros((2, 50, 10), np.float32)),
+                traj=dict(pose=traj, trans=trans))
+
+
+def gen_nets_train():
+    """forward(data) -- the training-mode pass (context encoder, posterior encoder, decoder in 'train' mode) -- and inference(recon=True)
+    of both VAEs, from the unmodified reference.  The posterior sample is drawn by torch.randn_like under a fixed seed; the port draws
+    the same numbers in the same order."""
+    from oracle import ref_harness as rh
+    model, _ = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
+    mt = model.mt_model
+    x = train_inputs()
+    out = {}
+    with torch.no_grad():
+        inf = mt.mfiller
+        d = inf.init_batch_data({k: torch.tensor(v) for k, v in x['infiller'].items()})
+        torch.manual_seed(1234)
+        d = inf.forward(d)
+        for k in ('q_z_dist', 'p_z_dist'):
+            out['inf_%s_mu' % k] = _np(d[k].mu)
+            out['inf_%s_logvar' % k] = _np(d[k].logvar)
+        out['inf_q_z_samp'] = _np(d['q_z_samp'])
+        out['inf_context'] = _np(d['context'])
+        out['inf_train_out_body_pose_tp'] = _np(d['train_out_body_pose_tp'])
+        out['inf_train_out_pose_tp'] = _np(d['train_out_pose_tp'])
+        d = inf.inference({k: torch.tensor(v) for k, v in x['infiller'].items()}, sample_num=1, recon=True, multi_step=False)
+        out['inf_recon_out_body_pose'] = _np(d['recon_out_body_pose'])
+        trj = mt.traj_predictor
+        d = trj.init_batch_data({k: torch.tensor(v) for k, v in x['traj'].items()})
+        out['trj_local_traj_tp'] = _np(d['local_traj_tp'])
+        torch.manual_seed(4321)
+        d = trj.forward(d)
+        for k in ('q_z_dist', 'p_z_dist'):
+            out['trj_%s_mu' % k] = _np(d[k].mu)
+            out['trj_%s_logvar' % k] = _np(d[k].logvar)
+        out['trj_q_z_samp'] = _np(d['q_z_samp'])
+        out['trj_train_out_local_traj_tp'] = _np(d['train_out_local_traj_tp'])
+        out['trj_train_out_trans_tp'] = _np(d['train_out_trans_tp'])
+        out['trj_train_out_orient_q_tp'] = _np(d['train_out_orient_q_tp'])
+        d = trj.inference({k: torch.tensor(v) for k, v in x['traj'].items()}, sample_num=1, recon=True)
+        for k in ('recon_out_trans', 'recon_out_orient', 'recon_out_local_traj_tp'):
+            if k in d:
+                out['trj_' + k] = _np(d[k])
+    np.savez_compressed(os.path.join(GOLD, 'nets_train.npz'), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
 def _flatten_state(data, keys_person, keys_top):
     out = {}
     for idx, pd in data['person_data'].items():
@@ -326,9 +393,9 @@ def main(argv):
     from oracle import ref_harness as rh
     rh.setup()
     os.makedirs(GOLD, exist_ok=True)
-    todo = argv or ['smpl', 'geom', 'nets', 'grecon', 'full', 'eval']
+    todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'eval': gen_eval}[name]()
         print('done', name)
 
 
