@@ -26,6 +26,30 @@ struct DeviceRT {
   // written by thread i mod blockDim only, so a caller whose next phase touches only its own elements needs no barrier after it;
   // one barrier per chunk of blockDim elements happens inside.
   // LDS: the arrays are known to be in LDS (ds_read / ds_write instead of flat accesses), else in global memory
+#ifdef GLAMR_SCAN_DPP
+  template <int CTRL> static __device__ __forceinline__ float dpp0(float v) {      // lane's DPP source, 0 where it falls outside the row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+  }
+  static __device__ __forceinline__ float lane_value(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+  }
+  // inclusive prefix (reverse: suffix) sum over the 64 lanes of a wave
+  static __device__ __forceinline__ float wave_scan_dpp(float v, bool reverse) {
+    const int row = (threadIdx.x & 63) >> 4;
+    if (!reverse) {
+      v += dpp0<0x111>(v); v += dpp0<0x112>(v); v += dpp0<0x114>(v); v += dpp0<0x118>(v);      // row_shr:1,2,4,8
+      const float t0 = lane_value(v, 15), t1 = lane_value(v, 31), t2 = lane_value(v, 47);      // row totals
+      const float s1 = t0, s2 = t0 + t1, s3 = s2 + t2;
+      v += row == 0 ? 0.f : (row == 1 ? s1 : (row == 2 ? s2 : s3));
+    } else {
+      v += dpp0<0x101>(v); v += dpp0<0x102>(v); v += dpp0<0x104>(v); v += dpp0<0x108>(v);      // row_shl:1,2,4,8
+      const float t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48);
+      const float s2 = t3, s1 = t3 + t2, s0 = s1 + t1;
+      v += row == 3 ? 0.f : (row == 2 ? s2 : (row == 1 ? s1 : s0));
+    }
+    return v;
+  }
+#endif
   template <bool LDS = false>
   __device__ void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -42,6 +66,12 @@ struct DeviceRT {
       float x[RT_MAX_CH];
       for (int c = 0; c < nch; ++c) {
         float v = (i < n) ? elem<LDS>(ch[c], idx) : 0.f;
+#ifdef GLAMR_SCAN_DPP
+        // NOT YET VALIDATED ON HARDWARE (off by default; next round): the wave scan through DPP row shifts inside the 16-lane rows
+        // (out-of-row sources read 0: bound_ctrl) and v_readlane of the three row totals, instead of six ds_bpermute round trips
+        v = wave_scan_dpp(v, reverse);
+        if (lane == (reverse ? 0 : 63)) r[c * 16 + wave] = v;
+#else
         if (!reverse) {
           for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_up(v, off); if (lane >= off) v += y; }
           if (lane == 63) r[c * 16 + wave] = v;
@@ -49,6 +79,7 @@ struct DeviceRT {
           for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_down(v, off); if (lane + off < 64) v += y; }
           if (lane == 0) r[c * 16 + wave] = v;
         }
+#endif
         x[c] = v;
       }
       __syncthreads();
