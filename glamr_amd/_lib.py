@@ -2,7 +2,7 @@
 fails, a RuntimeError is raised -- the product path never computes on the CPU."""
 import ctypes
 import os
-from ctypes import c_int, c_int32, c_int64, c_size_t, c_uint32, c_float, c_void_p, c_char_p, POINTER, Structure
+from ctypes import c_int, c_int32, c_int64, c_size_t, c_uint32, c_float, c_double, c_void_p, c_char_p, POINTER, Structure
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libglamr_hip.so')
@@ -15,7 +15,7 @@ class TensorDesc(Structure):
 
 class StageDesc(Structure):
     _fields_ = [('var_mask', c_uint32), ('flags', c_uint32), ('loss_mask', c_uint32), ('monitor_mask', c_uint32),
-                ('first_frame_only_mask', c_uint32), ('niters', c_int32), ('lr', c_float), ('loss_weight', c_float * 16),
+                ('first_frame_only_mask', c_uint32), ('niters', c_int32), ('lr', c_double), ('loss_weight', c_float * 16),
                 ('kp_min_conf', c_float), ('first_frame_weight', c_float * 16), ('rel_trans_weight', c_float)]
 
 
@@ -63,6 +63,7 @@ _SIGNATURES = {
     'glamr_grecon_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'glamr_grecon_run_stage': (c_int, [POINTER(SceneBatch), POINTER(StageDesc), c_void_p, c_void_p, c_void_p]),
     'glamr_grecon_last_launch_ns': (c_int, [c_void_p, POINTER(ctypes.c_double)]),
+    'glamr_adam_step': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
 }
 
 

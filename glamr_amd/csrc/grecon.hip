@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include "grecon_algo.hpp"
 #include "block_rt.hpp"
+#include <vector>
 
 namespace glamr {
 namespace grecon {
@@ -31,6 +32,7 @@ struct KernelArgs {
   unsigned long long* stamps;          // {earliest workgroup start, latest workgroup end} of this launch, 100 MHz ticks
   size_t ws_floats_per_scene;
   float* grads_out;
+  const float* adam_tab;               // per-iteration Adam scalars formed on the host (workspace header) or null
   int use_lds;
   unsigned fast_floats;
 };
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
     s_lay = a.lay;
     assemble_scene(a.b, s_lay, &s_st, si, a.b.n_persons[si], a.b.seq_len[si], a.workspace + (size_t)si * a.ws_floats_per_scene, a.grads_out, sc,
                    a.use_lds ? arena : nullptr, a.fast_floats, a.use_lds);
+    sc.adam_tab = a.adam_tab;
   }
   __syncthreads();
   glamr::DeviceRT rt{red};
@@ -68,7 +71,9 @@ extern "C" int glamr_grecon_param_layout(int max_persons, int max_len, glamr_par
   return GLAMR_OK;
 }
 
-constexpr size_t GLAMR_GRECON_WS_HEADER = 256;
+// workspace header: 256 bytes of launch stamps, then the per-iteration Adam scalars of the stage (2 floats per iteration)
+constexpr size_t GLAMR_GRECON_WS_STAMPS = 256;
+constexpr size_t GLAMR_GRECON_WS_HEADER = GLAMR_GRECON_WS_STAMPS + (size_t)ADAM_TAB_MAX * 2 * sizeof(float);
 
 extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len) {
   if (n_scenes <= 0 || max_persons < 1 || max_persons > 8 || max_len < 2) return 0;
@@ -100,6 +105,16 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   GLAMR_HIP_CHECK(hipMemsetAsync(workspace, 0xFF, 8, stream));
   GLAMR_HIP_CHECK(hipMemsetAsync(static_cast<char*>(workspace) + 8, 0, 8, stream));
   ka.workspace = reinterpret_cast<float*>(static_cast<char*>(workspace) + GLAMR_GRECON_WS_HEADER);
+  // Adam's step size and second-moment correction per iteration, in the reference's own arithmetic (Python doubles, libm pow): a
+  // running product on the device would differ in the last bit of the fp32 scalar now and then, and the update must not (rotmath.hpp)
+  ka.adam_tab = nullptr;
+  if (stage->niters > 0 && stage->niters <= ADAM_TAB_MAX) {
+    std::vector<float> tab(2 * (size_t)stage->niters);
+    for (int i = 0; i < stage->niters; ++i) adam_coef_host(stage->lr, i + 1, &tab[2 * (size_t)i]);
+    float* dtab = reinterpret_cast<float*>(static_cast<char*>(workspace) + GLAMR_GRECON_WS_STAMPS);
+    GLAMR_HIP_CHECK(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, stream));   // pageable source: staged before the call returns
+    ka.adam_tab = dtab;
+  }
   ka.ws_floats_per_scene = align_up(scene_workspace_floats(batch->max_persons, batch->max_len), 64);
   ka.grads_out = grads_out;
   int threads = (batch->max_len + 63) / 64 * 64;
@@ -161,6 +176,24 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   return GLAMR_OK;
 }
 
+// torch.optim.Adam on a flat parameter vector, with the optimiser's own update function: the entry point the parity tests use to
+// check the device arithmetic bit for bit against torch.optim.Adam (and a plain fused Adam for callers that keep their own loop)
+__global__ void adam_step_kernel(int n, float* p, float* m, float* v, const float* g, glamr::grecon::AdamCoef c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) glamr::grecon::adam(p[i], m[i], v[i], g[i], c);
+}
+extern "C" int glamr_adam_step(int n, float* params, float* exp_avg, float* exp_avg_sq, const float* grad, double lr, int step, void* stream_) {
+  GLAMR_REQUIRE(n >= 0 && (n == 0 || (params && exp_avg && exp_avg_sq && grad)), "null argument");
+  GLAMR_REQUIRE(step >= 1 && lr > 0.0, "step must be >= 1 (1-based, as torch counts) and lr > 0");
+  if (n == 0) return GLAMR_OK;
+  float tab[2];
+  adam_coef_host(lr, step, tab);
+  AdamCoef c{tab[0], tab[1]};
+  hipLaunchKernelGGL(adam_step_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), n, params, exp_avg, exp_avg_sq, grad, c);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
 #ifdef GLAMR_PHASE_TIMING
 // development builds only: per-phase time of workgroup 0 in the last stage launch, in 10 ns ticks
 extern "C" int glamr_debug_phase_ticks(unsigned long long* out16) {
@@ -173,7 +206,10 @@ extern "C" int glamr_debug_phase_ticks(unsigned long long* out16) {
 extern "C" int glamr_grecon_last_launch_ns(const void* workspace, double* ns) {
   GLAMR_REQUIRE(workspace && ns, "null argument");
   unsigned long long st[2];
-  GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));        // synchronises with the launch
+  // stage launches run on the caller's (non-blocking) streams, which the null stream's copy below does not wait for
+  GLAMR_HIP_CHECK(hipDeviceSynchronize());
+  GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));
+  GLAMR_REQUIRE(st[0] != ~0ull, "no stage launch has completed on this workspace");
   *ns = st[1] > st[0] ? (double)(st[1] - st[0]) * 10.0 : 0.0;
   return GLAMR_OK;
 }

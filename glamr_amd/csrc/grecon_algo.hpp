@@ -98,6 +98,7 @@ struct Scene {
   int rel_stride_p, rel_stride_t;     // padded person count / frame count of rel_cam
   float* fast_free; size_t fast_left; // unused tail of the on-chip arena (claimed by setup for kpc when it fits)
   int TM;                             // padded frame count (array strides)
+  const float* adam_tab;              // [niters][2] per-iteration (-lr / (1 - beta1^t), sqrt(1 - beta2^t)) formed on the host, or null
 };
 
 // ---- wave-uniform views ------------------------------------------------------------------------------------------------------
@@ -194,14 +195,27 @@ GLAMR_HD SceneView scene_view(const Scene& sc) {
 GLAMR_HD float gmof(float x, float sigma2) { return sigma2 * x * x / (sigma2 + x * x); }
 GLAMR_HD float gmof_d(float x, float sigma2) { const float r = rm::rcp_(sigma2 + x * x); return 2.0f * sigma2 * sigma2 * x * r * r; }
 
-struct AdamCoef { float lr_t; float inv_bc2_sqrt; };   // lr / (1 - beta1^t),  1 / sqrt(1 - beta2^t)
+struct AdamCoef { float neg_step; float bc2_sqrt; };   // -lr / (1 - beta1^t),  sqrt(1 - beta2^t)   (both formed in double, as Python does)
+constexpr int ADAM_TAB_MAX = 4096;
+// torch/optim/adam.py: bias_correction = 1 - beta ** step (Python float pow), step_size = lr / bias_correction1,
+// bias_correction2_sqrt = bias_correction2 ** 0.5; both reach the fp32 kernels as scalars rounded from double.  Host only (libm pow).
+inline void adam_coef_host(double lr, int step, float out[2]) {
+  const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+  out[0] = (float)(-(lr / bc1));
+  out[1] = (float)pow(bc2, 0.5);
+}
 
-// torch.optim.Adam single-tensor update (betas 0.9/0.999, eps 1e-8, no weight decay)
+// torch.optim.Adam, single-tensor path (betas 0.9/0.999, eps 1e-8, no weight decay), in the operation ORDER of its CPU kernels:
+//   exp_avg.lerp_(grad, 1 - beta1)                          -> fma(w, g - m, m)               (vectorised lerp is an fmadd)
+//   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)  -> fma((1 - beta2) g, g, beta2 v)
+//   denom = exp_avg_sq.sqrt() / sqrt(bias_correction2) + eps;   param.addcdiv_(exp_avg, denom, value=-step_size) -> p + (a m) / denom
+// with 1 - beta formed in DOUBLE and rounded to fp32 (0.1f, 0.001f -- not 1.0f - 0.9f).  Checked bit for bit against torch.optim.Adam
+// on the CPU runtime (tests/test_rotmath_grads.py); torch's own sqrt is 1 ulp off for 0.7 % of its arguments, which no one can follow.
 GLAMR_HD void adam(float& p, float& m, float& v, float g, const AdamCoef& c) {
-  m = m + (g - m) * (1.0f - 0.9f);
-  v = v * 0.999f + (1.0f - 0.999f) * g * g;
-  const float denom = rm::sqrt_(v) * c.inv_bc2_sqrt + 1e-8f;
-  p = p - c.lr_t * (m * rm::rcp_(denom));
+  m = rm::fma_(0.1f, g - m, m);
+  v = rm::fma_(0.001f * g, g, v * 0.999f);
+  const float denom = rm::div_(rm::sqrt_rn_(v), c.bc2_sqrt) + 1e-8f;
+  p = p + rm::div_(c.neg_step * m, denom);
 }
 
 GLAMR_HD void invert34(const float M[12], float O[12]) {       // [R|t] -> [R^T | -R^T t]   (inverse_transform)
@@ -415,6 +429,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   sc.fast_free = fast ? f : nullptr;
   sc.fast_left = fast ? fast_floats - (size_t)(f - fast) : 0;
   sc.TM = (int)TM;
+  sc.adam_tab = nullptr;
   // rel_transform_cam is indexed with the padded person count
   sc.rel_stride_p = b.max_persons;
   sc.rel_stride_t = (int)TM;
@@ -517,6 +532,11 @@ inline int camera_mode(const glamr_stage_desc& st) {
   return (st.flags & GLAMR_FLAG_FIXED_CAM) ? 2 : 1;
 }
 
+// per-iteration observer of the CPU test runtime (tests/hostsim records the parameter trajectory); runtimes without a `trace`
+// member -- the device runtime -- compile to nothing
+template <class RT> GLAMR_HD auto trace_hook(RT& rt, int it, Scene& sc, int) -> decltype(rt.trace(it, sc), void()) { rt.trace(it, sc); }
+template <class RT> GLAMR_HD void trace_hook(RT&, int, Scene&, long) {}
+
 template <int FAST, bool SINGLE, int CAM, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
   // Frame loops of the full-arena instances make ONE pass (the launcher only selects them when every frame has its own thread): with
@@ -618,6 +638,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
 
   const int niters = st.niters;
   double b1p = 1.0, b2p = 1.0;
+  int n_done = 0;
   const int n_eval = niters > 0 ? niters : 1;
   const SceneView sh = scene_view<FAST>(sc);
   // One evaluation (+ update).  Instantiated twice: the iterations that only update (no reported values, no outputs) and the LAST
@@ -628,8 +649,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const bool update = niters > 0;
     b1p *= 0.9; b2p *= 0.999;
     AdamCoef ac;
-    ac.lr_t = (float)((double)st.lr / (1.0 - b1p));
-    ac.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2p));
+    const float* tab = uni(sc.adam_tab);
+    if (tab) {                                     // the host's table: Python's own arithmetic (pow in double)
+      ac.neg_step = glob(tab)[2 * n_done]; ac.bc2_sqrt = glob(tab)[2 * n_done + 1];
+    } else {                                       // stages longer than the table: running products (same values to ~1 ulp of a double)
+      ac.neg_step = (float)(-(st.lr / (1.0 - b1p)));
+      ac.bc2_sqrt = (float)sqrt(1.0 - b2p);
+    }
+    ++n_done;
     float lsum[GLAMR_NUM_LOSSES];
     for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) lsum[i] = 0.f;
     float kp_dist_cnt = 0.f;
@@ -1269,8 +1296,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     }
     GLAMR_MARK(rt, 8);
   };
-  for (int it = 0; it + 1 < n_eval; ++it) evaluate(std::false_type{});
+  for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::false_type{}); trace_hook(rt, it, sc, 0); }
   evaluate(std::true_type{});
+  trace_hook(rt, n_eval - 1, sc, 0);
   rt.sync();
   GLAMR_MARK_END(rt);
 }

@@ -140,7 +140,8 @@ typedef struct glamr_stage_desc {
   uint32_t monitor_mask;                 /* bit i set: monitor_only (reported, not optimised; compute_loss :540-542) */
   uint32_t first_frame_only_mask;        /* per-loss `first_frame_only` */
   int32_t niters;                        /* opt_niters */
-  float lr;                              /* opt_lr; Adam betas (0.9, 0.999), eps 1e-8 (:642) */
+  double lr;                             /* opt_lr as the DOUBLE the YAML holds: torch forms lr / (1 - beta1^t) in double before rounding to fp32;
+                                            Adam betas (0.9, 0.999), eps 1e-8 (:642) */
   float loss_weight[16];
   float kp_min_conf;                     /* kp_2d / kp_2d_dist `min_conf` */
   float first_frame_weight[16];          /* per-loss `first_frame_weight` (rel_transform default 10, others 1) */
@@ -203,6 +204,13 @@ int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_des
  * workgroup end, 10 ns resolution): what a profiler reports for the dispatch, also when other streams share the GPU.  Blocks until
  * that launch has finished. */
 int glamr_grecon_last_launch_ns(const void* workspace, double* ns);
+
+/* One torch.optim.Adam step (betas 0.9 / 0.999, eps 1e-8, no weight decay; torch/optim/adam.py _single_tensor_adam, the path
+ * GlobalReconOptimizer.init_opt selects, global_recon_model.py:642) on a flat fp32 vector, with the update function the fused
+ * optimiser uses: operation order of torch's CPU kernels, IEEE quotient / square root, `lr` and the bias corrections formed in double
+ * as Python does.  `step` is 1-based.  All arrays dev, n floats; params / exp_avg / exp_avg_sq are updated in place.  The parity
+ * tests compare it bit for bit with torch.optim.Adam. */
+int glamr_adam_step(int n, float* params, float* exp_avg, float* exp_avg_sq, const float* grad, double lr, int step, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,45 @@ struct HostRT {
   }
 };
 
+// HostRT + a per-iteration record of the scene's parameter vector and gradient (scene 0): the trajectory tests/tools compare with
+// the reference's Adam trajectory iteration by iteration
+struct TraceRT : HostRT {
+  float* params_out = nullptr;   // [niters][scene_stride]
+  float* grads_out = nullptr;    // [niters][scene_stride] (needs store_grad) or null
+  int stride = 0;
+  void trace(int it, Scene& sc) {
+    if (params_out) for (int i = 0; i < stride; ++i) params_out[(size_t)it * stride + i] = sc.cp[i];
+    if (grads_out && sc.store_grad) for (int i = 0; i < stride; ++i) grads_out[(size_t)it * stride + i] = sc.cg[i];
+  }
+};
+
+template <class RT>
+static void run_one(RT& rt, const glamr_scene_batch* b, const glamr_stage_desc* st, const glamr_param_layout& l, Scene& sc, int si) {
+  std::vector<float> tab(2 * (size_t)(st->niters > 0 ? st->niters : 1));
+  for (int i = 0; i * 2 < (int)tab.size(); ++i) adam_coef_host(st->lr, i + 1, &tab[2 * i]);
+  sc.adam_tab = st->niters <= ADAM_TAB_MAX ? tab.data() : nullptr;
+  // the same instance the device launch would pick (single-person / camera-mode specialisations)
+  const bool single = b->n_persons[si] == 1;
+  switch (camera_mode(*st)) {
+    case 1: if (single) run_scene<0, true, 1>(rt, sc, *st, l); else run_scene<0, false, 1>(rt, sc, *st, l); break;
+    case 2: if (single) run_scene<0, true, 2>(rt, sc, *st, l); else run_scene<0, false, 2>(rt, sc, *st, l); break;
+    default: if (single) run_scene<0, true, 0>(rt, sc, *st, l); else run_scene<0, false, 0>(rt, sc, *st, l); break;
+  }
+}
+
+// scene 0 only, with the trajectory recorded
+extern "C" int hostsim_grecon_trace_stage(const glamr_scene_batch* b, const glamr_stage_desc* st, float* grads_scratch, float* params_trace, float* grads_trace) {
+  glamr_param_layout l;
+  param_layout(b->max_persons, b->max_len, l);
+  std::vector<float> ws(scene_workspace_floats(b->max_persons, b->max_len));
+  TraceRT rt;
+  rt.params_out = params_trace; rt.grads_out = grads_trace; rt.stride = l.scene_stride;
+  Scene sc;
+  assemble_scene(*b, l, st, 0, b->n_persons[0], b->seq_len[0], ws.data(), grads_scratch, sc);
+  run_one(rt, b, st, l, sc, 0);
+  return 0;
+}
+
 extern "C" int hostsim_grecon_param_layout(int max_persons, int max_len, glamr_param_layout* out) {
   param_layout(max_persons, max_len, *out);
   return 0;
@@ -33,13 +72,15 @@ extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_
   for (int si = 0; si < b->n_scenes; ++si) {
     Scene sc;
     assemble_scene(*b, l, st, si, b->n_persons[si], b->seq_len[si], ws.data(), grads_out, sc);
-    // the same instance the device launch would pick (single-person / camera-mode specialisations)
-    const bool single = b->n_persons[si] == 1;
-    switch (camera_mode(*st)) {
-      case 1: if (single) run_scene<0, true, 1>(rt, sc, *st, l); else run_scene<0, false, 1>(rt, sc, *st, l); break;
-      case 2: if (single) run_scene<0, true, 2>(rt, sc, *st, l); else run_scene<0, false, 2>(rt, sc, *st, l); break;
-      default: if (single) run_scene<0, true, 0>(rt, sc, *st, l); else run_scene<0, false, 0>(rt, sc, *st, l); break;
-    }
+    run_one(rt, b, st, l, sc, si);
   }
   return 0;
+}
+
+// the optimiser's Adam update on a flat vector (compared bit for bit with torch.optim.Adam in tests/test_adam_exact.py)
+extern "C" void hostsim_adam_step(int n, float* p, float* m, float* v, const float* g, double lr, int step) {
+  float tab[2];
+  adam_coef_host(lr, step, tab);
+  const AdamCoef c{tab[0], tab[1]};
+  for (int i = 0; i < n; ++i) adam(p[i], m[i], v[i], g[i], c);
 }

@@ -10,3 +10,35 @@ from tests import grecon_common as gc
 @pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES)
 def test_fused_optimiser_vs_reference_fixture(asset_root, golden, cfg_id, T, P, K):
     gc.check_case(gc.hostsim_runner(), asset_root, golden, cfg_id, T, P, K)
+
+
+def test_full_schedule_detection_gap_follows_the_reference(asset_root, golden):
+    """BASELINE.json configs[1] with person 0 undetected in frames [100,160): all 500 iterations of the kernel algorithm (CPU runtime)
+    from the oracle's initial state against the UNMODIFIED reference's result, value by value.  The unseen frames' cameras start as
+    zero matrices and wake up one per iteration; the reference's own answer moves by 0.03-0.04 px under 1e-7 perturbations or another
+    thread count and by 9.4 px (18 frames) when it is pushed into the neighbouring solution -- an Adam update that is not
+    torch's to the bit ends there too (tests/test_adam_exact.py)."""
+    import numpy as np
+    import torch
+    from oracle.port import build
+    from glamr_amd.global_recon import packing
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.utils import synth
+    run, dev = gc.hostsim_runner()
+    g = golden('full_glamr_dynamic_T300')
+    cfg = get_config('glamr_dynamic')
+    in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=synth.make_smpl_model())
+    ora = build.load_optimizer(asset_root, cfg)
+    data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 0))
+    packed = packing.PackedScenes([data], [gc.j_local_from_oracle(ora.smpl, data)], dev)
+    spec = cfg['opt_stage_specs']['init_opt']
+    run(packed, packing.stage_desc(spec, cfg['grecon_model_specs'], False), False)
+    vis = g['p0_vis_frames']
+    d = np.abs(packed.t['kp_2d_pred'][0, :300].numpy() - g['p0_kp_2d_pred'])[vis].max(axis=(1, 2))
+    print('gap case, CPU runtime: max %.4f px, median frame %.4f px' % (d.max(), np.median(d)))
+    assert d.max() < 0.1
+    for name, key in (('cam_rot6d', 'cam_rot_6d'), ('cam_trans', 'cam_trans')):
+        l = packed.layout
+        w = 6 if name == 'cam_rot6d' else 3
+        got = packed.t['params'][0, l[name]:l[name] + w * 300].numpy().reshape(300, w)
+        assert np.abs(got - g[key]).max() < 1e-3, name          # cameras of the UNSEEN frames included
