@@ -35,6 +35,15 @@ class PersonArrays(Structure):
     _fields_ = [(n, c_void_p) for n in ('visible_orig', 'smpl_pose', 'smpl_beta', 'trans_cam', 'nets_pose', 'nets_vis')]
 
 
+class InfillerIO(Structure):
+    _fields_ = [(n, c_void_p) for n in ('in_body_pose', 'body_pose', 'frame_mask', 'eps', 'context', 'q_z', 'p_z', 'z', 'out_body_pose')]
+
+
+class TrajIO(Structure):
+    _fields_ = [(n, c_void_p) for n in ('in_body_pose', 'in_joint_pos', 'trans', 'orient', 'eps', 'init_row')] + [('valid_len', c_int32)] + \
+               [(n, c_void_p) for n in ('local_traj', 'q_z', 'p_z', 'z', 'out_orig_local_traj', 'out_local_traj', 'out_trans', 'out_orient', 'out_orient_q')]
+
+
 class ParamLayout(Structure):
     _fields_ = [(n, c_int32) for n in ('scene_stride', 'cam_rot6d', 'cam_trans', 'cam_inv_rot_res', 'cam_inv_trans_res',
                                        'person_stride', 'person0', 'local_xy', 'local_dxy', 'local_heading', 'local_dheading',
@@ -55,6 +64,10 @@ _SIGNATURES = {
     'glamr_nets_destroy': (c_int, [c_void_p]),
     'glamr_nets_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
     'glamr_nets_infer': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
+    'glamr_nets_infiller_window': (c_int, [c_void_p, c_int, c_int, POINTER(InfillerIO), c_void_p, c_void_p]),
+    'glamr_nets_traj_clip': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(TrajIO), c_void_p, c_void_p]),
+    'glamr_traj_local_to_global_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'glamr_traj_local_to_global': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'glamr_init_workspace_bytes': (c_size_t, [c_int, c_int]),
     'glamr_init_prepare': (c_int, [POINTER(RawBatch), POINTER(SceneBatch), POINTER(PersonArrays), c_int, c_void_p, c_void_p]),
     'glamr_init_scenes': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays)] + [c_void_p] * 6),

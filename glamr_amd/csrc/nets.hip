@@ -122,9 +122,16 @@ struct glamr_nets {
   Lin dec_z; float* dec_pe = nullptr;               // z projection; [CUR][256] bias table (positions 10..39)
   DecLayer dec[2];
   Lin out1, out2, outfc;
+  // infiller posterior encoder (DataEncoder :126-249; forward(data) / recon only)
+  Lin qe_in; float* qe_table = nullptr;             // folded in_fc + pos projection; [32][256]: rows 0,1 = the projected tokens, 2..31 = positions
+  DecLayer qe[2];
+  Lin qe_pz;                                        // q_z_mu on token 0, q_z_logvar on token 1
   // trajectory predictor
   Lin t_in1, t_in2, t_ih[2]; float* t_hh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   Lin t_out1, t_out2, t_pr1, t_pr2, t_pz, t_dz, t_dctx, t_d2, t_dfc;
+  // trajectory posterior encoder (DataEncoder traj_pred_vae.py:95-199; forward(data) / recon only)
+  Lin te_in1, te_in2, te_ih[2]; float* te_hh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  Lin te_out1, te_out2, te_f1, te_f2, te_qz;
   float* rest_joints = nullptr; int32_t* parents = nullptr;
   std::vector<void*> allocs;
 };
@@ -264,7 +271,9 @@ __global__ __launch_bounds__(256) void traj_to_global_kernel(const float* raw, i
 struct Ws {
   float *pose, *x, *h0, *h1, *qkv, *att, *tmp, *ff, *ctxkv, *qbuf, *pz, *z, *zproj, *dq, *y;
   float *tx, *tg, *th, *tq, *tmean, *trow, *traw, *tscr;
-  unsigned char* mask; int* lens;
+  float *gx, *q2, *qpz;                      // infiller posterior: ground-truth window rows, the two token rows, their projection
+  float *te, *tcat, *e6, *tqz, *tloc;        // trajectory posterior: hidden rows, [encoder | context] rows, 6-d input rows, q(z) parameters, ground-truth local rows
+  unsigned char* mask; int* lens; int* lens2;
   size_t total; int Tpad;
 };
 Ws ws_layout(int B, int max_len, char* base) {
@@ -281,8 +290,11 @@ Ws ws_layout(int B, int max_len, char* base) {
   w.zproj = take((size_t)B * FF); w.dq = take(MW * D); w.y = take(MW * 128);
   w.tx = take(MT * XLD); w.tg = take(MT * 1024); w.th = take(MT * D); w.tq = take(MT * D); w.tmean = take((size_t)B * D); w.trow = take((size_t)B * FF);
   w.traw = take(MT * 64); w.tscr = take(MT * 3);
+  w.gx = take(MW * XLD); w.q2 = take((size_t)B * 2 * D); w.qpz = take((size_t)B * 2 * D);
+  w.te = take(MT * D); w.tcat = take(MT * FF); w.e6 = take(MT * 32); w.tqz = take((size_t)B * D); w.tloc = take(MT * 11);
   w.mask = reinterpret_cast<unsigned char*>(take((MW + 3) / 4 + 64));
   w.lens = reinterpret_cast<int*>(take((size_t)B + 64));
+  w.lens2 = reinterpret_cast<int*>(take((size_t)B + 64));
   w.total = off;
   return w;
 }
@@ -421,6 +433,28 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
     RC(dec_layer(h->dec[0], 78)); RC(dec_layer(h->dec[1], 96));
     RC(lin_plain(h->out1, I, 114)); RC(lin_plain(h->out2, I, 116)); RC(lin_plain(h->outfc, I, 118));
   }
+  // ---- infiller: posterior encoder (tokens 28,29; in_fc 30; pos_enc.fc 32; two decoder layers 34 / 52; q_z nets 70 / 72) ----------
+  {
+    const HostT Win = I.get(30), Wpe = I.get(32);
+    const std::vector<double> bin = vec_of(I.get(31)), bpe = vec_of(I.get(33));
+    const HostT Wx = cols(Wpe, 0, D), Wp = cols(Wpe, D, 2 * D);
+    RC(up_lin(h->qe_in, matmul(Wx, Win), nullptr));
+    const std::vector<double> bfold = matvec(Wx, bin);
+    std::vector<double> table((size_t)32 * D);
+    for (int pos = 0; pos < 32; ++pos) {
+      const std::vector<double> pp = matvec(Wp, pos_code(pos));
+      std::vector<double> tok;
+      if (pos < 2) tok = matvec(Wx, vec_of(I.get(28 + pos)));
+      for (int k = 0; k < D; ++k) table[(size_t)pos * D + k] = pp[k] + bpe[k] + (pos < 2 ? tok[k] : bfold[k]);
+    }
+    RC(up_vec(&h->qe_table, table));
+    RC(dec_layer(h->qe[0], 34)); RC(dec_layer(h->qe[1], 52));
+    HostT Wq; Wq.r = 2 * NZ; Wq.c = D; Wq.v.resize((size_t)2 * NZ * D);
+    const HostT Wmu = I.get(70), Wlv = I.get(72);
+    std::copy(Wmu.v.begin(), Wmu.v.end(), Wq.v.begin()); std::copy(Wlv.v.begin(), Wlv.v.end(), Wq.v.begin() + (size_t)NZ * D);
+    std::vector<double> bq = vec_of(I.get(71)); const std::vector<double> blv = vec_of(I.get(73)); bq.insert(bq.end(), blv.begin(), blv.end());
+    RC(up_lin(h->qe_pz, Wq, &bq));
+  }
   // ---- trajectory predictor ----------------------------------------------------------------------------------------------------
   {
     auto tl = [&](Lin& L, int iw) { const std::vector<double> bias = vec_of(Tj.get(iw + 1)); return up_lin(L, Tj.get(iw), &bias); };
@@ -444,6 +478,22 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
     RC(up_lin(h->t_dz, cols(Wd, 0, NZ), &bd));                 // z part carries the bias; added per sequence as a row bias
     RC(up_lin(h->t_dctx, cols(Wd, NZ, NZ + D), nullptr));
     RC(tl(h->t_d2, 56)); RC(tl(h->t_dfc, 58));
+    // posterior encoder: in_mlp 24/26, two bi-LSTM layers from 28, out_mlp 44/46, fusion_mlp 48/50, q_z_net 52
+    RC(tl(h->te_in1, 24)); RC(tl(h->te_in2, 26));
+    for (int l = 0; l < 2; ++l) {
+      const int b0 = 28 + 8 * l;
+      HostT W; W.r = 1024; W.c = D; W.v.resize((size_t)1024 * D);
+      std::vector<double> bias(1024);
+      for (int d = 0; d < 2; ++d) {
+        const HostT wi = Tj.get(b0 + 4 * d);
+        std::copy(wi.v.begin(), wi.v.end(), W.v.begin() + (size_t)d * 512 * D);
+        const std::vector<double> bi = vec_of(Tj.get(b0 + 4 * d + 2)), bh = vec_of(Tj.get(b0 + 4 * d + 3));
+        for (int k = 0; k < 512; ++k) bias[d * 512 + k] = bi[k] + bh[k];
+        RC(up_vec(&h->te_hh[l][d], vec_of(Tj.get(b0 + 4 * d + 1))));
+      }
+      RC(up_lin(h->te_ih[l], W, &bias));
+    }
+    RC(tl(h->te_out1, 44)); RC(tl(h->te_out2, 46)); RC(tl(h->te_f1, 48)); RC(tl(h->te_f2, 50)); RC(tl(h->te_qz, 52));
   }
   RC(upload(&h->rest_joints, fk_rest_joints, (size_t)72));
   RC(upload(&h->parents, parents, (size_t)24));
@@ -496,6 +546,254 @@ int decoder_layer(hipStream_t st, const DecLayer& Dl, Ws& w, float* x, const flo
 
 }  // namespace
 
+namespace {
+
+// ---- kernels of the training-mode / reconstruction passes ---------------------------------------------------------------------
+
+// one 50-frame window handed over as is: rows [B][50][69] -> [B][50][96], key-padding mask = frame not visible
+__global__ void window_in_kernel(const float* in_pose, const float* frame_mask, float* x, unsigned char* mask) {
+  const int b = blockIdx.x, j = blockIdx.y, c = threadIdx.x;          // 96 threads
+  x[((size_t)b * WIN + j) * XLD + c] = c < 69 ? in_pose[((size_t)b * WIN + j) * 69 + c] : 0.0f;
+  if (c == 0 && mask) mask[(size_t)b * WIN + j] = frame_mask[(size_t)b * WIN + j] == 1.0f ? 0 : 1;
+}
+// posterior encoder input: row 0, 1 = the two tokens (zero here, their projection is in the table), rows 2..31 = body_pose[10:40]
+__global__ void posterior_rows_kernel(const float* gx, float* x32) {
+  const int b = blockIdx.x, r = blockIdx.y, c = threadIdx.x;          // 96 threads, 32 rows
+  x32[((size_t)b * 32 + r) * XLD + c] = r < 2 ? 0.0f : gx[((size_t)b * WIN + PAST + r - 2) * XLD + c];
+}
+__global__ void take_rows_kernel(const float* src, int rows_per_seq, int n_take, float* dst) {       // dst[b][i][:] = src[b][i][:], i < n_take
+  const int b = blockIdx.x, i = blockIdx.y, k = threadIdx.x;
+  dst[((size_t)b * n_take + i) * D + k] = src[((size_t)b * rows_per_seq + i) * D + k];
+}
+// (mu, logvar) of the infiller distributions: token 0 cols [0,128), token 1 cols [128,256)  ->  out[b][2][128]
+__global__ void dist_out_kernel(const float* pz, float* out) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  out[((size_t)b * 2 + 0) * NZ + k] = pz[((size_t)b * 2 + 0) * D + k];
+  out[((size_t)b * 2 + 1) * NZ + k] = pz[((size_t)b * 2 + 1) * D + NZ + k];
+}
+__global__ void mode_infiller_kernel(const float* pz, float* z) { z[(size_t)blockIdx.x * NZ + threadIdx.x] = pz[((size_t)blockIdx.x * 2) * D + threadIdx.x]; }
+__global__ void mode_traj_kernel(const float* pz, float* z) { z[(size_t)blockIdx.x * NZ + threadIdx.x] = pz[(size_t)blockIdx.x * D + threadIdx.x]; }
+__global__ void rows_out_kernel(const float* y, int ldy, int rows, int cols, float* out) {            // out[r][c] = y[r][c], c < cols
+  const int r = blockIdx.x, c = threadIdx.x;
+  if (r < rows && c < cols) out[(size_t)r * cols + c] = y[(size_t)r * ldy + c];
+}
+__global__ void copy_cols_kernel(const float* src, int lds_, float* dst, int ldd, int col0, size_t n) {   // dst[r][col0 + k] = src[r][k], k < 256
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const size_t r = idx / D; const int k = (int)(idx % D);
+  dst[r * ldd + col0 + k] = src[r * lds_ + k];
+}
+// joint positions handed over by the caller (in_joint_pos): rows [B][T][69] -> [B][T][96]; frames >= lens are zero (get_seg_data padding)
+__global__ void joints_in_kernel(const float* jp, int max_len, const int* lens, float* x) {
+  const int b = blockIdx.x, t = blockIdx.y, c = threadIdx.x;
+  x[((size_t)b * max_len + t) * XLD + c] = (c < 69 && t < lens[b]) ? jp[((size_t)b * max_len + t) * 69 + c] : 0.0f;
+}
+// TrajPredVAE.init_batch_data :396-457 + DataEncoder input :160-175 for one sequence per workgroup:
+//   q = angle_axis_to_quaternion(orient);  local = traj_global2local_heading(trans, q) (traj_utils.py:44-62)
+//   (q_h, t_h) = convert_traj_world2heading(q, trans) (traj_utils.py:97-107);  encoder row = [t_h, quaternion_to_angle_axis(q_h)]
+__global__ __launch_bounds__(256) void traj_prepare_kernel(const float* trans, const float* orient, int max_len, const int* lens, float* local, float* e6) {
+  const int b = blockIdx.x, n = lens[b];
+  const float cbase[4] = {0.5f, -0.5f, -0.5f, -0.5f};
+  const float* tr = trans + (size_t)b * max_len * 3;
+  const float* oa = orient + (size_t)b * max_len * 3;
+  float q0[4], qn0[4], h0q[4], inv_h[4];
+  rm::aa_to_quat(oa, q0);
+  rm::quat_mul(q0, cbase, qn0);
+  rm::quat_heading_q(qn0, h0q);
+  rm::quat_conj(h0q, inv_h);
+  for (int t = threadIdx.x; t < max_len; t += blockDim.x) {
+    float* L = local + ((size_t)b * max_len + t) * 11;
+    float* e = e6 + ((size_t)b * max_len + t) * 32;
+    if (t >= n) { for (int c = 0; c < 11; ++c) L[c] = 0.f; for (int c = 0; c < 32; ++c) e[c] = 0.f; continue; }
+    float q[4], qn[4], hq[4], hqc[4], ql[4], R[9];
+    rm::aa_to_quat(oa + t * 3, q);
+    rm::quat_mul(q, cbase, qn);
+    const float h = rm::quat_heading(qn);
+    rm::quat_heading_q(qn, hq);
+    rm::quat_conj(hq, hqc);
+    rm::quat_mul(hqc, qn, ql);
+    rm::quat_to_rotmat(ql, R);
+    float dh = h, dx = tr[t * 3 + 0], dy = tr[t * 3 + 1];
+    if (t > 0) {
+      float qp[4], qnp[4];
+      rm::aa_to_quat(oa + (t - 1) * 3, qp);
+      rm::quat_mul(qp, cbase, qnp);
+      const float hp = rm::quat_heading(qnp);
+      dh = h - hp;
+      const float ex = tr[t * 3 + 0] - tr[(t - 1) * 3 + 0], ey = tr[t * 3 + 1] - tr[(t - 1) * 3 + 1];
+      const float c = cosf(-hp), s = sinf(-hp);
+      dx = ex * c - ey * s; dy = ex * s + ey * c;
+    }
+    L[0] = dx; L[1] = dy; L[2] = tr[t * 3 + 2];
+    for (int r = 0; r < 3; ++r) { L[3 + r] = R[r * 3 + 0]; L[6 + r] = R[r * 3 + 1]; }
+    L[9] = cosf(dh); L[10] = sinf(dh);
+    // heading frame of the first pose
+    float qh[4], aa[3], th[3];
+    rm::quat_mul(inv_h, qn, qh);
+    rm::quat_to_aa(qh, aa);
+    const float tt[3] = {tr[t * 3 + 0] - tr[0], tr[t * 3 + 1] - tr[1], tr[t * 3 + 2]};
+    rm::quat_rotate(inv_h, tt, th);
+    for (int c = 0; c < 3; ++c) { e[c] = th[c]; e[3 + c] = aa[c]; }
+    for (int c = 6; c < 32; ++c) e[c] = 0.f;
+  }
+}
+// local trajectory -> global, with the first row's xy / heading vector taken from `init` rows when given (DataDecoder :319-333:
+// init_xy / local_traj_tp[0] in train and recon modes, zeros and (0, 1) in inference); also the quaternion output
+__global__ __launch_bounds__(256) void traj_to_global2_kernel(const float* raw, int ldraw, int max_len, const int* lens, const float* init, int ldinit, int fix_first,
+                                                              float* local, float* trans, float* orient, float* orient_q, float* scratch) {
+  __shared__ float red[RT_RED_FLOATS];
+  DeviceRT rt{red};
+  const int b = blockIdx.x, n = lens[b];
+  float* L = local + (size_t)b * max_len * 11;
+  float* theta = scratch + (size_t)b * max_len * 3;
+  float* xy = theta + max_len;
+  for (int t = threadIdx.x; t < max_len; t += blockDim.x) {
+    for (int c = 0; c < 11; ++c) {
+      float v = (t < n) ? raw[((size_t)b * max_len + t) * ldraw + c] : 0.0f;
+      if (t == 0 && fix_first) {
+        if (init) { if (c < 2 || c >= 9) v = init[(size_t)b * ldinit + c]; }
+        else { if (c < 2) v = 0.0f; if (c == 9) v = 0.0f; if (c == 10) v = 1.0f; }
+      }
+      L[t * 11 + c] = v;
+    }
+    if (t < n) theta[t] = rm::atan2s(L[t * 11 + 10], L[t * 11 + 9]);
+  }
+  __syncthreads();
+  rt.scan(theta, n, 1, false);
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    float dx = L[t * 11], dy = L[t * 11 + 1];
+    if (t > 0) { const float th = theta[t - 1], c = cosf(th), s = sinf(th); const float a = dx * c - dy * s, bb = dx * s + dy * c; dx = a; dy = bb; }
+    xy[t * 2] = dx; xy[t * 2 + 1] = dy;
+  }
+  __syncthreads();
+  rt.scan(xy, n, 2, false);
+  rt.scan(xy + 1, n, 2, false);
+  for (int t = threadIdx.x; t < max_len; t += blockDim.x) {
+    float tr[3] = {0.f, 0.f, 0.f}, aa[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < n) {
+      const float base[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+      float hq[4], R[9], lq[4], q1[4];
+      rm::heading_quat(theta[t], hq);
+      rm::rot6d_to_rotmat(L + t * 11 + 3, R);
+      rm::rotmat_to_quat(R, lq);
+      rm::quat_mul(hq, lq, q1);
+      rm::quat_mul(q1, base, q);
+      rm::quat_to_aa(q, aa);
+      tr[0] = xy[t * 2]; tr[1] = xy[t * 2 + 1]; tr[2] = L[t * 11 + 2];
+    }
+    for (int c = 0; c < 3; ++c) {
+      if (trans) trans[((size_t)b * max_len + t) * 3 + c] = tr[c];
+      if (orient) orient[((size_t)b * max_len + t) * 3 + c] = aa[c];
+    }
+    if (orient_q) for (int c = 0; c < 4; ++c) orient_q[((size_t)b * max_len + t) * 4 + c] = q[c];
+  }
+}
+
+// ---- one window of the motion infiller --------------------------------------------------------------------------------------------
+// w.x / w.mask hold the window input; on return w.h0 = context [B][50][256], w.z = the latent, w.y = the 30 generated frames [B][30][128].
+// mode 0: z sampled from the prior (eps), 1: from the posterior (needs w.gx = the full window, eps), 2: posterior mode.
+int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const float* eps, int eps_stride, float* q_out, float* p_out) {
+  const int M = B * WIN;
+  RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M));
+  hipLaunchKernelGGL(add_table_kernel, dim3((M * D + 255) / 256), dim3(256), 0, st, w.h0, h->enc_pe, WIN, M * D);
+  RC(encoder_layer(st, h->enc[0], w, w.h0, w.h1, B));
+  RC(encoder_layer(st, h->enc[1], w, w.h1, w.h0, B));
+  float* ctx = w.h0;
+  if (mode != GLAMR_VAE_INFER) {
+    // posterior: [mu token, logvar token, 30 current frames] attend to each other and to the context (DataEncoder.forward :204-249)
+    float* x32 = w.dq;
+    hipLaunchKernelGGL(posterior_rows_kernel, dim3(B, 32), dim3(XLD), 0, st, w.gx, w.h1);      // w.h1 is free after the encoder: [B][32][96] rows
+    RC(lin(st, h->qe_in, w.h1, XLD, x32, D, B * 32));
+    hipLaunchKernelGGL(add_table_kernel, dim3((B * 32 * D + 255) / 256), dim3(256), 0, st, x32, h->qe_table, 32, B * 32 * D);
+    RC(decoder_layer(st, h->qe[0], w, x32, ctx, B, 32));
+    RC(decoder_layer(st, h->qe[1], w, x32, ctx, B, 32));
+    hipLaunchKernelGGL(take_rows_kernel, dim3(B, 2), dim3(D), 0, st, x32, 32, 2, w.q2);
+    RC(lin(st, h->qe_pz, w.q2, D, w.qpz, D, B * 2));
+    if (q_out) hipLaunchKernelGGL(dist_out_kernel, dim3(B), dim3(NZ), 0, st, w.qpz, q_out);
+  }
+  // prior: two learned tokens attend to the context
+  RC(lin(st, h->prior_kv, ctx, D, w.ctxkv, 2 * D, M));
+  launch_attention( dim3(B, 8), dim3(64), 0, st, h->prior_q, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, 2, WIN, 1);
+  RC(lin(st, h->prior_o, w.att, D, w.tmp, D, B * 2));
+  hipLaunchKernelGGL(tile_rows_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, st, w.dq, h->prior_x1, 2, B * 2 * D);
+  RC(ln(st, w.tmp, w.dq, h->prior_n2, w.dq, B * 2));
+  RC(lin(st, h->prior_f1, w.dq, D, w.ff, FF, B * 2, ACT_RELU));
+  RC(lin(st, h->prior_f2, w.ff, FF, w.tmp, D, B * 2));
+  RC(ln(st, w.tmp, w.dq, h->prior_n3, w.dq, B * 2));
+  RC(lin(st, h->prior_pz, w.dq, D, w.pz, D, B * 2));
+  if (p_out) hipLaunchKernelGGL(dist_out_kernel, dim3(B), dim3(NZ), 0, st, w.pz, p_out);
+  if (mode == GLAMR_VAE_INFER) hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.pz, eps, eps_stride, w.z, B);
+  else if (mode == GLAMR_VAE_TRAIN) hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.qpz, eps, eps_stride, w.z, B);
+  else hipLaunchKernelGGL(mode_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.qpz, w.z);
+  // decoder: 30 queries = position code of z
+  RC(lin(st, h->dec_z, w.z, NZ, w.zproj, D, B));
+  hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(D), 0, st, w.zproj, h->dec_pe, w.dq);
+  RC(decoder_layer(st, h->dec[0], w, w.dq, ctx, B, CUR));
+  RC(decoder_layer(st, h->dec[1], w, w.dq, ctx, B, CUR));
+  RC(lin(st, h->out1, w.dq, D, w.ff, FF, B * CUR, ACT_RELU));
+  RC(lin(st, h->out2, w.ff, FF, w.tmp, D, B * CUR, ACT_RELU));
+  RC(lin(st, h->outfc, w.tmp, D, w.y, 128, B * CUR));
+  return GLAMR_OK;
+}
+
+void bilstm(glamr_nets* h, hipStream_t st, const float* G, float* const hh[2], const int* lens, float* H, int max_len, int B) {
+  LstmArgs la{G, hh[0], hh[1], lens, H, max_len};
+  // large batches: 16 sequences per workgroup on the matrix cores; small ones: one sequence per workgroup keeps every CU busy
+  if (B >= 512) hipLaunchKernelGGL(lstm_mfma_kernel, dim3((B + 15) / 16, 2), dim3(512), 0, st, la, B);
+  else hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(512), 0, st, la);
+}
+
+// ---- the trajectory predictor on joint rows w.tx [B][max_len][96] -------------------------------------------------------------------
+// lens_run: frames the recurrent layers and the temporal means cover.  mode as above; modes 1 / 2 need w.e6 (encoder rows) and use
+// `init` (first row of the ground-truth local trajectory) for the first output row.
+int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const int* lens_run, int mode, const float* eps, float* q_out, float* p_out,
+              const float* init, int ldinit, float* out_orig, float* out_local, float* out_trans, float* out_orient, float* out_orient_q) {
+  const int MT = B * max_len;
+  RC(lin(st, h->t_in1, w.tx, XLD, w.tg, FF, MT, ACT_RELU));
+  RC(lin(st, h->t_in2, w.tg, FF, w.th, D, MT, ACT_RELU));
+  for (int l = 0; l < 2; ++l) {
+    RC(lin(st, h->t_ih[l], w.th, D, w.tg, 1024, MT));
+    bilstm(h, st, w.tg, h->t_hh[l], lens_run, w.th, max_len, B);
+  }
+  RC(lin(st, h->t_out1, w.th, D, w.tg, FF, MT, ACT_RELU));
+  RC(lin(st, h->t_out2, w.tg, FF, w.th, D, MT, ACT_RELU));          // context [B][max_len][256]
+  if (mode != GLAMR_VAE_INFER) {
+    // posterior (DataEncoder.forward :160-199): [t_h, aa(q_h)] -> in_mlp -> 2 bi-LSTM -> out_mlp; fused with the context, mean over time
+    RC(lin(st, h->te_in1, w.e6, 32, w.tg, FF, MT, ACT_RELU));
+    RC(lin(st, h->te_in2, w.tg, FF, w.te, D, MT, ACT_RELU));
+    for (int l = 0; l < 2; ++l) {
+      RC(lin(st, h->te_ih[l], w.te, D, w.tg, 1024, MT));
+      bilstm(h, st, w.tg, h->te_hh[l], lens_run, w.te, max_len, B);
+    }
+    RC(lin(st, h->te_out1, w.te, D, w.tg, FF, MT, ACT_RELU));
+    RC(lin(st, h->te_out2, w.tg, FF, w.tcat, FF, MT, ACT_RELU));     // columns [0,256) of the fused rows
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(((size_t)MT * D + 255) / 256), dim3(256), 0, st, w.th, D, w.tcat, FF, D, (size_t)MT * D);
+    RC(lin(st, h->te_f1, w.tcat, FF, w.tg, FF, MT, ACT_RELU));
+    RC(lin(st, h->te_f2, w.tg, FF, w.te, D, MT, ACT_RELU));
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(B), dim3(D), 0, st, w.te, max_len, lens_run, w.tmean);
+    RC(lin(st, h->te_qz, w.tmean, D, w.tqz, D, B));
+    if (q_out) GLAMR_HIP_CHECK(hipMemcpyAsync(q_out, w.tqz, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(B), dim3(D), 0, st, w.th, max_len, lens_run, w.tmean);
+  RC(lin(st, h->t_pr1, w.tmean, D, w.trow, FF, B, ACT_RELU));
+  RC(lin(st, h->t_pr2, w.trow, FF, w.tmean, D, B, ACT_RELU));
+  RC(lin(st, h->t_pz, w.tmean, D, w.pz, D, B));
+  if (p_out) GLAMR_HIP_CHECK(hipMemcpyAsync(p_out, w.pz, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (mode == GLAMR_VAE_INFER) hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(NZ), 0, st, w.pz, eps, w.z);
+  else if (mode == GLAMR_VAE_TRAIN) hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(NZ), 0, st, w.tqz, eps, w.z);
+  else hipLaunchKernelGGL(mode_traj_kernel, dim3(B), dim3(NZ), 0, st, w.tqz, w.z);
+  RC(lin(st, h->t_dz, w.z, NZ, w.trow, FF, B));                      // W_z z + b, one row per sequence
+  RC(lin(st, h->t_dctx, w.th, D, w.tg, FF, MT, ACT_RELU, nullptr, 0, w.trow, max_len, FF));
+  RC(lin(st, h->t_d2, w.tg, FF, w.tq, D, MT, ACT_RELU));
+  RC(lin(st, h->t_dfc, w.tq, D, w.traw, 64, MT));
+  if (out_orig) hipLaunchKernelGGL(rows_out_kernel, dim3(MT), dim3(64), 0, st, w.traw, 64, MT, 11, out_orig);
+  hipLaunchKernelGGL(traj_to_global2_kernel, dim3(B), dim3(256), 0, st, w.traw, 64, max_len, lens_run, init, ldinit, 1, out_local, out_trans, out_orient,
+                     out_orient_q, w.tscr);
+  return GLAMR_OK;
+}
+
+}  // namespace
+
 extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t* lens_host, const float* body_pose, const float* visible,
                                 const float* motion_eps, int n_win_max, const float* traj_eps, float* out_pose, float* out_local_traj,
                                 float* out_trans, float* out_orient, int flags, void* workspace, void* stream_) {
@@ -518,61 +816,92 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
 
   // ---- motion infiller: autoregressive windows [30 i, 30 i + 50) ------------------------------------------------------------
   for (int i = 0; do_infill && i < n_win; ++i) {
-    const int s = i * CUR, M = B * WIN;
+    const int s = i * CUR;
     hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(XLD), 0, st, w.pose, visible, w.lens, w.Tpad, max_len, s, w.x, w.mask);
-    RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M));
-    hipLaunchKernelGGL(add_table_kernel, dim3((M * D + 255) / 256), dim3(256), 0, st, w.h0, h->enc_pe, WIN, M * D);
-    RC(encoder_layer(st, h->enc[0], w, w.h0, w.h1, B));
-    RC(encoder_layer(st, h->enc[1], w, w.h1, w.h0, B));
-    float* ctx = w.h0;
-    // prior: two learned tokens attend to the context
-    RC(lin(st, h->prior_kv, ctx, D, w.ctxkv, 2 * D, M));
-    launch_attention( dim3(B, 8), dim3(64), 0, st, h->prior_q, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, 2, WIN, 1);
-    RC(lin(st, h->prior_o, w.att, D, w.tmp, D, B * 2));
-    hipLaunchKernelGGL(tile_rows_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, st, w.dq, h->prior_x1, 2, B * 2 * D);
-    RC(ln(st, w.tmp, w.dq, h->prior_n2, w.dq, B * 2));
-    RC(lin(st, h->prior_f1, w.dq, D, w.ff, FF, B * 2, ACT_RELU));
-    RC(lin(st, h->prior_f2, w.ff, FF, w.tmp, D, B * 2));
-    RC(ln(st, w.tmp, w.dq, h->prior_n3, w.dq, B * 2));
-    RC(lin(st, h->prior_pz, w.dq, D, w.pz, D, B * 2));
-    hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.pz, motion_eps + (size_t)i * NZ, n_win_max * NZ, w.z, B);
-    // decoder: 30 queries = position code of z
-    RC(lin(st, h->dec_z, w.z, NZ, w.zproj, D, B));
-    hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(D), 0, st, w.zproj, h->dec_pe, w.dq);
-    RC(decoder_layer(st, h->dec[0], w, w.dq, ctx, B, CUR));
-    RC(decoder_layer(st, h->dec[1], w, w.dq, ctx, B, CUR));
-    RC(lin(st, h->out1, w.dq, D, w.ff, FF, B * CUR, ACT_RELU));
-    RC(lin(st, h->out2, w.ff, FF, w.tmp, D, B * CUR, ACT_RELU));
-    RC(lin(st, h->outfc, w.tmp, D, w.y, 128, B * CUR));
+    RC(infiller_window(h, st, w, B, GLAMR_VAE_INFER, motion_eps + (size_t)i * NZ, n_win_max * NZ, nullptr, nullptr));
     hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(XLD), 0, st, w.y, 128, w.lens, w.Tpad, s, w.pose);
   }
   if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(XLD), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
   if (!do_traj) { GLAMR_HIP_CHECK(hipGetLastError()); return GLAMR_OK; }
 
   // ---- trajectory predictor -----------------------------------------------------------------------------------------------------
-  const int MT = B * max_len;
   hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + 63) / 64), dim3(64), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
-  RC(lin(st, h->t_in1, w.tx, XLD, w.tg, FF, MT, ACT_RELU));
-  RC(lin(st, h->t_in2, w.tg, FF, w.th, D, MT, ACT_RELU));
-  for (int l = 0; l < 2; ++l) {
-    RC(lin(st, h->t_ih[l], w.th, D, w.tg, 1024, MT));
-    LstmArgs la{w.tg, h->t_hh[l][0], h->t_hh[l][1], w.lens, w.th, max_len};
-    // large batches: 16 sequences per workgroup on the matrix cores; small ones: one sequence per workgroup keeps every CU busy
-    if (B >= 512) hipLaunchKernelGGL(lstm_mfma_kernel, dim3((B + 15) / 16, 2), dim3(512), 0, st, la, B);
-    else hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(512), 0, st, la);
-  }
-  RC(lin(st, h->t_out1, w.th, D, w.tg, FF, MT, ACT_RELU));
-  RC(lin(st, h->t_out2, w.tg, FF, w.th, D, MT, ACT_RELU));          // context [B][max_len][256]
-  hipLaunchKernelGGL(masked_mean_kernel, dim3(B), dim3(D), 0, st, w.th, max_len, w.lens, w.tmean);
-  RC(lin(st, h->t_pr1, w.tmean, D, w.trow, FF, B, ACT_RELU));
-  RC(lin(st, h->t_pr2, w.trow, FF, w.tmean, D, B, ACT_RELU));
-  RC(lin(st, h->t_pz, w.tmean, D, w.pz, D, B));
-  hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(NZ), 0, st, w.pz, traj_eps, w.z);
-  RC(lin(st, h->t_dz, w.z, NZ, w.trow, FF, B));                      // W_z z + b, one row per sequence
-  RC(lin(st, h->t_dctx, w.th, D, w.tg, FF, MT, ACT_RELU, nullptr, 0, w.trow, max_len, FF));
-  RC(lin(st, h->t_d2, w.tg, FF, w.tq, D, MT, ACT_RELU));
-  RC(lin(st, h->t_dfc, w.tq, D, w.traw, 64, MT));
-  hipLaunchKernelGGL(traj_to_global_kernel, dim3(B), dim3(256), 0, st, w.traw, 64, max_len, w.lens, out_local_traj, out_trans, out_orient, w.tscr);
+  RC(traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr));
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
+}
+
+extern "C" int glamr_nets_infiller_window(glamr_nets* h, int B, int mode, const glamr_infiller_io* io, void* workspace, void* stream_) {
+  GLAMR_REQUIRE(h && io && workspace && B > 0, "null argument");
+  GLAMR_REQUIRE(mode == GLAMR_VAE_INFER || mode == GLAMR_VAE_TRAIN || mode == GLAMR_VAE_RECON, "mode must be GLAMR_VAE_INFER / TRAIN / RECON");
+  GLAMR_REQUIRE(io->in_body_pose && io->frame_mask && io->out_body_pose, "in_body_pose, frame_mask and out_body_pose are required");
+  GLAMR_REQUIRE(mode == GLAMR_VAE_INFER || io->body_pose, "the posterior encoder (train / recon) needs body_pose");
+  GLAMR_REQUIRE(mode == GLAMR_VAE_RECON || io->eps, "sampling (infer / train) needs eps");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  Ws w = ws_layout(B, WIN, static_cast<char*>(workspace));
+  hipLaunchKernelGGL(window_in_kernel, dim3(B, WIN), dim3(XLD), 0, st, io->in_body_pose, io->frame_mask, w.x, w.mask);
+  if (mode != GLAMR_VAE_INFER) hipLaunchKernelGGL(window_in_kernel, dim3(B, WIN), dim3(XLD), 0, st, io->body_pose, io->frame_mask, w.gx, (unsigned char*)nullptr);
+  RC(infiller_window(h, st, w, B, mode, io->eps, NZ, io->q_z, io->p_z));
+  if (io->context) GLAMR_HIP_CHECK(hipMemcpyAsync(io->context, w.h0, (size_t)B * WIN * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (io->z) GLAMR_HIP_CHECK(hipMemcpyAsync(io->z, w.z, (size_t)B * NZ * sizeof(float), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(rows_out_kernel, dim3(B * CUR), dim3(128), 0, st, w.y, 128, B * CUR, 69, io->out_body_pose);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_nets_traj_clip(glamr_nets* h, int B, int T, int mode, const glamr_traj_io* io, void* workspace, void* stream_) {
+  GLAMR_REQUIRE(h && io && workspace && B > 0 && T > 1, "null argument / empty clip");
+  GLAMR_REQUIRE(mode == GLAMR_VAE_INFER || mode == GLAMR_VAE_TRAIN || mode == GLAMR_VAE_RECON, "mode must be GLAMR_VAE_INFER / TRAIN / RECON");
+  GLAMR_REQUIRE(io->in_body_pose || io->in_joint_pos, "in_body_pose (joints by forward kinematics) or in_joint_pos is required");
+  GLAMR_REQUIRE(mode == GLAMR_VAE_INFER || (io->trans && io->orient), "the posterior encoder (train / recon) needs trans and orient");
+  GLAMR_REQUIRE(mode == GLAMR_VAE_RECON || io->eps, "sampling (infer / train) needs eps");
+  GLAMR_REQUIRE(io->out_local_traj, "out_local_traj is required");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  Ws w = ws_layout(B, T, static_cast<char*>(workspace));
+  std::vector<int> run(B, T), valid(B, T);
+  if (io->valid_len > 0 && io->valid_len < T) std::fill(valid.begin(), valid.end(), io->valid_len);      // zero-padded chunk (get_seg_data)
+  GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, run.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens2, valid.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  if (io->in_joint_pos) {
+    hipLaunchKernelGGL(joints_in_kernel, dim3(B, T), dim3(XLD), 0, st, io->in_joint_pos, T, w.lens2, w.tx);
+  } else {
+    hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(XLD), 0, st, io->in_body_pose, T, w.Tpad, w.pose);
+    hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (T + 63) / 64), dim3(64), 0, st, w.pose, w.Tpad, T, w.lens2, h->rest_joints, h->parents, w.tx);
+  }
+  const float* init = nullptr;
+  if (io->trans && io->orient) {
+    hipLaunchKernelGGL(traj_prepare_kernel, dim3(B), dim3(256), 0, st, io->trans, io->orient, T, w.lens, w.tloc, w.e6);
+    if (io->local_traj) GLAMR_HIP_CHECK(hipMemcpyAsync(io->local_traj, w.tloc, (size_t)B * T * 11 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    init = w.tloc;            // DataDecoder :322-324: the first row's xy and heading vector come from local_traj_tp when it exists
+  }
+  int ldinit = T * 11;
+  if (io->init_row) { init = io->init_row; ldinit = 11; }      // :319-321 takes precedence
+  RC(traj_pass(h, st, w, B, T, w.lens, mode, io->eps, io->q_z, io->p_z, init, ldinit, io->out_orig_local_traj, io->out_local_traj, io->out_trans,
+               io->out_orient, io->out_orient_q));
+  if (io->z) GLAMR_HIP_CHECK(hipMemcpyAsync(io->z, w.z, (size_t)B * NZ * sizeof(float), hipMemcpyDeviceToDevice, st));
+  GLAMR_HIP_CHECK(hipStreamSynchronize(st));          // `run` / `valid` are pageable host buffers
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_traj_local_to_global(int B, int T, const float* local_traj, float* out_trans, float* out_orient, float* out_orient_q, void* workspace,
+                                          void* stream_) {
+  GLAMR_REQUIRE(local_traj && workspace && B > 0 && T > 0 && (out_trans || out_orient || out_orient_q), "null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  // workspace: [B] lengths, [B][T][11] rows, [B][T][3] scan buffers  (glamr_traj_local_to_global_workspace_bytes)
+  int* lens = static_cast<int*>(workspace);
+  float* rows = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)B * sizeof(int), 256));
+  float* scr = rows + (size_t)B * T * 11;
+  std::vector<int> run(B, T);
+  GLAMR_HIP_CHECK(hipMemcpyAsync(lens, run.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(traj_to_global2_kernel, dim3(B), dim3(256), 0, st, local_traj, 11, T, lens, (const float*)nullptr, 0, 0, rows, out_trans, out_orient,
+                     out_orient_q, scr);
+  GLAMR_HIP_CHECK(hipStreamSynchronize(st));
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" size_t glamr_traj_local_to_global_workspace_bytes(int B, int T) {
+  if (B <= 0 || T <= 0) return 0;
+  return align_up((size_t)B * sizeof(int), 256) + (size_t)B * T * 14 * sizeof(float);
 }

@@ -474,6 +474,34 @@ GLAMR_HD void rotmat_to_aa_bwd(const float R[9], const float g[3], float gR[9]) 
   rotmat_to_quat_bwd(R, gq, gR);
 }
 
+// ---- quaternion helpers of the trajectory predictor's training-mode inputs (lib/utils/torch_transform.py) -----------------------
+GLAMR_HD void quat_conj(const float q[4], float o[4]) { o[0] = q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = -q[3]; }      // :31-35
+// quat_apply :38-45
+GLAMR_HD void quat_rotate(const float q[4], const float v[3], float o[3]) {
+  float t[3], u[3];
+  cross3(q + 1, v, t);
+  for (int i = 0; i < 3; ++i) t[i] *= 2.0f;
+  cross3(q + 1, t, u);
+  for (int i = 0; i < 3; ++i) o[i] = v[i] + q[0] * t[i] + u[i];
+}
+// get_heading :172-177 = 2 atan2s(z, w);  get_heading_q :180-185 = normalize(w, 0, 0, z)
+GLAMR_HD float quat_heading(const float q[4]) { return 2.0f * atan2s(q[3], q[0]); }
+GLAMR_HD void quat_heading_q(const float q[4], float o[4]) {
+  const float n = sqrtf(q[0] * q[0] + q[3] * q[3]);
+  const float c = fmaxf(n, 1e-9f);
+  o[0] = q[0] / c; o[1] = 0.f; o[2] = 0.f; o[3] = q[3] / c;
+}
+// quaternion_to_rotation_matrix (konia_transform.py:470-555): normalised with eps 1e-12 first
+GLAMR_HD void quat_to_rotmat(const float q[4], float R[9]) {
+  const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+  const float w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0f - (txx + tyy);
+}
+
 // heading quaternion of angle theta: angle_axis_to_quaternion((0, 0, theta))
 GLAMR_HD void heading_quat(float theta, float q[4]) {
   const float aa[3] = {0.f, 0.f, theta};

@@ -9,6 +9,7 @@ from .. import _lib
 from .layouts import INFILLER_LAYOUT, TRAJPRED_LAYOUT
 
 NETS_INFILL, NETS_TRAJ = 1, 2
+VAE_INFER, VAE_TRAIN, VAE_RECON = 0, 1, 2
 PAST, CUR, NZ = 10, 30, 128
 
 
@@ -75,3 +76,66 @@ class MotionPriorsHandle:
                                       _lib.ptr(out.get('pose')), _lib.ptr(out.get('local_traj')), _lib.ptr(out.get('trans')),
                                       _lib.ptr(out.get('orient')), flags, _lib.ptr(ws), _lib.current_stream()))
         return out
+
+
+    # -- training-mode / reconstruction passes (forward(data), inference(recon=True)) -----------------------------------------------------
+    def infiller_window(self, mode, in_body_pose, frame_mask, eps=None, body_pose=None, want_context=True):
+        """One 50-frame window per sequence through context encoder, (posterior encoder,) prior and decoder.  in_body_pose / body_pose
+        (B,50,69), frame_mask (B,50) 1 = visible, eps (B,128).  Returns dict: out_body_pose (B,30,69), p_z (B,2,128), z (B,128)
+        [, context (B,50,256), q_z (B,2,128)]."""
+        L = _lib.lib()
+        B = in_body_pose.shape[0]
+        dev = in_body_pose.device
+        if tuple(in_body_pose.shape[1:]) != (50, 69):
+            raise ValueError('the motion infiller takes windows of 50 frames (past 10 / current 30 / future 10), got %s' % (tuple(in_body_pose.shape),))
+        f = lambda t: None if t is None else t.to(dev).float().contiguous()
+        in_body_pose, frame_mask, eps, body_pose = f(in_body_pose), f(frame_mask), f(eps), f(body_pose)
+        out = {'out_body_pose': torch.empty((B, 30, 69), device=dev), 'p_z': torch.empty((B, 2, NZ), device=dev), 'z': torch.empty((B, NZ), device=dev)}
+        if want_context:
+            out['context'] = torch.empty((B, 50, 256), device=dev)
+        if mode != VAE_INFER:
+            out['q_z'] = torch.empty((B, 2, NZ), device=dev)
+        io = _lib.InfillerIO(_lib.ptr(in_body_pose), _lib.ptr(body_pose), _lib.ptr(frame_mask), _lib.ptr(eps), _lib.ptr(out.get('context')),
+                             _lib.ptr(out.get('q_z')), _lib.ptr(out['p_z']), _lib.ptr(out['z']), _lib.ptr(out['out_body_pose']))
+        ws = torch.empty(L.glamr_nets_workspace_bytes(self.h, B, 50), dtype=torch.uint8, device=dev)
+        _lib.check(L.glamr_nets_infiller_window(self.h, B, mode, ctypes.byref(io), _lib.ptr(ws), _lib.current_stream()))
+        return out
+
+    def traj_clip(self, mode, in_body_pose=None, in_joint_pos=None, trans=None, orient=None, eps=None, valid_len=0, init_row=None,
+                  want=('trans', 'orient', 'orient_q')):
+        """One clip per sequence through the trajectory predictor.  in_body_pose or in_joint_pos (B,T,69); trans / orient (B,T,3) for the
+        posterior encoder and the first output row; eps (B,128).  Returns dict of device tensors (batch-major)."""
+        L = _lib.lib()
+        src = in_body_pose if in_body_pose is not None else in_joint_pos
+        B, T = src.shape[:2]
+        dev = src.device
+        f = lambda t: None if t is None else t.to(dev).float().contiguous()
+        in_body_pose, in_joint_pos, trans, orient, eps, init_row = f(in_body_pose), f(in_joint_pos), f(trans), f(orient), f(eps), f(init_row)
+        out = {'out_local_traj': torch.empty((B, T, 11), device=dev), 'out_orig_local_traj': torch.empty((B, T, 11), device=dev),
+               'p_z': torch.empty((B, 2 * NZ), device=dev), 'z': torch.empty((B, NZ), device=dev)}
+        if trans is not None:
+            out['local_traj'] = torch.empty((B, T, 11), device=dev)
+        if mode != VAE_INFER:
+            out['q_z'] = torch.empty((B, 2 * NZ), device=dev)
+        for k, w in (('trans', 3), ('orient', 3), ('orient_q', 4)):
+            if k in want:
+                out['out_' + k] = torch.empty((B, T, w), device=dev)
+        io = _lib.TrajIO(_lib.ptr(in_body_pose), _lib.ptr(in_joint_pos), _lib.ptr(trans), _lib.ptr(orient), _lib.ptr(eps), _lib.ptr(init_row), int(valid_len),
+                         _lib.ptr(out.get('local_traj')), _lib.ptr(out.get('q_z')), _lib.ptr(out['p_z']), _lib.ptr(out['z']),
+                         _lib.ptr(out['out_orig_local_traj']), _lib.ptr(out['out_local_traj']), _lib.ptr(out.get('out_trans')),
+                         _lib.ptr(out.get('out_orient')), _lib.ptr(out.get('out_orient_q')))
+        ws = torch.empty(L.glamr_nets_workspace_bytes(self.h, B, T), dtype=torch.uint8, device=dev)
+        _lib.check(L.glamr_nets_traj_clip(self.h, B, T, mode, ctypes.byref(io), _lib.ptr(ws), _lib.current_stream()))
+        return out
+
+
+def local_to_global(local_traj):
+    """traj_local2global_heading on the device: local_traj (B,T,11) -> trans (B,T,3), orient axis-angle (B,T,3), orient quaternion (B,T,4)."""
+    L = _lib.lib()
+    local_traj = local_traj.float().contiguous()
+    B, T = local_traj.shape[:2]
+    dev = local_traj.device
+    trans, orient, q = torch.empty((B, T, 3), device=dev), torch.empty((B, T, 3), device=dev), torch.empty((B, T, 4), device=dev)
+    ws = torch.empty(L.glamr_traj_local_to_global_workspace_bytes(B, T), dtype=torch.uint8, device=dev)
+    _lib.check(L.glamr_traj_local_to_global(B, T, _lib.ptr(local_traj), _lib.ptr(trans), _lib.ptr(orient), _lib.ptr(q), _lib.ptr(ws), _lib.current_stream()))
+    return trans, orient, q

@@ -103,6 +103,54 @@ int glamr_nets_infer(glamr_nets* h, int n_seq, int max_len, const int32_t* lens,
                      float* out_pose, float* out_local_traj, float* out_trans, float* out_orient,
                      int flags, void* workspace, void* stream);
 
+/* Training-mode / reconstruction passes of the two VAEs -- what `forward(data)` and `inference(recon=True)` run:
+ *   MotionInfillerVAE.forward  motion_infiller/models/motion_infiller_vae.py:478-482 = ContextEncoder :92-123, DataEncoder (posterior)
+ *                              :126-249, DataDecoder in mode 'train' / 'recon' / 'infer' :345-433; one-shot inference :659-666
+ *   TrajPredVAE.forward        traj_pred/models/traj_pred_vae.py:378-382 = ContextEncoder :72-92, DataEncoder :95-199, DataDecoder :269-334;
+ *                              init_batch_data :396-457 (global -> local trajectory); one-shot and chunked inference :478-548
+ * The decoder mode selects the latent: INFER z = prior mu + eps sigma, TRAIN z = posterior mu + eps sigma, RECON z = posterior mu. */
+enum { GLAMR_VAE_INFER = 0, GLAMR_VAE_TRAIN = 1, GLAMR_VAE_RECON = 2 };
+
+typedef struct glamr_infiller_io {       /* one 50-frame window per sequence; all dev fp32 */
+  const float* in_body_pose;             /* (n_seq, 50, 69) in_body_pose_tp: the masked window the context encoder sees */
+  const float* body_pose;                /* (n_seq, 50, 69) body_pose_tp: the full window, posterior input (TRAIN / RECON), else NULL */
+  const float* frame_mask;               /* (n_seq, 50) 1 = frame visible; the key-padding mask is its complement (:497-499) */
+  const float* eps;                      /* (n_seq, 128) Gaussian draw (dist.py:21-23) for INFER / TRAIN, NULL for RECON */
+  float* context;                        /* out (n_seq, 50, 256) data['context'], or NULL */
+  float* q_z;                            /* out (n_seq, 2, 128) posterior mu, logvar (TRAIN / RECON), or NULL */
+  float* p_z;                            /* out (n_seq, 2, 128) prior mu, logvar, or NULL */
+  float* z;                              /* out (n_seq, 128) the latent the decoder used, or NULL */
+  float* out_body_pose;                  /* out (n_seq, 30, 69) the generated current frames [10, 40) */
+} glamr_infiller_io;
+/* workspace: glamr_nets_workspace_bytes(h, n_seq, 50) */
+int glamr_nets_infiller_window(glamr_nets* h, int n_seq, int mode, const glamr_infiller_io* io, void* workspace, void* stream);
+
+typedef struct glamr_traj_io {           /* one clip of T frames per sequence; all dev fp32 */
+  const float* in_body_pose;             /* (n_seq, T, 69): joints by forward kinematics (get_joint_pos :384-394), or NULL with in_joint_pos */
+  const float* in_joint_pos;             /* (n_seq, T, 69) joint positions handed over as they are, or NULL */
+  const float* trans;                    /* (n_seq, T, 3) root translation: posterior input + first row of the output (TRAIN / RECON), else NULL */
+  const float* orient;                   /* (n_seq, T, 3) root orientation, axis-angle, with trans */
+  const float* eps;                      /* (n_seq, 128) for INFER / TRAIN */
+  const float* init_row;                 /* (n_seq, 11) columns 0,1 (xy) and 9,10 (heading vector) pin the FIRST output row (DataDecoder :319-321 init_xy /
+                                            init_heading); NULL: the first row of local_traj when trans is given (:322-324), else zeros and (0, 1) (:325-327) */
+  int32_t valid_len;                     /* > 0: frames >= valid_len are zero-padded joint rows (get_seg_data :487-496), the networks still run over T */
+  float* local_traj;                     /* out (n_seq, T, 11) local_traj_tp = traj_global2local_heading(trans, orient), or NULL */
+  float* q_z;                            /* out (n_seq, 256) posterior mu | logvar, or NULL */
+  float* p_z;                            /* out (n_seq, 256) prior mu | logvar, or NULL */
+  float* z;                              /* out (n_seq, 128), or NULL */
+  float* out_orig_local_traj;            /* out (n_seq, T, 11) <mode>_orig_out_local_traj_tp (decoder output before the first row is pinned), or NULL */
+  float* out_local_traj;                 /* out (n_seq, T, 11) <mode>_out_local_traj_tp */
+  float* out_trans;                      /* out (n_seq, T, 3), or NULL */
+  float* out_orient;                     /* out (n_seq, T, 3) axis-angle, or NULL */
+  float* out_orient_q;                   /* out (n_seq, T, 4) quaternion (w, x, y, z), or NULL */
+} glamr_traj_io;
+/* workspace: glamr_nets_workspace_bytes(h, n_seq, T) */
+int glamr_nets_traj_clip(glamr_nets* h, int n_seq, int T, int mode, const glamr_traj_io* io, void* workspace, void* stream);
+/* traj_local2global_heading (traj_pred/utils/traj_utils.py:65-88) on its own: the chunked inference concatenates local rows first (:498-517) */
+size_t glamr_traj_local_to_global_workspace_bytes(int n_seq, int T);
+int glamr_traj_local_to_global(int n_seq, int T, const float* local_traj, float* out_trans, float* out_orient, float* out_orient_q,
+                               void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Fused global optimiser -- replaces GlobalReconOptimizer.forward/compute_loss/optimize_main
  * (global_recon/models/global_recon_model.py:394-570) and the residuals of global_recon/models/loss_func.py.

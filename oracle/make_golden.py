@@ -11,6 +11,7 @@ Fixture -> reference entry point:
   nets.npz      MotionInfillerVAE.inference / TrajPredVAE.inference / MotionTrajJointModel.inference with supplied latents
   grecon_<cfg>_T<T>_P<P>.npz   GlobalReconOptimizer.init_data, first-iteration losses + gradients, state after K Adam steps
   full_glamr_dynamic_T300.npz  GlobalReconOptimizer.optimize end to end (500 iterations), BASELINE.json configs[1]
+  full_glamr_dynamic_T300_family.npz   the same run under thread-count / 1e-7 / 1e-6 perturbations: the reference's own spread
 """
 import os
 import sys
@@ -168,6 +169,35 @@ def train_inputs(seed=0):
                 traj=dict(pose=traj, trans=trans))
 
 
+def multi_step_inputs(seed=0):
+    """Sequences longer than one window / chunk for the multi-step paths with reconstruction."""
+    rng = np.random.default_rng(999 + seed)
+    def clip(B, T):
+        t = np.arange(T)[None, :, None] / 30.0
+        pose = 0.3 * np.sin(2 * np.pi * rng.uniform(0.2, 0.8, size=(B, 1, 72)) * t + rng.uniform(0, 6.28, size=(B, 1, 72)))
+        pose[..., 0] += np.pi / 2
+        pose[..., 2] += 0.4 * t[..., 0]
+        return pose.astype(np.float32)
+    def walk(B, T):
+        tt = np.repeat(np.arange(T)[None, :, None] / 30.0, B, axis=0)
+        return np.concatenate([0.8 * np.sin(0.7 * tt + rng.uniform(0, 3, (B, 1, 1))), 1.1 * tt + 0.1 * np.cos(1.3 * tt), 0.9 + 0.03 * np.sin(5 * tt)], axis=-1).astype(np.float32)
+    tp = clip(2, 130)
+    traj = dict(pose=tp, trans=walk(2, 130), in_traj_latent=rng.normal(size=(2, 128)).astype(np.float32))
+    ip = clip(2, 85)
+    fm = np.ones((2, 85), np.float32)
+    fm[0, 20:45] = 0.0
+    fm[1, 50:70] = 0.0
+    infiller = dict(pose=ip, pose_mask=np.repeat(fm[..., None], 72, axis=-1), frame_mask=fm,
+                    in_motion_latent=rng.normal(size=(3, 128)).astype(np.float32))
+    jp = clip(1, 85)
+    fj = np.ones((1, 85), np.float32)
+    fj[0, 30:52] = 0.0
+    joint = dict(pose=jp, pose_mask=np.repeat(fj[..., None], 72, axis=-1), frame_mask=fj, trans=walk(1, 85),
+                 in_motion_latent=rng.normal(size=(3, 128)).astype(np.float32), in_traj_latent=rng.normal(size=(1, 128)).astype(np.float32),
+                 joint_pos_shape=np.zeros((1, 85, 69), np.float32))      # an AMASS batch carries it (amass_dataset.py); only handed through
+    return dict(traj=traj, infiller=infiller, joint=joint)
+
+
 def gen_nets_train():
     """forward(data) -- the training-mode pass (context encoder, posterior encoder, decoder in 'train' mode) -- and inference(recon=True)
     of both VAEs, from the unmodified reference.  The posterior sample is drawn by torch.randn_like under a fixed seed; the port draws
@@ -207,6 +237,21 @@ def gen_nets_train():
         for k in ('recon_out_trans', 'recon_out_orient', 'recon_out_local_traj_tp'):
             if k in d:
                 out['trj_' + k] = _np(d[k])
+        # chunked trajectory inference (inference_multi_step :508-519): 130 frames = one full chunk of 100 + one zero-padded chunk;
+        # sampled (supplied latent) and reconstructed
+        y = multi_step_inputs()
+        d = trj.inference({k: torch.tensor(v) for k, v in y['traj'].items()}, sample_num=1, recon=True, multi_step=True)
+        for k in ('infer_out_local_traj_tp', 'infer_out_trans', 'infer_out_orient', 'recon_out_local_traj_tp', 'recon_out_trans', 'recon_out_orient'):
+            out['trjms_' + k] = _np(d[k])
+        # sliding-window reconstruction of the infiller (inference_multi_step(recon=True) :618-632) on an 85-frame sequence
+        d = inf.inference({k: torch.tensor(v) for k, v in y['infiller'].items()}, sample_num=1, recon=True, multi_step=True)
+        for k in ('infer_out_body_pose', 'recon_out_body_pose', 'recon_out_pose'):
+            out['infms_' + k] = _np(d[k])
+        # the joint model with reconstruction (motion_traj_joint_model.py:141-145, pred_trajectory :73-133 incl. init_xy / init_heading)
+        d = mt.inference({k: torch.tensor(v) for k, v in y['joint'].items()}, sample_num=2, recon=True)
+        for k in ('infer_out_body_pose', 'infer_out_trans', 'infer_out_orient', 'infer_out_local_traj_tp', 'recon_out_body_pose', 'recon_out_trans',
+                  'recon_out_orient', 'recon_out_local_traj_tp'):
+            out['joint_' + k] = _np(d[k])
     np.savez_compressed(os.path.join(GOLD, 'nets_train.npz'), **out)
     print({k: v.shape for k, v in out.items()})
 
@@ -340,6 +385,46 @@ def gen_full(which=('gap', 'nogap')):
         print('full reference optimize() [%s]: %.1f s on %d threads' % (name, dt, torch.get_num_threads()))
 
 
+FAMILY = [('threads3', dict(threads=3)), ('threads8', dict(threads=8))] + \
+         [('eps%s_seed%d' % (name, sd), dict(eps=eps, seed=sd)) for name, eps in (('1e-7', 1e-7), ('1e-6', 1e-6)) for sd in (0, 1, 2)]
+
+
+def gen_full_family():
+    """The reference's OWN spread on BASELINE.json configs[1] with the detection gap: the unmodified reference re-run with another
+    intra-op thread count (different reduction order) and with its initial cam_pose multiplied by (1 + eps U(-1, 1)) right before the
+    optimiser is created (VERDICT r1 'What's weak' 1).  Members: projected keypoints + cameras; the tests hold the device path to this
+    envelope (tests/test_e2e_gpu.py)."""
+    import time
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    base = np.load(os.path.join(GOLD, 'full_glamr_dynamic_T300.npz'))
+    out = {}
+    keep_threads = torch.get_num_threads()
+    for name, opt in FAMILY:
+        torch.set_num_threads(opt.get('threads', keep_threads))
+        model, cfg = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
+        in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=md)
+        keep = model.init_opt
+
+        def init_opt(data, opt_variables, opt_lr, keep=keep, opt=opt):
+            if opt.get('eps'):
+                rng = np.random.RandomState(opt['seed'])
+                cp = data['cam_pose']
+                cp.mul_(torch.from_numpy((1 + opt['eps'] * rng.uniform(-1, 1, tuple(cp.shape))).astype(np.float32)))
+            return keep(data, opt_variables, opt_lr)
+        model.init_opt = init_opt
+        t0 = time.time()
+        data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 0))
+        kp = _np(data['person_data'][0]['kp_2d_pred'])
+        out[name + '_kp_2d_pred'] = kp
+        out[name + '_cam_pose'] = _np(data['cam_pose'])
+        d = np.abs(kp - base['p0_kp_2d_pred'])[base['p0_vis_frames']].max(axis=(1, 2))
+        print('family member %-16s %.0f s: max %.3f px, frames > 1 px %d, median %.4f px' % (name, time.time() - t0, d.max(), int((d > 1).sum()), np.median(d)))
+    torch.set_num_threads(keep_threads)
+    np.savez_compressed(os.path.join(GOLD, 'full_glamr_dynamic_T300_family.npz'), **out)
+
+
 EVAL_CASES = [('glamr_dynamic', 300, 1, '3DPW'), ('glamr_static_multi', 120, 2, '')]
 
 
@@ -395,7 +480,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'eval': gen_eval}[name]()
         print('done', name)
 
 

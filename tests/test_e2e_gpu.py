@@ -104,26 +104,41 @@ def test_full_schedule_300_frames_all_detected(make_model, golden):
     assert d_kp.max() < 0.25 and e_root < 5e-3
 
 
-def test_full_schedule_300_frames_detection_gap(make_model, golden):
-    """Same sequence with person 0 undetected in frames [100,160).  There the reference is ill conditioned: the first-iteration
-    gradients of the unseen frames are 1e-5..1e-2 (against 1e3..1e4 elsewhere, tests/golden grecon_*), Adam turns their SIGNS into
-    full +-lr steps, and a 1-ulp change of the initial camera poses moves the reference's own answer by 34 px in the frames before the
-    gap ('conditioning').  Every implementation whose arithmetic differs in the last bit lands in one of these solutions, so
-    this case is held to the solution QUALITY (reprojection error within 1% of the reference's) and to the typical frame."""
-    d_kp, e_root, ours, ref = _full_schedule(make_model, golden, '', None)
-    assert abs(ours - ref) < 0.01 * ref
-    assert np.median(d_kp) < 2.0
+def _family_envelope(golden):
+    """Spread of the UNMODIFIED reference on this input (oracle/make_golden.py gen_full_family): re-runs with another thread count and
+    with its initial cam_pose perturbed by 1e-7 stay within 0.05 px of the committed golden; 1e-6 perturbations push it into a
+    neighbouring solution (up to 9.4 px in 18 of 240 frames)."""
+    g = golden('full_glamr_dynamic_T300')
+    fam = golden('full_glamr_dynamic_T300_family')
+    vis = g['p0_vis_frames']
+    stats = {}
+    for key in fam:
+        if key.endswith('_kp_2d_pred'):
+            d = np.abs(fam[key] - g['p0_kp_2d_pred'])[vis].max(axis=(1, 2))
+            stats[key[:-len('_kp_2d_pred')]] = (float(d.max()), int((d > 1).sum()))
+    return stats
 
 
 def test_full_schedule_300_frames_detection_gap_host_init(make_model, golden):
-    """The numpy variant of init_data_batch (kept for cam_fix_frames other than the default) rounds like the reference's CPU
-    operators, so the optimiser starts from the reference's own initial state to the last bit.  Even so the ill-conditioned frames
-    decide by the kernel's rounding: with the 2.5-ulp division sequence this case ended in the reference's solution (0.069 px), with
-    single-instruction reciprocals (1 ulp) it ends in the neighbouring one -- the same one the device init path reaches.  Held to
-    the solution quality like the case above."""
+    """BASELINE.json configs[1] with person 0 undetected in frames [100,160), starting from the numpy variant of init_data_batch (rounds
+    like the reference's CPU operators: the reference's own initial state).  The reference holds 0.03-0.04 px under 1e-7 perturbations and
+    thread-count changes, so a start that is equal to the last bit must stay in its solution: VALUE BY VALUE, 0.1 px."""
     d_kp, e_root, ours, ref = _full_schedule(make_model, golden, '', None, host_init=True)
-    assert abs(ours - ref) < 0.01 * ref
-    assert np.median(d_kp) < 2.0
+    assert d_kp.max() < 0.1 and e_root < 5e-3
+
+
+def test_full_schedule_300_frames_detection_gap(make_model, golden):
+    """Same input through the default path (init_data on the device: initial arrays differ from the reference's by <= 8e-6).  Held to the
+    envelope of the reference's own perturbation family -- and, since the Adam update is torch's to the bit, it is in fact inside the
+    TIGHT part of it (the members that stay in the golden's solution)."""
+    stats = _family_envelope(golden)
+    tight = max(v[0] for k, v in stats.items() if k.startswith('threads') or '1e-7' in k)
+    loose_px = max(v[0] for v in stats.values())
+    loose_n = max(v[1] for v in stats.values())
+    d_kp, e_root, ours, ref = _full_schedule(make_model, golden, '', None)
+    print('reference family: tight members <= %.3f px; whole family <= %.2f px, <= %d frames above 1 px' % (tight, loose_px, loose_n))
+    assert d_kp.max() <= loose_px and int((d_kp > 1).sum()) <= loose_n          # the reference's envelope (VERDICT r1)
+    assert d_kp.max() < 0.25 and e_root < 5e-3                                  # and the same bound as the no-gap case
 
 
 def test_run_demo_entry_point(asset_root, tmp_path, monkeypatch):
