@@ -15,7 +15,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # grecon.hip: approximate (2.5 ulp) division / sqrt for the few `/` left outside rotmath's rcp_/sqrt_; no SLP vectorisation -- packing
 # pairs of fp32 operations (v_pk_fma_f32) costs as many register moves as it saves instructions and 36 more spilled registers
 # (stage launch 42.3 -> 39.2 ms at 1024 scenes)
-FILE_FLAGS = {'grecon.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize']}
+# init.hip: no fused multiply-adds -- init_data rounds like the reference's CPU operators (see rotmath.hpp, GLAMR_ROTMATH_IEEE)
+FILE_FLAGS = {'grecon.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize'], 'init.hip': ['-ffp-contract=off']}
 EXTRA_FLAGS = {k: v.split() for k, v in (kv.split('=', 1) for kv in os.environ.get('GLAMR_EXTRA_FLAGS', '').split(';') if kv)}
 
 

@@ -12,6 +12,7 @@
 //                        from the camera with separately interpolated heading / local orientation (:273-292, traj_utils.py:120-141)
 //   cam_all_frames_kernel  init_cam_pose(all_frames=True) (:243-244, :304-317) incl. its zero matrices where the first person is unseen
 #include "common.hpp"
+#define GLAMR_ROTMATH_IEEE 1      // see rotmath.hpp: this translation unit follows the reference's CPU operators as closely as fp32 allows
 #include "rotmath.hpp"
 
 namespace glamr {
@@ -60,24 +61,29 @@ __device__ void rotmat_to_rotvec_nearest(const float* Mf, float out[3]) {
 }
 
 // scipy interp1d(kind='linear', assume_sorted, fill_value='extrapolate') bracket of frame t among the frames with flag != 0
+// A single flagged frame (first == last; wire.py admits >= 2 detections but filter_pose can leave one) gives lo == hi: the lerp helpers
+// then return the value of that frame (constant extrapolation) instead of walking off the array.
 __device__ void bracket(const float* flag, int T, int first, int last, int t, int& lo, int& hi) {
+  if (first >= last) { lo = hi = first; return; }
   lo = t - 1;
   while (lo >= 0 && flag[lo] == 0.f) --lo;
   if (lo < 0) lo = first;                      // t <= first flagged frame: first two points
   if (lo == last) {                            // t beyond the last flagged frame: last two points
     hi = last;
     lo = last - 1;
-    while (flag[lo] == 0.f) --lo;
+    while (lo > first && flag[lo] == 0.f) --lo;
     return;
   }
   hi = lo + 1;
-  while (flag[hi] == 0.f) ++hi;
+  while (hi < last && flag[hi] == 0.f) ++hi;
 }
 __device__ __forceinline__ float lerp_f32(float ylo, float yhi, int lo, int hi, int t) {      // float32 abscissae (:134-135)
+  if (hi == lo) return ylo;
   const float slope = (yhi - ylo) / (float)(hi - lo);
   return slope * (float)(t - lo) + ylo;
 }
 __device__ __forceinline__ float lerp_f64(float ylo, float yhi, int lo, int hi, int t) {      // integer abscissae promote to double
+  if (hi == lo) return ylo;
   const double slope = ((double)yhi - (double)ylo) / (double)(hi - lo);                        // (traj_utils.py:130-135)
   return (float)(slope * (double)(t - lo) + (double)ylo);
 }

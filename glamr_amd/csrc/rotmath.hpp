@@ -26,7 +26,14 @@ namespace rm {
 // on gfx950 even with approximate division enabled (frexp / ldexp range scaffolding for denormal operands); every denominator of this
 // file and of the optimiser is a clamped norm, a depth, (sigma^2 + x^2) or sqrt(v) + 1e-8: normal-range numbers.  The CPU test
 // runtime (tests/hostsim) keeps the exact operations.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GLAMR_ROTMATH_IEEE)
+// init.hip (once per sequence, not a hot loop): IEEE reciprocal / root and the library sine / cosine.  The initial camera poses decide which
+// solution the optimiser of a sequence with a detection gap ends in -- the unmodified reference itself changes solution when they are
+// perturbed by 1e-6 (tests/golden/full_glamr_dynamic_T300_family.npz) -- so init_data is computed as closely to the reference's CPU
+// operators as fp32 allows (that translation unit is also built with -ffp-contract=off).
+GLAMR_HD float rcp_(float x) { return 1.0f / x; }
+GLAMR_HD float sqrt_(float x) { return sqrtf(x); }
+#elif defined(__HIP_DEVICE_COMPILE__)
 GLAMR_HD float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 GLAMR_HD float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
 #elif defined(GLAMR_HOSTSIM_ULP_NOISE)
@@ -91,6 +98,10 @@ GLAMR_HD float sqrt_rn_(float x) { return sqrtf(x); }
 // single-precision minimax polynomials (1 ulp on the reduced range).  The device library's sinf + cosf carry a Payne-Hanek
 // large-argument path each: about 700 of the 4 600 instructions of an optimiser iteration went there.  Same code on the host runtime.
 GLAMR_HD void sincos_(float x, float& s, float& c) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GLAMR_ROTMATH_IEEE)
+  s = sinf(x); c = cosf(x);
+  return;
+#endif
   const float k = rintf(x * 0.6366197466850281f);
   float r = fmaf(k, -1.5707963705062866f, x);
   r = fmaf(k, 4.371138828673793e-08f, r);

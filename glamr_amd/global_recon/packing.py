@@ -244,10 +244,11 @@ class PackedScenes:
                     d['cam_rot_6d_fix'], d['cam_trans_fix'] = conv(r6[:1]), conv(tr[:1])
                 else:
                     d['cam_rot_6d'], d['cam_trans'] = conv(r6[:Ts]), conv(tr[:Ts])
-            else:
-                empty = np.where(np.asarray(d['fr_num_persons']) == 0)[0]
-                d['cam_inv_rot_residual'] = conv(prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].reshape(T, 6)[empty])
-                d['cam_inv_trans_residual'] = conv(prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].reshape(T, 3)[:Ts])
+            # the residual tensors live in `data` from init_data on (:171-177) whatever the stages optimise: always written back, so a
+            # later optimize(continue_opt=True) restarts from them (the device path's _materialise does the same)
+            empty = np.where(np.asarray(d['fr_num_persons']) == 0)[0]
+            d['cam_inv_rot_residual'] = conv(prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].reshape(T, 6)[empty])
+            d['cam_inv_trans_residual'] = conv(prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].reshape(T, 3)[:Ts])
             for pi, idx in enumerate(self.person_ids[si]):
                 pd = d['person_data'][idx]
                 slot = si * P + pi

@@ -151,16 +151,32 @@ def check_case(runner, asset_root, golden, cfg_id, T, P, K):
         run(packed, sd, False)
         packed.unpack_into([data], spec, specs)
         has_wd = has_wd or 'world_dheading' in spec['opt_variables']
-    # free-running state after K steps per stage (tolerances as in tests/test_oracle_golden.py: Adam amplifies rounding noise
-    # along directions the loss does not see -- a gradient that is pure rounding noise still moves its parameter by +-lr per step, so
-    # two correct implementations drift apart by up to K * lr along those directions; 0.1-0.7 px after 10-25 steps at lr 0.01)
+    # free-running state after K steps per stage.  With the Adam update torch's to the bit (tests/test_adam_exact.py) the trajectories
+    # stay together; what is left are the sign flips of rounding-noise gradients along directions the loss does not see (a structurally
+    # zero gradient is +-1e-7 in both implementations and Adam turns its SIGN into a full +-lr step).  Bounds per case = 3 x what the
+    # kernel achieves, measured on the MI355X and the CPU runtime.
+    tol_kp, tol_tr, tol_rot = KSTEP_TOL[(cfg_id, T, P)]
+    worst = [0.0, 0.0, 0.0]
     for pi in range(P):
         pd = data['person_data'][pi]
         vis = g['init_p%d_vis_frames' % pi] & g['init_p0_vis_frames']
-        err = kp_err(pd['kp_2d_pred'].numpy(), g['opt_p%d_kp_2d_pred' % pi], vis)
-        assert err < 1.0, 'kp_2d_pred after optimisation: %g px' % err
+        worst[0] = max(worst[0], kp_err(pd['kp_2d_pred'].numpy(), g['opt_p%d_kp_2d_pred' % pi], vis))
         if cfg_id != 'glamr_3dpw':
-            err = np.abs(pd['root_trans_world'].numpy() - g['opt_p%d_root_trans_world' % pi]).max()
-            assert err < 1e-2, 'root_trans_world: %g' % err
-            err = _rot_err(pd['smpl_orient_world'].numpy(), g['opt_p%d_smpl_orient_world' % pi])
-            assert err < 1e-2, 'smpl_orient_world (as rotation): %g' % err
+            worst[1] = max(worst[1], float(np.abs(pd['root_trans_world'].numpy() - g['opt_p%d_root_trans_world' % pi]).max()))
+            worst[2] = max(worst[2], _rot_err(pd['smpl_orient_world'].numpy(), g['opt_p%d_smpl_orient_world' % pi]))
+    print('K-step state %s T=%d P=%d K=%d: kp %.4f px, root_trans_world %.2e, smpl_orient_world %.2e' % (cfg_id, T, P, K, *worst))
+    assert worst[0] < tol_kp, 'kp_2d_pred after optimisation: %g px' % worst[0]
+    assert worst[1] < tol_tr, 'root_trans_world: %g' % worst[1]
+    assert worst[2] < tol_rot, 'smpl_orient_world (as rotation): %g' % worst[2]
+
+
+# (projected keypoints px, root_trans_world m, smpl_orient_world as rotation) after K free-running Adam steps per stage
+KSTEP_TOL = {   # achieved (MI355X / CPU runtime):           kp px            root m            orientation
+    ('glamr_dynamic', 120, 1): (0.15, 1.5e-5, 3.5e-3),        # 0.009 / 0.046    3.9e-6 / 2.9e-6   1.0e-3 / 7.4e-4
+    ('glamr_static', 90, 1): (0.2, 3e-5, 6e-3),               # 0.064 / 0.046    9.7e-6 / 6.6e-7   2.0e-3 / 8.6e-4
+    ('glamr_static_multi', 120, 2): (0.01, 2e-5, 6e-4),       # 0.001 / 0.001    5.7e-6 / 2.2e-6   1.9e-4 / 1.8e-4
+    ('glamr_dynamic_multi', 100, 2): (0.15, 6e-4, 5e-3),      # 0.043 / 0.046    1.6e-4 / 1.8e-4   1.6e-3 / 1.6e-3
+    ('glamr_3dpw', 120, 1): (0.01, 1e-6, 1e-6),               # 0.002 / 0.002    (the person's world pose is not compared: the camera rides on it)
+    ('glamr_h36m', 100, 2): (0.55, 2e-5, 9e-4),               # 0.074 / 0.177    2.4e-6 / 5.0e-6   2.8e-4 / 2.6e-4
+    ('glamr_static_multi', 300, 4): (0.05, 6e-5, 1.1e-3),     # 0.012 / 0.015    1.2e-5 / 1.9e-5   3.5e-4 / 3.3e-4
+}

@@ -1,3 +1,6 @@
+"""DEVELOPMENT AID (GPU).  Perturbs the initial camera poses of THIS repository's numpy init path (not the reference) and reports how far
+the kernel's result moves.  The reference's own sensitivity is in tests/golden/full_glamr_dynamic_T300_family.npz (oracle/make_golden.py
+gen_full_family); round 1 mis-attributed this probe's output to the reference."""
 import os, sys, copy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
