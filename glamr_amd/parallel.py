@@ -38,6 +38,15 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def sum_over_ranks(value, device=None):
+    """Units all ranks processed (the numerator of the whole-job throughput)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def gather_results(local_results, dst=0):
     """Per-sequence result summaries (small python objects) collected on rank `dst` in global sequence order."""
     if not (dist.is_available() and dist.is_initialized()):
