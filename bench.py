@@ -354,7 +354,7 @@ def run(argv=None):
     tm = dict(model.timings)
     host_stream = None
     if hasattr(model, 'optimize_stream'):
-        nb = 4
+        nb = 6
         t0 = time.time()
         n_out = sum(len(r) for r in model.optimize_stream([in_dicts] * nb))
         host_stream = n_out / (time.time() - t0)

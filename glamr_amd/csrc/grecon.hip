@@ -8,6 +8,9 @@
 #include "common.hpp"
 #include "grecon_algo.hpp"
 #include "block_rt.hpp"
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 namespace glamr {
@@ -71,9 +74,8 @@ extern "C" int glamr_grecon_param_layout(int max_persons, int max_len, glamr_par
   return GLAMR_OK;
 }
 
-// workspace header: 256 bytes of launch stamps, then the per-iteration Adam scalars of the stage (2 floats per iteration)
-constexpr size_t GLAMR_GRECON_WS_STAMPS = 256;
-constexpr size_t GLAMR_GRECON_WS_HEADER = GLAMR_GRECON_WS_STAMPS + (size_t)ADAM_TAB_MAX * 2 * sizeof(float);
+// workspace header: the launch's clock stamps
+constexpr size_t GLAMR_GRECON_WS_HEADER = 256;
 
 extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len) {
   if (n_scenes <= 0 || max_persons < 1 || max_persons > 8 || max_len < 2) return 0;
@@ -106,13 +108,23 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   GLAMR_HIP_CHECK(hipMemsetAsync(static_cast<char*>(workspace) + 8, 0, 8, stream));
   ka.workspace = reinterpret_cast<float*>(static_cast<char*>(workspace) + GLAMR_GRECON_WS_HEADER);
   // Adam's step size and second-moment correction per iteration, in the reference's own arithmetic (Python doubles, libm pow): a
-  // running product on the device would differ in the last bit of the fp32 scalar now and then, and the update must not (rotmath.hpp)
+  // running product on the device would differ in the last bit of the fp32 scalar now and then, and the update must not (rotmath.hpp).
+  // One table per (device, lr, niters), uploaded the first time a stage with that schedule runs and kept for the life of the process:
+  // no per-launch host->device copy (a pageable copy on the launch stream would stall a pipelined host).
   ka.adam_tab = nullptr;
   if (stage->niters > 0 && stage->niters <= ADAM_TAB_MAX) {
-    std::vector<float> tab(2 * (size_t)stage->niters);
-    for (int i = 0; i < stage->niters; ++i) adam_coef_host(stage->lr, i + 1, &tab[2 * (size_t)i]);
-    float* dtab = reinterpret_cast<float*>(static_cast<char*>(workspace) + GLAMR_GRECON_WS_STAMPS);
-    GLAMR_HIP_CHECK(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, stream));   // pageable source: staged before the call returns
+    static std::mutex mu;
+    static std::map<std::tuple<int, double, int>, float*> tables;
+    int devid = 0;
+    GLAMR_HIP_CHECK(hipGetDevice(&devid));
+    std::lock_guard<std::mutex> lock(mu);
+    float*& dtab = tables[std::make_tuple(devid, stage->lr, (int)stage->niters)];
+    if (!dtab) {
+      std::vector<float> tab(2 * (size_t)stage->niters);
+      for (int i = 0; i < stage->niters; ++i) adam_coef_host(stage->lr, i + 1, &tab[2 * (size_t)i]);
+      GLAMR_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dtab), tab.size() * sizeof(float)));
+      GLAMR_HIP_CHECK(hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     ka.adam_tab = dtab;
   }
   ka.ws_floats_per_scene = align_up(scene_workspace_floats(batch->max_persons, batch->max_len), 64);

@@ -13,6 +13,7 @@ Division of labour:
     Adam iterations of all scenes (glamr_grecon_run_stage).
 There is no CPU path for the device part: a missing library or a non-HIP device raises.
 """
+import contextlib
 import time
 
 import numpy as np
@@ -40,10 +41,97 @@ def _cfg_parts(cfg):
     return cfg.grecon_model_specs, cfg.opt_stage_specs, getattr(cfg, 'id', 'glamr')
 
 
+_PERSON_KEYS = ('smpl_pose', 'smpl_beta', 'smpl_orient_cam', 'root_trans_cam', 'cam_K', 'traj_local_pred', 'smpl_orient_world_base',
+                'root_trans_world_base', 'smpl_orient_world', 'root_trans_world', 'kp_2d_pred', 'smpl_orient_cam_in_world', 'traj_local_xy',
+                'traj_local_heading', 'traj_local_dxy', 'traj_local_dheading', 'traj_local_z', 'traj_local_rot', 'visible', 'visible_orig',
+                'exist_frames', 'frames', 'vis_frames', 'invis_frames', 'frame2ind', 'kp_2d', 'kp_2d_aligned', 'kp_2d_score', 'person2cam')
+
+
 class ResidentInputs:
     """A batch of sequences in HBM as stage_inputs() leaves it: the HybrIK arrays on their frame rows (`g`), lengths, optional latent
     draws, plus the host-side bookkeeping (person ids, sequence names) that never needs the device."""
     pass
+
+
+class LazyDict(dict):
+    """A dictionary some of whose values are produced on first access (and then kept).  optimize_batch returns the reference's per-person
+    dictionaries (~40 arrays each); most consumers read a handful of them, so the slices of the batch arrays -- and
+    the ones that need a conversion (float64 copies of the masks and keypoints, 4 x 4 expansions, frame tables) -- are cut when somebody
+    asks.  Pending values come from per-key thunks (`lazy`) or from one `factory(key)` shared by the keys in `factory_keys`.  Behaves as
+    a plain dict otherwise: `in`, iteration, len, items(), pickling and equality see every key."""
+
+    def __init__(self, eager, lazy=(), factory=None, factory_keys=()):
+        super().__init__(eager)
+        self._lazy = dict(lazy)
+        self._factory, self._fkeys, self._gone = factory, factory_keys, None
+
+    def _pending(self, key):
+        return key in self._lazy or (key in self._fkeys and not dict.__contains__(self, key) and not (self._gone and key in self._gone))
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            value = self._lazy.pop(key)()
+        elif self._pending(key):
+            value = self._factory(key)
+        else:
+            raise KeyError(key)
+        dict.__setitem__(self, key, value)
+        return value
+
+    def _force(self):
+        for k in list(self._lazy):
+            self[k]
+        for k in self._fkeys:
+            if self._pending(k):
+                self[k]
+        return self
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or self._pending(key)
+
+    def __iter__(self):
+        return iter(self._force().keys())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy) + sum(1 for k in self._fkeys if self._pending(k) and k not in self._lazy)
+
+    def keys(self):
+        return dict.keys(self._force())
+
+    def values(self):
+        return dict.values(self._force())
+
+    def items(self):
+        return dict.items(self._force())
+
+    def __eq__(self, other):
+        return dict.__eq__(self._force(), other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self.pop(key)
+
+    def pop(self, key, *default):
+        if self._pending(key):
+            self[key]
+        if key in self._fkeys:
+            self._gone = (self._gone or set()) | {key}
+        return dict.pop(self, key, *default)
+
+    def copy(self):
+        return dict(self._force())
+
+    def __reduce__(self):
+        return (dict, (dict(self._force()),))
 
 
 class GlobalReconOptimizer:
@@ -276,15 +364,45 @@ class GlobalReconOptimizer:
     # ------------------------------------------------------------------------------------------------------------------------
     # device pipeline: the host only scatters the HybrIK arrays to their frame rows (pose_est/hybrik_demo/demo.py:317-354 layout)
     # ------------------------------------------------------------------------------------------------------------------------
+    def _staging(self, n_slots, T):
+        """Pinned host staging buffers for the HybrIK arrays, two sets used alternately (a set is rewritten only after the upload that
+        last used it has finished).  Rows of frames without a detection keep whatever an earlier batch left there: the device
+        preparation reads detection rows only (init.hip prep_person_kernel); `exist` and `K` are cleared because their other rows count."""
+        pool = self.__dict__.setdefault('_pinned', {'sets': [None, None], 'turn': 0})
+        i = pool['turn']
+        pool['turn'] = 1 - i
+        cur = pool['sets'][i]
+        widths = dict(exist=0, rot=216, betas=10, trans=3, kp=48, K=9)
+        if cur is None or cur['shape'] != (n_slots, T):
+            mk = lambda w: torch.zeros((n_slots, T, w) if w else (n_slots, T), dtype=torch.float32).pin_memory()
+            cur = {'shape': (n_slots, T), 't': {k: mk(w) for k, w in widths.items()}, 'event': None}
+            cur['np'] = {k: v.numpy() for k, v in cur['t'].items()}
+            pool['sets'][i] = cur
+        else:
+            if cur['event'] is not None:
+                cur['event'].synchronize()
+            cur['np']['exist'].fill(0.0)
+            cur['np']['K'].fill(0.0)
+        return cur
+
+    def _pool(self):
+        import concurrent.futures
+        p = self.__dict__.get('_thread_pool')
+        if p is None:
+            p = self.__dict__['_thread_pool'] = concurrent.futures.ThreadPoolExecutor(max_workers=4)
+        return p
+
     def stage_inputs(self, in_dicts, latents=None, validate=True):
-        """Host dictionaries -> HBM: checks them against the wire format (glamr_amd/utils/wire.py), scatters the per-detection
-        HybrIK arrays to their frame rows and uploads them (the ONLY host->device traffic of a batch).  Returns a ResidentInputs;
-        everything after this runs on device arrays."""
+        """Host dictionaries -> HBM: checks them against the wire format (glamr_amd/utils/wire.py: keys and shapes on the host, values --
+        finite numbers, orthonormal rotation matrices -- on the uploaded arrays, reported by check_inputs() / collect()), scatters the
+        per-detection HybrIK arrays to their frame rows in pinned staging buffers and uploads them asynchronously (the ONLY host->device
+        traffic of a batch).  Returns a ResidentInputs; everything after this runs on device arrays."""
         t0 = time.time()
         dev = self.device
         if validate:
             from glamr_amd.utils import wire
-            in_dicts = [dict(d, est=wire.normalise_est(d['est'])) for d in in_dicts]
+            for d in in_dicts:
+                wire.check_layout(d['est'])
         S = len(in_dicts)
         ids = [list(d['est'].keys()) for d in in_dicts]
         P = max(len(x) for x in ids)
@@ -293,11 +411,13 @@ class GlobalReconOptimizer:
         if P > 8:
             raise NotImplementedError('at most 8 persons per scene')
         n_slots = S * P
-        h = dict(exist=np.zeros((n_slots, T), np.float32), rot=np.zeros((n_slots, T, 216), np.float32), betas=np.zeros((n_slots, T, 10), np.float32),
-                 trans=np.zeros((n_slots, T, 3), np.float32), kp=np.zeros((n_slots, T, 48), np.float32), K=np.zeros((n_slots, T, 9), np.float32))
+        stg = self._staging(n_slots, T)
+        h = stg['np']
         seq_len_slot = np.zeros(n_slots, np.int32)
         lens = np.full(n_slots, 11, np.int32)
         exists = {}
+        fields = (('rot', 'smpl_pose_quat_wroot', 216), ('betas', 'smpl_beta', 10), ('trans', 'root_trans', 3), ('K', 'cam_K', 9))
+        jobs = []                                                  # (destination view, source view): the bulk copies, done by a few threads
         for si, d in enumerate(in_dicts):
             for pi, idx in enumerate(ids[si]):
                 src = d['est'][idx]
@@ -305,20 +425,34 @@ class GlobalReconOptimizer:
                 ex = np.asarray(src['bboxes_dict']['exist'])
                 vi = np.flatnonzero(ex)
                 exists[(si, idx)] = ex
-                seq_len_slot[k] = ex.shape[0]
+                n_fr, nv = ex.shape[0], vi.shape[0]
+                seq_len_slot[k] = n_fr
                 lens[k] = vi[-1] + 1 - vi[0]
-                h['exist'][k, :ex.shape[0]] = ex
-                h['rot'][k, vi] = src['smpl_pose_quat_wroot'].reshape(len(vi), 216)
-                h['betas'][k, vi] = src['smpl_beta']
-                h['trans'][k, vi] = src['root_trans']
-                h['kp'][k, vi] = src['kp_2d'][:, :24].reshape(len(vi), 48)
-                h['K'][k, vi] = src['cam_K'].reshape(len(vi), 9)
+                h['exist'][k, :n_fr] = ex
+                kp = np.asarray(src['kp_2d'])
+                if lens[k] == nv:                              # one run of detections: plain block copies
+                    a, b = int(vi[0]), int(vi[-1]) + 1
+                    jobs.append((h['rot'][k, a:b], np.asarray(src['smpl_pose_quat_wroot']).reshape(nv, 216)))
+                    for dst, key, w in fields[1:]:
+                        h[dst][k, a:b] = np.asarray(src[key]).reshape(nv, w)
+                    h['kp'][k, a:b] = kp[:, :24].reshape(nv, 48)
+                else:
+                    for dst, key, w in fields:
+                        h[dst][k, vi] = np.asarray(src[key]).reshape(nv, w)
+                    h['kp'][k, vi] = kp[:, :24].reshape(nv, 48)
+        if jobs:                                                   # 0.86 KB per frame of rotation matrices: numpy releases the GIL while it copies
+            def work(chunk):
+                for dst, srcv in chunk:
+                    dst[...] = srcv
+            nthr = min(4, len(jobs))
+            chunks = [jobs[i::nthr] for i in range(nthr)]
+            list(self._pool().map(work, chunks))
         rin = ResidentInputs()
         rin.S, rin.P, rin.T, rin.Ts, rin.ids, rin.lens, rin.exists = S, P, T, Ts, ids, lens, exists
-        rin.g = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
-        rin.n_persons = torch.tensor([len(x) for x in ids], dtype=torch.int32, device=dev)
-        rin.seq_len = torch.tensor(Ts, dtype=torch.int32, device=dev)
-        rin.seq_len_slot = torch.from_numpy(seq_len_slot).to(dev)
+        rin.g = {k: v.to(dev, non_blocking=True) for k, v in stg['t'].items()}
+        rin.n_persons = torch.tensor([len(x) for x in ids], dtype=torch.int32).to(dev, non_blocking=True)
+        rin.seq_len = torch.tensor(Ts, dtype=torch.int32).to(dev, non_blocking=True)
+        rin.seq_len_slot = torch.from_numpy(seq_len_slot).to(dev, non_blocking=True)
         rin.meps = rin.teps = None
         if latents is not None:
             nw = num_windows(int(lens.max()))
@@ -331,8 +465,39 @@ class GlobalReconOptimizer:
                     teps[si * P + pi] = np.asarray(latents[si][idx]['traj'], np.float32).reshape(-1)
             rin.meps, rin.teps = torch.from_numpy(meps).to(dev), torch.from_numpy(teps).to(dev)
         rin.meta = [{'seq_name': d['seq_name'], 'seq_len': Ts[si], 'gt': d.get('gt', {}), 'gt_meta': d.get('gt_meta', {})} for si, d in enumerate(in_dicts)]
+        # value checks of the wire format on the device (asynchronous; the verdict is read by check_inputs()): every number of a detection
+        # row finite, the 24 matrices of `smpl_pose_quat_wroot` orthonormal to 1e-2 (the field is named after quaternions, demo.py:320)
+        rin.verdict = None
+        if validate:
+            m = rin.g['exist'] != 0
+            R = rin.g['rot'].view(n_slots, T, 24, 3, 3)
+            dots = [(R[..., i, :] * R[..., j, :]).sum(-1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(i, 3)]
+            err = torch.stack(dots, -1).abs().amax(dim=(-1, -2))                                     # (n_slots, T)
+            fin = torch.stack([torch.isfinite(rin.g[k]).reshape(n_slots, T, -1).all(-1) for k in ('rot', 'betas', 'trans', 'kp', 'K')], -1).all(-1)
+            bad_rot = (m & ~(err <= 1e-2)).any(-1)
+            rin.verdict = torch.stack([bad_rot, (m & ~fin).any(-1)], 0)                              # (2, n_slots) on the device
+        # one event for "uploaded and checked", on the stream this call ran on: the staging set is rewritten only after it, a pipelined
+        # caller's compute stream waits for it, and check_inputs() reads the verdict after it
+        stg['event'] = torch.cuda.Event()
+        stg['event'].record()
+        rin.upload_done = stg['event']
         self.timings['host_pre'] = time.time() - t0
         return rin
+
+    def check_inputs(self, rin):
+        """Raises WireFormatError for the first person whose uploaded arrays failed the value checks (one small device->host copy)."""
+        if getattr(rin, 'verdict', None) is None:
+            return
+        from glamr_amd.utils import wire
+        rin.upload_done.synchronize()
+        v = rin.verdict.cpu().numpy()
+        rin.verdict = None
+        for kind, msg in ((0, 'smpl_pose_quat_wroot does not hold rotation matrices (|R R^T - I| > 1e-2); the field is named after quaternions but '
+                              'carries 24 x 3 x 3 matrices regrouped by 4 (demo.py:320)'), (1, 'an input array contains non-finite values')):
+            bad = np.flatnonzero(v[kind])
+            if bad.size:
+                si, pi = divmod(int(bad[0]), rin.P)
+                raise wire.WireFormatError('sequence %d (%s), person %r: %s' % (si, rin.meta[si]['seq_name'], rin.ids[si][pi] if pi < len(rin.ids[si]) else pi, msg))
 
     def init_resident(self, rin):
         """init_data (:76-248) on device-resident inputs: per-person preparation, motion priors, scene assembly, cached joints and
@@ -395,14 +560,38 @@ class GlobalReconOptimizer:
             return self.init_data_batch_host(in_dicts, latents)
         return self.init_resident(self.stage_inputs(in_dicts, latents))
 
-    def _materialise(self, datas, packed, stage_vars):
-        """Builds the reference-style output dictionaries (numpy) from the device arrays: ONE device->host copy per array."""
+    _FETCH = ('fr_start', 'fr_end', 'vis', 'kp_2d', 'kp_score', 'cam_K', 'traj_local_pred', 'orient_cam', 'base_orient', 'base_trans', 'person2cam',
+              'cam_pose', 'params', 'orient_world', 'trans_world', 'kp_2d_pred', 'orient_cam_in_world', 'losses')
+
+    def _fetch_async(self, packed, stream=None):
+        """Device -> pinned host copies of everything the output dictionaries are cut from, enqueued on `stream` (default: the current
+        one).  Returns (host arrays, event); the arrays are valid once the event has completed."""
+        src = {k: packed.t[k] for k in self._FETCH}
+        src.update({'pa_' + k: v for k, v in packed.person_arrays.items() if k not in ('nets_pose', 'nets_vis')})
+        if 'rel_transform_cam' in packed.t:
+            src['rel'] = packed.t['rel_transform_cam']
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        host = {}
+        with ctx:
+            for k, v in src.items():
+                hbuf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                hbuf.copy_(v, non_blocking=True)
+                host[k] = hbuf
+            ev = torch.cuda.Event()
+            ev.record()
+        return host, ev
+
+    def _materialise(self, datas, packed, stage_vars, fetched=None):
+        """Builds the reference-style output dictionaries (numpy) from the device arrays: ONE device->host copy per array; per person, plain
+        slices of the batch arrays right away and the converted ones (float64 masks / keypoints, 4 x 4 matrices, frame tables) on access."""
         P, T, l = packed.P, packed.T, packed.layout
-        names = ('fr_start', 'fr_end', 'vis', 'kp_2d', 'kp_score', 'cam_K', 'traj_local_pred', 'orient_cam', 'base_orient', 'base_trans', 'person2cam',
-                 'cam_pose', 'params', 'orient_world', 'trans_world', 'kp_2d_pred', 'orient_cam_in_world')
-        h = packed.fetch(names)
-        pa = {k: v.cpu().numpy() for k, v in packed.person_arrays.items() if k not in ('nets_pose', 'nets_vis')}
-        rel = packed.t['rel_transform_cam'].cpu().numpy() if 'rel_transform_cam' in packed.t else None
+        if fetched is None:
+            fetched = self._fetch_async(packed)
+        host, ev = fetched
+        ev.synchronize()
+        h = {k: v.numpy() for k, v in host.items()}
+        self.last_losses = h['losses']
+        rel = h.get('rel')
         eye_row = np.array([0, 0, 0, 1], np.float32)
 
         def to44(m12):
@@ -410,61 +599,82 @@ class GlobalReconOptimizer:
             out[..., :3, :] = m12.reshape(m12.shape[:-1] + (3, 4))
             out[..., 3, :] = eye_row
             return out
+        fr_start, fr_end = h['fr_start'].tolist(), h['fr_end'].tolist()
+        wd = 'world_dheading' in stage_vars
+        person_keys = _PERSON_KEYS + (('world_dheading',) if wd else ())
+
+        def person_factory(k, pi, si, Ts):
+            fs, fe = fr_start[k], fr_end[k]
+            n = fe - fs
+            pp = h['params'][si, l['person0'] + pi * l['person_stride']:l['person0'] + (pi + 1) * l['person_stride']]
+            frame = lambda name: (lambda: h[name][k, :Ts])
+            cut = {
+                'smpl_pose': frame('pa_smpl_pose'), 'smpl_beta': frame('pa_smpl_beta'), 'smpl_orient_cam': frame('orient_cam'), 'root_trans_cam': frame('pa_trans_cam'),
+                'cam_K': lambda: h['cam_K'][k, :Ts].reshape(Ts, 3, 3), 'traj_local_pred': lambda: h['traj_local_pred'][k, :n],
+                'smpl_orient_world_base': frame('base_orient'), 'root_trans_world_base': frame('base_trans'), 'smpl_orient_world': frame('orient_world'),
+                'root_trans_world': frame('trans_world'), 'kp_2d_pred': frame('kp_2d_pred'), 'smpl_orient_cam_in_world': frame('orient_cam_in_world'),
+                'traj_local_xy': lambda: pp[l['local_xy']:l['local_xy'] + 2], 'traj_local_heading': lambda: pp[l['local_heading']:l['local_heading'] + 1],
+                'traj_local_dxy': lambda: pp[l['local_dxy']:l['local_dxy'] + 2 * T].reshape(T, 2)[1:n],
+                'traj_local_dheading': lambda: pp[l['local_dheading']:l['local_dheading'] + T][1:n],
+                'traj_local_z': lambda: pp[l['local_z']:l['local_z'] + T][:n], 'traj_local_rot': lambda: pp[l['local_rot']:l['local_rot'] + 6 * T].reshape(T, 6)[:n],
+                'world_dheading': lambda: pp[l['world_dheading']:l['world_dheading'] + T][:Ts, None],
+                'visible': lambda: h['vis'][k, :Ts].astype(np.float64), 'visible_orig': lambda: h['pa_visible_orig'][k, :Ts].astype(np.float64),
+                'frames': lambda: np.arange(Ts), 'vis_frames': lambda: h['vis'][k, :Ts] == 1, 'invis_frames': lambda: h['vis'][k, :Ts] == 0,
+                'frame2ind': lambda: {f: f for f in range(Ts)},
+                'kp_2d': lambda: h['kp_2d'][k, :Ts].astype(np.float64), 'kp_2d_aligned': lambda: h['kp_2d'][k, :Ts].astype(np.float64),
+                'kp_2d_score': lambda: h['kp_score'][k, :Ts].astype(np.float64), 'person2cam': lambda: to44(h['person2cam'][k, :Ts]),
+            }
+
+            def exist_frames():
+                e = np.zeros(Ts, bool)
+                e[fs:fe] = True
+                return e
+            cut['exist_frames'] = exist_frames
+            return lambda key: cut[key]()
         for si, d in enumerate(datas):
             Ts = d['seq_len']
             persons = {}
+            vis_list = []
             for pi, idx in enumerate(packed.person_ids[si]):
                 k = si * P + pi
-                fs, fe = int(h['fr_start'][k]), int(h['fr_end'][k])
-                n = fe - fs
-                vis = h['vis'][k, :Ts]
-                visible = vis.astype(np.float64)
-                exist = np.zeros(Ts, bool)
-                exist[fs:fe] = True
-                pp = h['params'][si, l['person0'] + pi * l['person_stride']:l['person0'] + (pi + 1) * l['person_stride']]
-                pd = {
-                    'visible': visible, 'visible_orig': pa['visible_orig'][k, :Ts].astype(np.float64), 'fr_start': fs, 'fr_end': fe,
-                    'exist_frames': exist, 'exist_len': n, 'max_len': Ts, 'frames': np.arange(Ts), 'vis_frames': vis == 1, 'invis_frames': vis == 0,
-                    'frame2ind': {f: f for f in range(Ts)}, 'scale': None,
-                    'smpl_pose': pa['smpl_pose'][k, :Ts], 'smpl_beta': pa['smpl_beta'][k, :Ts], 'smpl_orient_cam': h['orient_cam'][k, :Ts],
-                    'root_trans_cam': pa['trans_cam'][k, :Ts], 'kp_2d': h['kp_2d'][k, :Ts].astype(np.float64),
-                    'kp_2d_score': h['kp_score'][k, :Ts].astype(np.float64), 'kp_2d_aligned': h['kp_2d'][k, :Ts].astype(np.float64),
-                    'cam_K': h['cam_K'][k, :Ts].reshape(Ts, 3, 3), 'infilled': True, 'traj_predicted': True,
-                    'traj_local_pred': h['traj_local_pred'][k, :n], 'smpl_orient_world_base': h['base_orient'][k, :Ts],
-                    'root_trans_world_base': h['base_trans'][k, :Ts], 'person2cam': to44(h['person2cam'][k, :Ts]),
-                    'smpl_orient_world': h['orient_world'][k, :Ts], 'root_trans_world': h['trans_world'][k, :Ts],
-                    'kp_2d_pred': h['kp_2d_pred'][k, :Ts], 'smpl_orient_cam_in_world': h['orient_cam_in_world'][k, :Ts],
-                    'traj_local_xy': pp[l['local_xy']:l['local_xy'] + 2].copy(), 'traj_local_heading': pp[l['local_heading']:l['local_heading'] + 1].copy(),
-                    'traj_local_dxy': pp[l['local_dxy']:l['local_dxy'] + 2 * T].reshape(T, 2)[1:n].copy(),
-                    'traj_local_dheading': pp[l['local_dheading']:l['local_dheading'] + T][1:n].copy(),
-                    'traj_local_z': pp[l['local_z']:l['local_z'] + T][:n].copy(),
-                    'traj_local_rot': pp[l['local_rot']:l['local_rot'] + 6 * T].reshape(T, 6)[:n].copy(),
-                }
-                if 'world_dheading' in stage_vars:
-                    pd['world_dheading'] = pp[l['world_dheading']:l['world_dheading'] + T][:Ts, None].copy()
-                persons[idx] = pd
-            cam = to44(h['cam_pose'][si, :Ts])
-            d['person_data'] = persons
-            d['cam_pose'] = cam
-            d['cam_pose_inv'] = nt.invert_transform(cam)
-            d['fr_num_persons'] = sum(p_['vis_frames'].astype(np.int64) for p_ in persons.values())
+                vis_list.append(h['vis'][k, :Ts])
+                eager = {'fr_start': fr_start[k], 'fr_end': fr_end[k], 'exist_len': fr_end[k] - fr_start[k], 'max_len': Ts, 'scale': None, 'infilled': True,
+                         'traj_predicted': True}
+
+                def factory(key, args=(k, pi, si, Ts), cache=[None]):
+                    if cache[0] is None:
+                        cache[0] = person_factory(*args)
+                    return cache[0](key)
+                persons[idx] = LazyDict(eager, factory=factory, factory_keys=person_keys)
             prm = h['params'][si]
+            eager = {'person_data': persons}
+            cam12 = h['cam_pose'][si, :Ts]
             if 'cam' in stage_vars:
                 r6 = prm[l['cam_rot6d']:l['cam_rot6d'] + 6 * T].reshape(T, 6)
                 tr = prm[l['cam_trans']:l['cam_trans'] + 3 * T].reshape(T, 3)
                 if self.specs.get('flag_fixed_cam', False):
-                    d['cam_rot_6d_fix'], d['cam_trans_fix'] = r6[:1].copy(), tr[:1].copy()
+                    eager['cam_rot_6d_fix'], eager['cam_trans_fix'] = r6[:1], tr[:1]
                 else:
-                    d['cam_rot_6d'], d['cam_trans'] = r6[:Ts].copy(), tr[:Ts].copy()
-            empty = np.where(d['fr_num_persons'] == 0)[0]
-            d['cam_inv_rot_residual'] = prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].reshape(T, 6)[empty].copy()
-            d['cam_inv_trans_residual'] = prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].reshape(T, 3)[:Ts].copy()
-            if rel is not None:
+                    eager['cam_rot_6d'], eager['cam_trans'] = r6[:Ts], tr[:Ts]
+            eager['cam_inv_trans_residual'] = prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].reshape(T, 3)[:Ts]
+
+            def num_persons(vis_list=vis_list):
+                return sum((v == 1).astype(np.int64) for v in vis_list)
+
+            def rot_residual(prm=prm, vis_list=vis_list):
+                empty = np.where(num_persons(vis_list) == 0)[0]
+                return prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].reshape(T, 6)[empty]
+
+            def rel_dict(si=si, Ts=Ts):
+                if rel is None:
+                    return {}
                 npers = len(packed.person_ids[si])
-                d['rel_transform_cam'] = {(i, j): to44(rel[si, i, j, :Ts]) for i in range(npers) for j in range(npers) if i != j}
-            else:
-                d['rel_transform_cam'] = {}
+                return {(i, j): to44(rel[si, i, j, :Ts]) for i in range(npers) for j in range(npers) if i != j}
+            lazy = {'cam_pose': (lambda c=cam12: to44(c)), 'cam_pose_inv': (lambda c=cam12: nt.invert_transform(to44(c))), 'fr_num_persons': num_persons,
+                    'cam_inv_rot_residual': rot_residual, 'rel_transform_cam': rel_dict}
             d.pop('_pending', None)
+            out = LazyDict(dict(d, **eager), lazy)
+            datas[si] = out
         return datas
 
     def _forward_only_desc(self):
@@ -513,20 +723,64 @@ class GlobalReconOptimizer:
         self.run_schedule(packed, max_iters)
         return datas, packed
 
-    def collect(self, datas, packed):
-        """Device arrays -> the reference's output dictionaries (numpy): one device->host copy per array."""
-        torch.cuda.synchronize(self.device)
+    def collect(self, datas, packed, fetched=None):
+        """Device arrays -> the reference's output dictionaries (numpy): one device->host copy per array.  Waits for this batch only."""
+        rin = packed.keepalive[0] if getattr(packed, 'keepalive', None) else None
+        if datas and datas[0].get('_pending'):
+            if fetched is None:
+                fetched = self._fetch_async(packed)
+            if rin is not None:
+                self.check_inputs(rin)
+            t0 = time.time()
+            self._materialise(datas, packed, self._all_vars(), fetched)
+        else:
+            torch.cuda.synchronize(self.device)
+            t0 = time.time()
+            all_vars = self._all_vars()
+            packed.unpack_into(datas, {'opt_variables': all_vars} if self.opt_stage_specs else None, self.specs, as_torch=False)
+            self.last_losses = packed.t['losses'].cpu().numpy()
         if getattr(self, 'kernel_ms', None) is not None and getattr(packed, 'stage_ws', None):
             self.kernel_ms.extend(self.launch_ms(ws) for ws in packed.stage_ws)
-        t0 = time.time()
-        all_vars = sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))
-        if datas and datas[0].get('_pending'):
-            self._materialise(datas, packed, all_vars)
-        else:
-            packed.unpack_into(datas, {'opt_variables': all_vars} if self.opt_stage_specs else None, self.specs, as_torch=False)
-        self.last_losses = packed.t['losses'].cpu().numpy()
         self.timings['unpack'] = time.time() - t0
         return datas
+
+    def _all_vars(self):
+        return sorted(set(v for s in self.opt_stage_specs.values() for v in s['opt_variables']))
+
+    def optimize_stream(self, batches, latents=None, max_iters=None):
+        """Host dictionaries in, host dictionaries out for a STREAM of batches (an iterable of lists of in_dicts): yields one list of
+        result dictionaries per batch, in order.  Software pipeline on the host thread: while the device runs batch i (asynchronous
+        launches on a compute stream), the host scatters and uploads batch i + 1 (copy stream, pinned staging) and cuts the output
+        dictionaries of batch i - 1 from its device->host copies (copy stream, after that batch's own event -- never a device-wide wait)."""
+        dev = self.device
+        compute = self.__dict__.setdefault('_compute_stream', torch.cuda.Stream(device=dev))
+        copy = self.__dict__.setdefault('_copy_stream', torch.cuda.Stream(device=dev))
+        it = iter(batches)
+        lat = iter(latents) if latents is not None else None
+
+        def stage(batch):
+            with torch.cuda.stream(copy):
+                return self.stage_inputs(batch, next(lat) if lat is not None else None)
+        nxt = next(it, None)
+        if nxt is None:
+            return
+        rin = stage(nxt)
+        prev = None
+        while rin is not None:
+            with torch.cuda.stream(compute):
+                compute.wait_event(rin.upload_done)
+                datas, packed = self.init_resident(rin)
+                self.run_schedule(packed, max_iters)
+                done = torch.cuda.Event()
+                done.record()
+            copy.wait_event(done)
+            fetched = self._fetch_async(packed, copy)                  # queued behind this batch only
+            nxt = next(it, None)
+            rin = stage(nxt) if nxt is not None else None              # host work under the device's
+            if prev is not None:
+                yield self.collect(*prev)
+            prev = (datas, packed, fetched)
+        yield self.collect(*prev)
 
     def optimize_batch(self, in_dicts, latents=None, max_iters=None):
         """Host dictionaries in, host dictionaries out (optimize() of the reference for a batch of independent sequences)."""

@@ -30,7 +30,9 @@ def _fail(pid, msg):
     raise WireFormatError('person %r: %s' % (pid, msg))
 
 
-def normalise_person(pid, src, check_rotations=True):
+def normalise_person(pid, src, check_rotations=True, check_values=True):
+    """check_values=False leaves the value checks (finite numbers, orthonormal rotations) to the caller: the batched device path runs them on
+    the uploaded arrays instead of person by person on the host (GlobalReconOptimizer.stage_inputs)."""
     for k in REQUIRED:
         if k not in src:
             _fail(pid, 'missing key %r (have %s)' % (k, sorted(src.keys())))
@@ -60,10 +62,10 @@ def normalise_person(pid, src, check_rotations=True):
     if kp.ndim != 3 or kp.shape[0] != n_vis or kp.shape[1] < 24 or kp.shape[2] != 2:
         _fail(pid, 'kp_2d must have shape (%d, >=24, 2), got %s' % (n_vis, kp.shape))
     out['kp_2d'] = kp
-    for key, a in list(out.items()):
+    for key, a in list(out.items()) if check_values else ():
         if not np.all(np.isfinite(a)):
             _fail(pid, '%s contains non-finite values' % key)
-    if check_rotations:
+    if check_rotations and check_values:
         R = rot.reshape(n_vis * 24, 3, 3)
         r = np.ascontiguousarray(R.reshape(-1, 9).T)                                       # nine component vectors: |R R^T - I| from the six row products
         dot = lambda i, j: r[3 * i] * r[3 * j] + r[3 * i + 1] * r[3 * j + 1] + r[3 * i + 2] * r[3 * j + 2]
@@ -88,13 +90,53 @@ def normalise_person(pid, src, check_rotations=True):
     return out
 
 
-def normalise_est(est, check_rotations=True):
+def check_layout(est):
+    """The structural half of normalise_est -- keys, shapes, the 0/1 detection mask, a common video length -- WITHOUT building the
+    normalised copies: the batched device path (GlobalReconOptimizer.stage_inputs) scatters straight from the producer's arrays and
+    checks the values on the device.  Returns the video length."""
+    if not isinstance(est, dict) or not est:
+        raise WireFormatError('est_dict must be a non-empty {person_id: dict}')
+    if len(est) > 8:
+        raise WireFormatError('at most 8 persons per sequence are supported (got %d)' % len(est))
+    n_fr = None
+    for pid, src in est.items():
+        for k in REQUIRED:
+            if k not in src:
+                _fail(pid, 'missing key %r (have %s)' % (k, sorted(src.keys())))
+        bb = src['bboxes_dict']
+        if 'exist' not in bb:
+            _fail(pid, "bboxes_dict has no 'exist' mask")
+        exist = np.asarray(bb['exist'])
+        if exist.ndim != 1 or exist.size < 2:
+            _fail(pid, "bboxes_dict['exist'] must be a 1-D mask over the video frames, got shape %s" % (exist.shape,))
+        n_vis = int(np.count_nonzero(exist))
+        if n_vis != int(np.count_nonzero(exist == 1)):
+            _fail(pid, "bboxes_dict['exist'] must hold 0/1 values")
+        if n_vis < 2:
+            _fail(pid, 'needs at least two detections to interpolate between (has %d)' % n_vis)
+        rot = src['smpl_pose_quat_wroot']
+        if np.shape(rot)[0] != n_vis or np.size(rot) != n_vis * 216:
+            _fail(pid, "smpl_pose_quat_wroot must hold 24 rotation matrices for each of the %d detections, got shape %s" % (n_vis, np.shape(rot)))
+        for key, tail in (('smpl_beta', (10,)), ('root_trans', (3,)), ('cam_K', (3, 3))):
+            if np.shape(src[key]) != (n_vis,) + tail:
+                _fail(pid, '%s must have shape %s, got %s' % (key, (n_vis,) + tail, np.shape(src[key])))
+        kps = np.shape(src['kp_2d'])
+        if len(kps) != 3 or kps[0] != n_vis or kps[1] < 24 or kps[2] != 2:
+            _fail(pid, 'kp_2d must have shape (%d, >=24, 2), got %s' % (n_vis, kps))
+        if n_fr is None:
+            n_fr = exist.size
+        elif exist.size != n_fr:
+            raise WireFormatError("all persons must share the video length; bboxes_dict['exist'] lengths differ (%d vs %d)" % (n_fr, exist.size))
+    return n_fr
+
+
+def normalise_est(est, check_rotations=True, check_values=True):
     """Validated copy of `est_dict`.  All persons must cover the same number of video frames (global_recon_model.py:85)."""
     if not isinstance(est, dict) or not est:
         raise WireFormatError('est_dict must be a non-empty {person_id: dict}')
     if len(est) > 8:
         raise WireFormatError('at most 8 persons per sequence are supported (got %d)' % len(est))
-    out = {pid: normalise_person(pid, src, check_rotations) for pid, src in est.items()}
+    out = {pid: normalise_person(pid, src, check_rotations, check_values) for pid, src in est.items()}
     lens = {pid: len(d['bboxes_dict']['exist']) for pid, d in out.items()}
     if len(set(lens.values())) != 1:
         raise WireFormatError("all persons must share the video length; bboxes_dict['exist'] lengths: %s" % lens)

@@ -70,3 +70,38 @@ def test_filter_pose_drops_orientation_jumps():
     Ora.filter_pose(Ora.__new__(Ora), ref)
     assert np.array_equal(d['visible'], ref['visible'].numpy())
     assert d['visible'].sum() < T
+
+
+def test_lazy_dict_is_a_dict_to_its_consumers():
+    """LazyDict (the per-person / per-sequence output dictionaries): values made on first access, every dict protocol sees all keys."""
+    import pickle
+    from glamr_amd.global_recon.models.global_recon_model import LazyDict
+    calls = []
+    d = LazyDict({'a': 1}, {'b': lambda: calls.append('b') or 2, 'c': lambda: calls.append('c') or 3})
+    assert 'b' in d and len(d) == 3 and calls == []
+    assert d['b'] == 2 and d['b'] == 2 and calls == ['b']                  # computed once
+    assert d.get('c') == 3 and d.get('zzz', 7) == 7
+    assert sorted(d.keys()) == ['a', 'b', 'c'] and dict(d) == {'a': 1, 'b': 2, 'c': 3} and d == {'a': 1, 'b': 2, 'c': 3}
+    e = LazyDict({}, {'x': lambda: 5})
+    e['x'] = 6                                                             # assignment wins over the pending value
+    assert e['x'] == 6 and len(e) == 1
+    f = LazyDict({'k': 0}, {'y': lambda: [1, 2]})
+    back = pickle.loads(pickle.dumps(f))
+    assert type(back) is dict and back == {'k': 0, 'y': [1, 2]}
+    g = LazyDict({'k': 0}, {'y': lambda: 1})
+    assert g.pop('y') == 1 and 'y' not in g
+    try:
+        g['nope']
+        assert False
+    except KeyError:
+        pass
+
+
+def test_lazy_dict_with_a_shared_factory():
+    from glamr_amd.global_recon.models.global_recon_model import LazyDict
+    made = []
+    d = LazyDict({'n': 3}, factory=lambda k: made.append(k) or k.upper(), factory_keys=('a', 'b'))
+    assert len(d) == 3 and 'a' in d and 'zz' not in d and made == []
+    assert d['a'] == 'A' and d['a'] == 'A' and made == ['a']
+    assert d.pop('b') == 'B' and 'b' not in d and len(d) == 2             # a popped key does not come back
+    assert dict(d) == {'n': 3, 'a': 'A'}
