@@ -148,7 +148,7 @@ def kernel_lines(asset_root, model, dev):
                           'write_gbs': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9, 1) if verts else None,
                           'frac_of_hbm_peak': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9 / HBM_PEAK_GBS, 3) if verts else None})
     out['smpl_lbs'] = {'flop_per_frame': SMPL_FLOP_PER_FRAME, 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'runs': lines}
-    # the two priors on 1024 sequences of 300 frames (GEMM-dominated: the split-bf16 MFMA kernels)
+    # the two priors on 1024 sequences of 300 frames (GEMM-dominated: the fp16-split MFMA kernels)
     md = synth.make_smpl_model()
     Bn, T = 1024, NUM_FRAMES
     pose = (torch.randn(Bn, T, 69, generator=g) * 0.2).to(dev)
@@ -158,7 +158,7 @@ def kernel_lines(asset_root, model, dev):
     dt = _timed(lambda: model.mt_model.infer_padded(pose, vis, [T] * Bn, meps, teps), reps=2)
     out['priors'] = {'sequences': Bn, 'frames': T, 'ms': round(dt * 1e3, 2), 'sequences_per_sec': round(Bn / dt, 1),
                      'tflops_fp32_equivalent': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12, 1), 'flop_per_sequence': NETS_FLOP_PER_SEQUENCE,
-                     'note': 'infiller (10 autoregressive windows) + trajectory predictor; fp32 results on the bf16 matrix cores by 3-way operand splitting'}
+                     'note': 'infiller (10 autoregressive windows) + trajectory predictor; fp32-grade results on the fp16 matrix cores by 2-way operand splitting (3 MFMAs per k step)'}
     # BASELINE configs[0]: one 120-frame clip through the infiller, then full skinning with vertices -- batched over 1024 clips
     T0 = 120
     pose0, vis0 = pose[:, :T0].contiguous(), vis[:, :T0].contiguous()

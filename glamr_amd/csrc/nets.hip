@@ -24,7 +24,7 @@ namespace {
 
 constexpr int D = 256, FF = 512, NZ = 128, WIN = 50, PAST = 10, CUR = 30, XLD = 96;
 
-struct Lin { float* W = nullptr; float* b = nullptr; int N = 0, K = 0; unsigned short* Ws = nullptr; };   // W: [Npad][K]; Ws: its three bf16 planes
+struct Lin { float* W = nullptr; float* b = nullptr; int N = 0, K = 0; unsigned short* Ws = nullptr; };   // W: [Npad][K]; Ws: its two fp16 planes
 struct LN { float* g = nullptr; float* b = nullptr; };
 struct EncLayer { Lin qkv, o, f1, f2; LN n1, n2; };
 struct DecLayer { Lin sa_qkv, sa_o, ca_q, ca_kv, ca_o, f1, f2; LN n1, n2, n3; };
@@ -83,25 +83,18 @@ int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
   int rc = upload(&L.W, f.data(), f.size());
   if (rc) return rc;
   {
-    // fp32 = hi + mid + lo in bf16 (round to nearest even each time; the remainders are exact in fp32)
-    auto bf16_rne = [](float x) -> unsigned short {
-      unsigned u; std::memcpy(&u, &x, 4);
-      u += 0x7FFFu + ((u >> 16) & 1u);
-      return (unsigned short)(u >> 16);
-    };
-    auto bf16_val = [](unsigned short h) -> float { unsigned u = (unsigned)h << 16; float x; std::memcpy(&x, &u, 4); return x; };
-    // fragment order of v_mfma_f32_32x32x16_bf16's B operand: [32-column block][16-deep k step][lane = column % 32 + 32 (k % 16 / 8)][k % 8]
-    std::vector<unsigned short> planes(3 * f.size());
+    // fp32 ~ hi + lo in fp16 (round to nearest even; the remainder is exact in fp32), see nn_kernels.hpp
+    auto f16_bits = [](float x) -> unsigned short { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
+    auto f16_val = [](float x) -> float { return (float)(_Float16)x; };
+    // fragment order of v_mfma_f32_32x32x16_f16's B operand: [32-column block][16-deep k step][lane = column % 32 + 32 (k % 16 / 8)][k % 8]
+    std::vector<unsigned short> planes(2 * f.size());
     const int ksteps = L.K / 16;
     for (int n = 0; n < Np; ++n)
       for (int k = 0; k < L.K; ++k) {
         const float x = f[(size_t)n * L.K + k];
-        const unsigned short h = bf16_rne(x);
-        const float r1 = x - bf16_val(h);
-        const unsigned short m = bf16_rne(r1);
-        const float r2 = r1 - bf16_val(m);
+        const float r1 = x - f16_val(x);
         const size_t dst = (((size_t)(n / 32) * ksteps + k / 16) * 64 + (n % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8;
-        planes[dst] = h; planes[f.size() + dst] = m; planes[2 * f.size() + dst] = bf16_rne(r2);
+        planes[dst] = f16_bits(x); planes[f.size() + dst] = f16_bits(r1);
       }
     if ((rc = upload(&L.Ws, planes.data(), planes.size()))) return rc;
   }
