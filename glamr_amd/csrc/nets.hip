@@ -294,13 +294,10 @@ Ws ws_layout(int B, int max_len, char* base) {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-// attention with the key count known at compile time where the model fixes it (a window of 50 frames, 30 current frames)
 template <class... A>
 void launch_attention(dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldk,
                       const unsigned char* mask, float* O, int ldo, int Lq, int Lk, int q_shared) {
-  if (Lk == WIN) hipLaunchKernelGGL(attention_kernel<WIN>, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
-  else if (Lk == CUR) hipLaunchKernelGGL(attention_kernel<CUR>, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
-  else hipLaunchKernelGGL(attention_kernel<0>, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
+  hipLaunchKernelGGL(attention_mfma_kernel, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
 }
 
 int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, int rows) {

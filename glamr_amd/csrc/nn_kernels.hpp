@@ -224,75 +224,145 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* X, cons
   *reinterpret_cast<f32x4*>(Y + (size_t)row * ld + lane * 4) = d * rstd * g + be;
 }
 
-// Multi-head attention for short sequences: 8 heads x 32 dims, Lq, Lk <= 64.  One 64-thread workgroup per (sequence, head);
-// thread i owns query i.  Q rows at Q[(b*Lq + i)*ldq + h*32], K/V rows at K[(b*Lk + j)*ldk + h*32].
-// key_mask[b*Lk + j] != 0 -> key j is ignored (PyTorch key_padding_mask).  A fully masked row yields zeros.
-template <int LK>
-__global__ __launch_bounds__(64) void attention_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
-                                                       float* O, int ldo, int Lq, int Lk_rt, int q_shared) {
-  // LK > 0: the key count is a compile-time constant -- both key loops are unrolled, the scores stay in registers and the LDS
-  // footprint drops from 35 KB to 18 KB (8 workgroups per CU instead of 4); LK == 0: any Lk <= 64, scores through LDS
-  constexpr bool STATIC = LK > 0;
-  const int Lk = STATIC ? LK : Lk_rt;
-  // rows padded to 36 floats: 16-byte aligned, so a key / value row is fetched with eight broadcast ds_read_b128
-  __shared__ __attribute__((aligned(16))) float sK[64][36], sV[64][36];
-  __shared__ float sS[STATIC ? 1 : 64][64];          // scores [key][query] when the loops are not unrolled (a dynamically indexed private array would live in scratch)
-  float sreg[STATIC ? LK : 1];
-  __shared__ unsigned char sM[64];                  // key-padding mask of this sequence (a global byte load per key would serialise the loop)
-  const int b = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
-  if (i < Lk) sM[i] = key_mask ? key_mask[(size_t)b * Lk + i] : 0;
-  for (int idx = i; idx < Lk * 8; idx += 64) {
+// Multi-head attention for short sequences on the matrix cores: 8 heads x 32 dims, Lq, Lk <= 64; ONE wave per (sequence, head).
+//   S^T = K Q^T / sqrt(32)   A = K rows (m = key), B = Q rows (n = query)        -> lane owns a QUERY column, its 16 registers per tile are keys
+//   softmax over the keys    = over the lane's own registers + ONE exchange with lane ^ 32 (the other half of the rows)
+//   O^T = V^T P^T            A = V columns (m = dim, from LDS), B = P^T straight from the score registers: the MFMA sums over its 16 k slots
+//                            in any order, so the k slots are DEFINED as the keys the score registers already hold (slot j of half g =
+//                            key 32 t + 16 u + (j & 3) + 8 (j >> 2) + 4 g) and V is gathered from LDS in that order -- no transposition
+// fp32 operands as two fp16 planes, three v_mfma_f32_32x32x16_f16 per product (see the GEMM above): 48 MFMAs per head instead of
+// ~50 x 50 x 64 scalar FMAs per query lane.  Q rows at Q[(b*Lq + i)*ldq + h*32] (q_shared: the same Lq rows for every sequence), K / V rows
+// at K[(b*Lk + j)*ldk + h*32]; key_mask[b*Lk + j] != 0 -> key j is ignored (PyTorch key_padding_mask); a fully masked row yields zeros.
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(x[i] - (float)h);
+  }
+}
+__device__ __forceinline__ f32x16 mfma3(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
+                                                            float* O, int ldo, int Lq, int Lk, int q_shared) {
+  __shared__ __attribute__((aligned(16))) float sV[64][36];      // rows padded to 36 floats: float4 stores, conflict-free column reads
+  __shared__ unsigned char sM[64];
+  const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, c = lane & 31, kg = lane >> 5;
+  for (int idx = lane; idx < 64 * 8; idx += 64) {
     const int j = idx >> 3, d4 = (idx & 7) * 4;
-    *reinterpret_cast<f32x4*>(&sK[j][d4]) = *reinterpret_cast<const f32x4*>(K + (size_t)(b * Lk + j) * ldk + h * 32 + d4);
-    *reinterpret_cast<f32x4*>(&sV[j][d4]) = *reinterpret_cast<const f32x4*>(V + (size_t)(b * Lk + j) * ldk + h * 32 + d4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (j < Lk) v = *reinterpret_cast<const f32x4*>(V + (size_t)(b * Lk + j) * ldk + h * 32 + d4);
+    *reinterpret_cast<f32x4*>(&sV[j][d4]) = v;
   }
-  __syncthreads();
-  if (i >= Lq) return;
-  float q[32];
-  const float* qp = Q + (size_t)((q_shared ? 0 : b * Lq) + i) * ldq + h * 32;
-  const float scale = 0.17677669529663687f;        // 1 / sqrt(32)
+  sM[lane] = (lane < Lk) ? (key_mask ? key_mask[(size_t)b * Lk + lane] : 0) : 1;
+  const bool two_k = Lk > 32, two_q = Lq > 32;
+  // operand fragments: 8 consecutive dims (16 s + 8 kg ...) of row (32 tile + c)
+  auto row_frag = [&](const float* base, int ld, int row, int nrows, int s, float scale, f16x8& hi, f16x8& lo) {
+    float x[8];
+    if (row < nrows) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + h * 32 + 16 * s + 8 * kg);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + h * 32 + 16 * s + 8 * kg + 4);
 #pragma unroll
-  for (int d = 0; d < 32; d += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(qp + d);
-    q[d] = v[0] * scale; q[d + 1] = v[1] * scale; q[d + 2] = v[2] * scale; q[d + 3] = v[3] * scale;
-  }
-  float mx = -INFINITY;
+      for (int i = 0; i < 4; ++i) { x[i] = u[i] * scale; x[4 + i] = w[i] * scale; }
+    } else {
 #pragma unroll
-  for (int j = 0; j < Lk; ++j) {
-    // four interleaved partial sums: a single accumulator would be a 32-deep dependent chain per key
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-      const f32x4 kv = *reinterpret_cast<const f32x4*>(&sK[j][d]);
-      s0 = fmaf(q[d], kv[0], s0); s1 = fmaf(q[d + 1], kv[1], s1); s2 = fmaf(q[d + 2], kv[2], s2); s3 = fmaf(q[d + 3], kv[3], s3);
+      for (int i = 0; i < 8; ++i) x[i] = 0.f;
     }
-    float s = (s0 + s1) + (s2 + s3);
-    if (sM[j]) s = -INFINITY;
-    if (STATIC) sreg[j] = s; else sS[j][i] = s;
-    mx = fmaxf(mx, s);
+    split8(x, hi, lo);
+  };
+  const float* Kb = K + (size_t)b * Lk * ldk;
+  const float* Qb = Q + (q_shared ? (size_t)0 : (size_t)b * Lq * ldq);
+  f16x8 kh_[2][2], kl_[2][2], qh_[2][2], ql_[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (t == 0 || two_k) row_frag(Kb, ldk, 32 * t + c, Lk, s, 1.0f, kh_[t][s], kl_[t][s]);
+      if (t == 0 || two_q) row_frag(Qb, ldq, 32 * t + c, Lq, s, 0.17677669529663687f, qh_[t][s], ql_[t][s]);
+    }
+  f32x16 sc[2][2];                                  // [key tile][query tile]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      sc[kt][qt] = (f32x16){0};
+      if ((kt == 0 || two_k) && (qt == 0 || two_q)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) sc[kt][qt] = mfma3(kh_[kt][s], kl_[kt][s], qh_[qt][s], ql_[qt][s], sc[kt][qt]);
+      }
+    }
+  __syncthreads();                                  // sV / sM visible
+  // softmax over the keys of each query column
+  float inv[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    inv[qt] = 0.f;
+    if (qt == 1 && !two_q) continue;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two_k) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const float v = sM[key] ? -INFINITY : sc[kt][qt][r];
+        sc[kt][qt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two_k) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = (mx > -INFINITY) ? __expf(sc[kt][qt][r] - mx) : 0.f;
+        sc[kt][qt][r] = p;
+        den += p;
+      }
+    }
+    den += __shfl_xor(den, 32);
+    inv[qt] = den > 0.f ? 1.0f / den : 0.f;
   }
-  float o[32];
+  // O^T = V^T P^T
+  f32x16 oc[2] = {(f32x16){0}, (f32x16){0}};
 #pragma unroll
-  for (int d = 0; d < 32; ++d) o[d] = 0.f;
-  float den = 0.f;
-  if (mx > -INFINITY) {
+  for (int kt = 0; kt < 2; ++kt) {
+    if (kt == 1 && !two_k) continue;
 #pragma unroll
-    for (int j = 0; j < Lk; ++j) {
-      const float p = expf((STATIC ? sreg[j] : sS[j][i]) - mx);
-      den += p;
+    for (int u = 0; u < 2; ++u) {
+      float vx[8];
 #pragma unroll
-      for (int d = 0; d < 32; d += 4) {
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(&sV[j][d]);
-        o[d] = fmaf(p, vv[0], o[d]); o[d + 1] = fmaf(p, vv[1], o[d + 1]); o[d + 2] = fmaf(p, vv[2], o[d + 2]); o[d + 3] = fmaf(p, vv[3], o[d + 3]);
+      for (int j = 0; j < 8; ++j) vx[j] = sV[32 * kt + 16 * u + (j & 3) + 8 * (j >> 2) + 4 * kg][c];
+      f16x8 vh, vl;
+      split8(vx, vh, vl);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        if (qt == 1 && !two_q) continue;
+        float px[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) px[j] = sc[kt][qt][8 * u + j];
+        f16x8 ph, pl;
+        split8(px, ph, pl);
+        oc[qt] = mfma3(vh, vl, ph, pl, oc[qt]);
       }
     }
   }
-  const float inv = den > 0.f ? 1.0f / den : 0.f;
-  float* op = O + (size_t)(b * Lq + i) * ldo + h * 32;
 #pragma unroll
-  for (int d = 0; d < 32; d += 4) {
-    const f32x4 v = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
-    *reinterpret_cast<f32x4*>(op + d) = v;
+  for (int qt = 0; qt < 2; ++qt) {
+    const int query = 32 * qt + c;
+    if ((qt == 1 && !two_q) || query >= Lq) continue;
+    float* op = O + (size_t)(b * Lq + query) * ldo + h * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {oc[qt][4 * g] * inv[qt], oc[qt][4 * g + 1] * inv[qt], oc[qt][4 * g + 2] * inv[qt], oc[qt][4 * g + 3] * inv[qt]};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * kg) = v;
+    }
   }
 }
 
