@@ -314,6 +314,7 @@ def run(argv=None):
     t0 = time.time()
     for i in range(args.steps):
         step(i)
+    enqueue = time.time() - t0                                       # host time to ENQUEUE the timed steps (launch-bound if close to `elapsed`)
     sync()
     if world > 1:
         dist.barrier()
@@ -378,7 +379,7 @@ def run(argv=None):
             'metric': 'sequences/sec (300-frame, 1-person) end-to-end global_recon', 'value': n_total * args.steps / elapsed,
             'unit': 'sequences/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.mode, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'host_enqueue_ms_per_step': enqueue / args.steps * 1e3,
             'config': {'workload': ('BASELINE configs[1]: %d-frame 1-person dynamic-camera sequences, cfg %s (%d Adam iterations), batch of %d independent '
                                     'sequences per GPU, HybrIK arrays resident in HBM' % (NUM_FRAMES, CFG_ID, iters, B)) if args.mode == 'weak' else
                                    ('BASELINE configs[2]: %d independent %d-frame 1-person sequences (cfg %s, %d iterations) split over %d GPU(s): %d per GPU '

@@ -114,7 +114,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * TN;
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  All column
+  // blocks of one 128-row block of the activations run on the SAME XCD (linear id -> xcd = id % 8 -> row block 8 * group + xcd), so the
+  // tile of X is fetched into one L2 once instead of once per column block.
+  const int ncb = gridDim.x, lin = blockIdx.y * ncb + blockIdx.x;
+  const int grp = lin / (8 * ncb), within = lin % (8 * ncb);
+  const int rb = grp * 8 + (within & 7), cb = within >> 3;
+  if (rb * 128 >= a.M) return;
+  const int m0 = rb * 128, n0 = cb * TN;
   const int ksteps = a.K / 16;
   f32x16 acc[2][WN];
 #pragma unroll
@@ -520,9 +527,9 @@ inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, 
     a.ws_plane = (size_t)npad * K;
     const bool narrow_only = std::getenv("GLAMR_GEMM_NARROW") != nullptr;      // development aid: 128x64 tiles only (116 registers)
     if (!narrow_only && npad % 128 == 0 && (size_t)(M / 128) * (npad / 128) >= 512)
-      hipLaunchKernelGGL((gemm_split_kernel<2>), dim3(npad / 128, (M + 127) / 128), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((gemm_split_kernel<2>), dim3(npad / 128, ((M + 127) / 128 + 7) / 8 * 8), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((gemm_split_kernel<1>), dim3(npad / 64, (M + 127) / 128), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((gemm_split_kernel<1>), dim3(npad / 64, ((M + 127) / 128 + 7) / 8 * 8), dim3(256), 0, st, a);
     return GLAMR_OK;
   }
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M), dim3(256), 0, st, a);
