@@ -304,9 +304,35 @@ int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, in
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, R, n.g, n.b, Y, rows, D);
   return GLAMR_OK;
 }
+constexpr int FUSE_MIN_ROWS = 2048;      // below this the launches are latency-bound either way: separate small-M kernels
+// Y = LayerNorm(X W^T + b + R): attention out-projection + residual + norm in one pass over the rows
+int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const float* R, float* Y, float* tmp, int M);
+// Y = [LayerNorm](act2(relu(X W1^T + b1) W2^T + b2) [+ R]): feed-forward block / two-layer MLP with the hidden rows on chip
+int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float* X, int ldx, const float* R, float* Y, float* hidden, float* tmp, int M,
+         int act2);
+
 int lin(hipStream_t st, const Lin& L, const float* X, int ldx, float* Y, int ldy, int M, int act = ACT_NONE, const float* R = nullptr, int ldr = 0,
         const float* rowbias = nullptr, int rpg = 1, int ldrb = 0) {
   return launch_gemm(st, X, ldx, L.W, L.b, Y, ldy, M, L.N, L.K, act, R, ldr, rowbias, rpg, ldrb, L.Ws);
+}
+
+int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const float* R, float* Y, float* tmp, int M) {
+  static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;      // development aid: the separate GEMM + LayerNorm launches
+  if (!no_fuse && M >= FUSE_MIN_ROWS && L.N == D && L.K == D && L.Ws)
+    return launch_rows(st, X, D, M, D, nullptr, 0, nullptr, nullptr, 1, 0, L.Ws, (size_t)D * L.K, L.K, L.b, ACT_NONE, R, D, n.g, n.b, Y, D);
+  RC(lin(st, L, X, D, tmp, D, M));
+  return ln(st, tmp, R, n, Y, M);
+}
+int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float* X, int ldx, const float* R, float* Y, float* hidden, float* tmp, int M,
+         int act2) {
+  static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;
+  if (!no_fuse && M >= FUSE_MIN_ROWS && L1.N == FF && L2.N == D && L2.K == FF && L1.K <= D && L1.Ws && L2.Ws)
+    return launch_rows(st, X, ldx, M, L1.K, L1.Ws, (size_t)FF * L1.K, L1.b, nullptr, 1, 0, L2.Ws, (size_t)D * L2.K, L2.K, L2.b, act2, R, D,
+                       n ? n->g : nullptr, n ? n->b : nullptr, Y, D);
+  RC(lin(st, L1, X, ldx, hidden, FF, M, ACT_RELU));
+  if (!n) return lin(st, L2, hidden, FF, Y, D, M, act2, R, D);
+  RC(lin(st, L2, hidden, FF, tmp, D, M, act2));
+  return ln(st, tmp, R, *n, Y, M);
 }
 
 }  // namespace
@@ -508,11 +534,8 @@ int encoder_layer(hipStream_t st, const EncLayer& E, Ws& w, float* h_in, float* 
   const int M = B * WIN;
   RC(lin(st, E.qkv, h_in, D, w.qkv, 3 * D, M));
   launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, w.mask, w.att, D, WIN, WIN, 0);
-  RC(lin(st, E.o, w.att, D, w.tmp, D, M));
-  RC(ln(st, w.tmp, h_in, E.n1, h_out, M));
-  RC(lin(st, E.f1, h_out, D, w.ff, FF, M, ACT_RELU));
-  RC(lin(st, E.f2, w.ff, FF, w.tmp, D, M));
-  RC(ln(st, w.tmp, h_out, E.n2, h_out, M));
+  RC(proj_ln(st, E.o, E.n1, w.att, h_in, h_out, w.tmp, M));
+  RC(mlp2(st, E.f1, E.f2, &E.n2, h_out, D, h_out, h_out, w.ff, w.tmp, M, ACT_NONE));
   return GLAMR_OK;
 }
 
@@ -521,16 +544,12 @@ int decoder_layer(hipStream_t st, const DecLayer& Dl, Ws& w, float* x, const flo
   const int M = B * Lq;
   RC(lin(st, Dl.sa_qkv, x, D, w.qkv, 3 * D, M));
   launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, (const unsigned char*)nullptr, w.att, D, Lq, Lq, 0);
-  RC(lin(st, Dl.sa_o, w.att, D, w.tmp, D, M));
-  RC(ln(st, w.tmp, x, Dl.n1, x, M));
+  RC(proj_ln(st, Dl.sa_o, Dl.n1, w.att, x, x, w.tmp, M));
   RC(lin(st, Dl.ca_q, x, D, w.qbuf, D, M));
   RC(lin(st, Dl.ca_kv, ctx, D, w.ctxkv, 2 * D, B * WIN));
   launch_attention( dim3(B, 8), dim3(64), 0, st, w.qbuf, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, Lq, WIN, 0);
-  RC(lin(st, Dl.ca_o, w.att, D, w.tmp, D, M));
-  RC(ln(st, w.tmp, x, Dl.n2, x, M));
-  RC(lin(st, Dl.f1, x, D, w.ff, FF, M, ACT_RELU));
-  RC(lin(st, Dl.f2, w.ff, FF, w.tmp, D, M));
-  RC(ln(st, w.tmp, x, Dl.n3, x, M));
+  RC(proj_ln(st, Dl.ca_o, Dl.n2, w.att, x, x, w.tmp, M));
+  RC(mlp2(st, Dl.f1, Dl.f2, &Dl.n3, x, D, x, x, w.ff, w.tmp, M, ACT_NONE));
   return GLAMR_OK;
 }
 
@@ -720,8 +739,7 @@ int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const
   hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(D), 0, st, w.zproj, h->dec_pe, w.dq);
   RC(decoder_layer(st, h->dec[0], w, w.dq, ctx, B, CUR));
   RC(decoder_layer(st, h->dec[1], w, w.dq, ctx, B, CUR));
-  RC(lin(st, h->out1, w.dq, D, w.ff, FF, B * CUR, ACT_RELU));
-  RC(lin(st, h->out2, w.ff, FF, w.tmp, D, B * CUR, ACT_RELU));
+  RC(mlp2(st, h->out1, h->out2, nullptr, w.dq, D, nullptr, w.tmp, w.ff, w.tmp, B * CUR, ACT_RELU));
   RC(lin(st, h->outfc, w.tmp, D, w.y, 128, B * CUR));
   return GLAMR_OK;
 }
@@ -739,14 +757,12 @@ void bilstm(glamr_nets* h, hipStream_t st, const float* G, float* const hh[2], c
 int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const int* lens_run, int mode, const float* eps, float* q_out, float* p_out,
               const float* init, int ldinit, float* out_orig, float* out_local, float* out_trans, float* out_orient, float* out_orient_q) {
   const int MT = B * max_len;
-  RC(lin(st, h->t_in1, w.tx, XLD, w.tg, FF, MT, ACT_RELU));
-  RC(lin(st, h->t_in2, w.tg, FF, w.th, D, MT, ACT_RELU));
+  RC(mlp2(st, h->t_in1, h->t_in2, nullptr, w.tx, XLD, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU));
   for (int l = 0; l < 2; ++l) {
     RC(lin(st, h->t_ih[l], w.th, D, w.tg, 1024, MT));
     bilstm(h, st, w.tg, h->t_hh[l], lens_run, w.th, max_len, B);
   }
-  RC(lin(st, h->t_out1, w.th, D, w.tg, FF, MT, ACT_RELU));
-  RC(lin(st, h->t_out2, w.tg, FF, w.th, D, MT, ACT_RELU));          // context [B][max_len][256]
+  RC(mlp2(st, h->t_out1, h->t_out2, nullptr, w.th, D, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU));          // context [B][max_len][256]
   if (mode != GLAMR_VAE_INFER) {
     // posterior (DataEncoder.forward :160-199): [t_h, aa(q_h)] -> in_mlp -> 2 bi-LSTM -> out_mlp; fused with the context, mean over time
     RC(lin(st, h->te_in1, w.e6, 32, w.tg, FF, MT, ACT_RELU));

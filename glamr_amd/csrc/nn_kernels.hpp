@@ -231,6 +231,171 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* X, cons
   *reinterpret_cast<f32x4*>(Y + (size_t)row * ld + lane * 4) = d * rstd * g + be;
 }
 
+// ---- fused row-block layers: activations stay on chip between the GEMMs of a block ------------------------------------------------
+// The priors' linear layers are K = 256 / 512 deep: as separate GEMMs each is an HBM round trip of its activations (52 MB in, 52-157 MB
+// out per 51 200 rows) and the matrix pipe idles 80 % of the time.  This kernel keeps a block of 64 rows in LDS through a whole
+// sub-block of a transformer / MLP layer, with the full 256-wide output row in ONE workgroup so LayerNorm can follow in the epilogue:
+//   ONE layer :  Y = [LN]( act(X W2^T + b2) + R )                                   e.g. attention out-projection + residual + LayerNorm
+//   TWO layers:  H = relu(X W1^T + b1 [+ row bias]),  Y = [LN]( act(H W2^T + b2) + R )   feed-forward block (hidden 512 in two 256-column halves,
+//                                                                                     never leaving LDS), the MLPs of the trajectory predictor
+// X tile and hidden tile live in LDS as two fp16 planes (hi, lo; rows padded by 16 B: conflict-free ds_read_b128), i.e. directly as MFMA A
+// operands -- no per-k-step conversion; weights come from L2 in fragment order as in gemm_split_kernel, one k step ahead.  8 waves, each
+// owning 2 row tiles x 1 column tile of the 64 x 256 output (and of each hidden half).  LayerNorm arithmetic = add_layernorm_kernel.
+struct RowsArgs {
+  const float* X; int ldx, M, K1;                     // input rows [M][K1] (K1 multiple of 32, <= 256 with two layers, <= 512 with one)
+  const unsigned short* W1s; size_t w1_plane;         // layer 1 weight planes (N = 512, K = K1), null for ONE layer
+  const float* b1; const float* rowbias; int rpg, ldrb;
+  const unsigned short* W2s; size_t w2_plane; int K2; // layer 2 (or the only layer): N = 256, K = K2 (512 after a hidden layer, else K1)
+  const float* b2; int act2;
+  const float* R; int ldr;                            // residual rows (added after act2) or null
+  const float* gamma; const float* beta;              // LayerNorm over the 256 outputs, or null
+  float* Y; int ldy;
+};
+
+template <bool TWO>
+__global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NJ = 1;                                             // 8 waves: one 32-column tile each (x 2 row tiles)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, kg = lane >> 5;
+  const int m0 = blockIdx.x * 64;
+  const int K1 = a.K1, XS = (K1 + 8) * 2;                         // bytes per row of one X plane
+  constexpr int HS = (256 + 8) * 2;                               // bytes per row of one hidden plane
+  unsigned char* sX = smem;                                       // [2][64][XS]
+  unsigned char* sH = smem + 2 * 64 * XS;                         // [2][64][HS]; later the fp32 output rows [64][260]
+  float* sOut = reinterpret_cast<float*>(sH);
+  // ---- X tile -> planes ---------------------------------------------------------------------------------------------------------
+  for (int f = tid; f < 64 * (K1 / 4); f += 512) {
+    const int row = f / (K1 / 4), c4 = (f % (K1 / 4)) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + c4);
+    unsigned h0, l0, h1, l1;
+    split2((f32x2){v[0], v[1]}, h0, l0);
+    split2((f32x2){v[2], v[3]}, h1, l1);
+    *reinterpret_cast<uint2*>(sX + row * XS + c4 * 2) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(sX + 64 * XS + row * XS + c4 * 2) = make_uint2(l0, l1);
+  }
+  __syncthreads();
+  // one GEMM phase: acc[i][j] += A(rows 32 i.., K) * W(cols of this wave's tiles j, k range) with A planes in LDS
+  auto phase = [&](const unsigned char* sA, int AS, int ksteps_here, const unsigned short* Ws, size_t plane, int ksteps_w, int kstep0, int nb0, f32x16 (&acc)[2][NJ]) {
+    const uint4* wf[2][NJ];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wf[p][j] = reinterpret_cast<const uint4*>(Ws + p * plane) + ((size_t)(nb0 + j) * ksteps_w + kstep0) * 64 + lane;
+    // weight fragments THREE k steps ahead (a wave has one other wave on its SIMD to hide an L2 round trip behind: 3 x 6 MFMAs do)
+    uint4 vb[4][2][NJ];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (d < ksteps_here) vb[d][p][j] = wf[p][j][(size_t)d * 64];
+    for (int ks = 0; ks < ksteps_here; ks += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kstep = ks + u;
+        if (kstep >= ksteps_here) break;
+        if (kstep + 3 < ksteps_here) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) vb[(u + 3) & 3][p][j] = wf[p][j][(size_t)(kstep + 3) * 64];
+        }
+        f16x8 xa[2][2], xb[2][NJ];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) xa[p][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + p * 64 * AS + (i * 32 + c) * AS + kstep * 32 + kg * 16));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) xb[p][j] = __builtin_bit_cast(f16x8, vb[u][p][j]);
+        }
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[PA[term]][i], xb[PB[term]][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  f32x16 acc2[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc2[i][j] = (f32x16){0};
+  if (TWO) {
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x16 acc1[2][NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc1[i][j] = (f32x16){0};
+      phase(sX, XS, K1 / 16, a.W1s, a.w1_plane, K1 / 16, 0, hh * 8 + wave * NJ, acc1);
+      if (hh) __syncthreads();                                    // everybody is done reading the previous hidden half
+      // hidden half -> planes: lane owns column n, rows (q & 3) + 8 (q >> 2) + 4 kg of each tile
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int nloc = (wave * NJ + j) * 32 + c, n = hh * 256 + nloc;
+        const float b = a.b1 ? a.b1[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+            float v = acc1[i][j][q] + b;
+            if (a.rowbias) v += a.rowbias[(size_t)(min(m0 + row, a.M - 1) / a.rpg) * a.ldrb + n];
+            v = fmaxf(v, 0.0f);
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            *reinterpret_cast<_Float16*>(sH + row * HS + nloc * 2) = h;
+            *reinterpret_cast<_Float16*>(sH + 64 * HS + row * HS + nloc * 2) = l;
+          }
+      }
+      __syncthreads();
+      phase(sH, HS, 16, a.W2s, a.w2_plane, a.K2 / 16, hh * 16, wave * NJ, acc2);
+    }
+  } else {
+    phase(sX, XS, K1 / 16, a.W2s, a.w2_plane, a.K2 / 16, 0, wave * NJ, acc2);
+  }
+  __syncthreads();                                                // sH is free: output rows go there
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = (wave * NJ + j) * 32 + c;
+    const float b = a.b2 ? a.b2[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        float v = acc2[i][j][q] + b;
+        if (a.act2 == ACT_RELU) v = fmaxf(v, 0.0f);
+        sOut[row * 260 + n] = v;
+      }
+  }
+  __syncthreads();
+  // rows out: one wave per row, 4 columns per lane (coalesced 1 KB rows); residual and LayerNorm as add_layernorm_kernel
+  for (int row = wave; row < 64; row += 8) {
+    const int m = m0 + row;
+    if (m >= a.M) break;
+    f32x4 v = *reinterpret_cast<const f32x4*>(sOut + row * 260 + lane * 4);
+    if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + (size_t)m * a.ldr + lane * 4);
+    if (a.gamma) {
+      float s_ = v[0] + v[1] + v[2] + v[3];
+      for (int off = 32; off > 0; off >>= 1) s_ += __shfl_xor(s_, off);
+      const float mean = s_ * (1.0f / 256.0f);
+      const f32x4 d = v - mean;
+      float q_ = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+      for (int off = 32; off > 0; off >>= 1) q_ += __shfl_xor(q_, off);
+      const float rstd = 1.0f / sqrtf(q_ * (1.0f / 256.0f) + 1e-5f);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + lane * 4), be = *reinterpret_cast<const f32x4*>(a.beta + lane * 4);
+      v = d * rstd * g + be;
+    }
+    *reinterpret_cast<f32x4*>(a.Y + (size_t)m * a.ldy + lane * 4) = v;
+  }
+}
+
+inline size_t rows_fused_lds(int K1) { return (size_t)2 * 64 * (K1 + 8) * 2 + (size_t)2 * 64 * (256 + 8) * 2; }
+
 // Multi-head attention for short sequences on the matrix cores: 8 heads x 32 dims, Lq, Lk <= 64; ONE wave per (sequence, head).
 //   S^T = K Q^T / sqrt(32)   A = K rows (m = key), B = Q rows (n = query)        -> lane owns a QUERY column, its 16 registers per tile are keys
 //   softmax over the keys    = over the lane's own registers + ONE exchange with lane ^ 32 (the other half of the rows)
@@ -533,6 +698,27 @@ inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, 
     return GLAMR_OK;
   }
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M), dim3(256), 0, st, a);
+  return GLAMR_OK;
+}
+
+// ONE layer (W1s == nullptr) or TWO layers on row blocks, see rows_fused_kernel.  Output width is 256.
+inline int launch_rows(hipStream_t st, const float* X, int ldx, int M, int K1, const unsigned short* W1s, size_t w1_plane, const float* b1,
+                       const float* rowbias, int rpg, int ldrb, const unsigned short* W2s, size_t w2_plane, int K2, const float* b2, int act2,
+                       const float* R, int ldr, const float* gamma, const float* beta, float* Y, int ldy) {
+  if (M <= 0) return GLAMR_OK;
+  if (K1 % 32 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || (W1s && (K1 > 256 || K2 != 512)) || (!W1s && (K1 > 256 || K2 != K1)))
+    return fail(GLAMR_E_INVALID, "fused rows: unsupported shape K1=%d K2=%d", K1, K2);
+  RowsArgs a{X, ldx, M, K1, W1s, w1_plane, b1, rowbias, rpg, ldrb, W2s, w2_plane, K2, b2, act2, R, ldr, gamma, beta, Y, ldy};
+  const size_t lds = rows_fused_lds(K1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(GLAMR_E_HIP, "hipFuncSetAttribute(rows_fused_kernel) failed");
+    attr_done = true;
+  }
+  if (W1s) hipLaunchKernelGGL(rows_fused_kernel<true>, dim3((M + 63) / 64), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(rows_fused_kernel<false>, dim3((M + 63) / 64), dim3(512), lds, st, a);
   return GLAMR_OK;
 }
 
