@@ -304,7 +304,11 @@ int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, in
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, R, n.g, n.b, Y, rows, D);
   return GLAMR_OK;
 }
-constexpr int FUSE_MIN_ROWS = 2048;      // below this the launches are latency-bound either way: separate small-M kernels
+constexpr int FUSE_MIN_ROWS = 2048;
+inline bool fuse_attention(int M) {
+  static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE_ATTN") != nullptr || std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;      // development aid
+  return !no_fuse && M >= FUSE_MIN_ROWS;
+}      // below this the launches are latency-bound either way: separate small-M kernels
 // Y = LayerNorm(X W^T + b + R): attention out-projection + residual + norm in one pass over the rows
 int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const float* R, float* Y, float* tmp, int M);
 // Y = [LayerNorm](act2(relu(X W1^T + b1) W2^T + b2) [+ R]): feed-forward block / two-layer MLP with the hidden rows on chip
@@ -532,8 +536,13 @@ namespace {
 
 int encoder_layer(hipStream_t st, const EncLayer& E, Ws& w, float* h_in, float* h_out, int B) {
   const int M = B * WIN;
-  RC(lin(st, E.qkv, h_in, D, w.qkv, 3 * D, M));
-  launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, w.mask, w.att, D, WIN, WIN, 0);
+  if (fuse_attention(M)) {
+    const size_t pl = (size_t)3 * D * D;
+    RC(launch_qkv_attention(st, B, QkvAttnArgs{h_in, WIN, h_in, WIN, E.qkv.Ws, pl, E.qkv.b, 0, E.qkv.Ws, pl, E.qkv.b, 8, 16, w.mask, w.att, D}));
+  } else {
+    RC(lin(st, E.qkv, h_in, D, w.qkv, 3 * D, M));
+    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, w.mask, w.att, D, WIN, WIN, 0);
+  }
   RC(proj_ln(st, E.o, E.n1, w.att, h_in, h_out, w.tmp, M));
   RC(mlp2(st, E.f1, E.f2, &E.n2, h_out, D, h_out, h_out, w.ff, w.tmp, M, ACT_NONE));
   return GLAMR_OK;
@@ -542,12 +551,22 @@ int encoder_layer(hipStream_t st, const EncLayer& E, Ws& w, float* h_in, float* 
 // x: [B][Lq][256] queries (in place), ctx keys/values already projected into w.ctxkv ([B][WIN][512]) by the caller
 int decoder_layer(hipStream_t st, const DecLayer& Dl, Ws& w, float* x, const float* ctx, int B, int Lq) {
   const int M = B * Lq;
-  RC(lin(st, Dl.sa_qkv, x, D, w.qkv, 3 * D, M));
-  launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, (const unsigned char*)nullptr, w.att, D, Lq, Lq, 0);
+  if (fuse_attention(M)) {
+    const size_t pl = (size_t)3 * D * D;
+    RC(launch_qkv_attention(st, B, QkvAttnArgs{x, Lq, x, Lq, Dl.sa_qkv.Ws, pl, Dl.sa_qkv.b, 0, Dl.sa_qkv.Ws, pl, Dl.sa_qkv.b, 8, 16, nullptr, w.att, D}));
+  } else {
+    RC(lin(st, Dl.sa_qkv, x, D, w.qkv, 3 * D, M));
+    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, (const unsigned char*)nullptr, w.att, D, Lq, Lq, 0);
+  }
   RC(proj_ln(st, Dl.sa_o, Dl.n1, w.att, x, x, w.tmp, M));
-  RC(lin(st, Dl.ca_q, x, D, w.qbuf, D, M));
-  RC(lin(st, Dl.ca_kv, ctx, D, w.ctxkv, 2 * D, B * WIN));
-  launch_attention( dim3(B, 8), dim3(64), 0, st, w.qbuf, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, Lq, WIN, 0);
+  if (fuse_attention(M)) {
+    RC(launch_qkv_attention(st, B, QkvAttnArgs{x, Lq, ctx, WIN, Dl.ca_q.Ws, (size_t)D * D, Dl.ca_q.b, 0, Dl.ca_kv.Ws, (size_t)2 * D * D, Dl.ca_kv.b, 0, 8, w.mask,
+                                               w.att, D}));
+  } else {
+    RC(lin(st, Dl.ca_q, x, D, w.qbuf, D, M));
+    RC(lin(st, Dl.ca_kv, ctx, D, w.ctxkv, 2 * D, B * WIN));
+    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qbuf, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, Lq, WIN, 0);
+  }
   RC(proj_ln(st, Dl.ca_o, Dl.n2, w.att, x, x, w.tmp, M));
   RC(mlp2(st, Dl.f1, Dl.f2, &Dl.n3, x, D, x, x, w.ff, w.tmp, M, ACT_NONE));
   return GLAMR_OK;

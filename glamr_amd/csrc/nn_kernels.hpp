@@ -538,6 +538,196 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* Q, int 
   }
 }
 
+// ---- QKV projection + attention in one pass: Q, K, V never exist in memory ---------------------------------------------------------
+// One workgroup per sequence, one wave per head (8 x 32).  The rows of the sequence sit in LDS as fp16 planes (MFMA operands).  The
+// projections are computed in the ORIENTATION the attention MFMAs consume, so nothing is transposed through LDS:
+//   Q^T_h = W_q,h X^T  (A = weight fragment: lane = dim, B = row fragment: lane = token)  -> lane owns a TOKEN, its 16 registers are dims
+//   K^T_h likewise.  S^T = K Q^T contracts over the 32 dims in any order, so the k slots of that MFMA are DEFINED as the dims the
+//   registers hold (slot j of step u, half g = dim 16 u + (j & 3) + 8 (j >> 2) + 4 g) -- for both operands alike.
+//   V_h = X W_v,h^T      (A = row fragment: lane = token, B = weight fragment: lane = dim)  -> lane owns a DIM, registers are tokens in
+//   exactly the key order the probabilities come out of the softmax in: the A operand of O^T = V^T P^T as it stands.
+// Self-attention: Xq = Xkv.  Cross-attention: queries from the decoder rows, keys / values from the context rows.  Saves the write and
+// re-read of the (3 x 256)-wide QKV rows (157 + 157 MB per 51 200 rows) and a launch per attention block.
+struct QkvAttnArgs {
+  const float* Xq; int Lq;                       // [B][Lq][256] rows the queries are projected from
+  const float* Xkv; int Lk;                      // [B][Lk][256] rows the keys / values are projected from (== Xq for self-attention)
+  const unsigned short* Wq; size_t wq_plane; const float* bq; int q_nb0;       // fragment-ordered planes holding the query projection; its first 32-column block
+  const unsigned short* Wkv; size_t wkv_plane; const float* bkv; int k_nb0, v_nb0;
+  const unsigned char* mask;                     // [B][Lk] key-padding mask or null
+  float* O; int ldo;                             // [B][Lq][256]
+};
+
+__global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int XS = (256 + 8) * 2;                               // bytes per row of one plane
+  constexpr int KS = 16;                                          // k steps of the projections (K = 256)
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, c = lane & 31, kg = lane >> 5;
+  const int b = blockIdx.x, Lq = a.Lq, Lk = a.Lk;
+  const bool self = a.Xq == a.Xkv;
+  unsigned char* sKV = smem;                                      // [2][64][XS]
+  unsigned char* sQ = self ? sKV : smem + 2 * 64 * XS;            // [2][64][XS] (rows >= L are zero)
+  __shared__ unsigned char sM[64];
+  auto stage = [&](const float* X, int L, unsigned char* dst) {
+    for (int f = tid; f < 64 * 64; f += 512) {
+      const int row = f >> 6, c4 = (f & 63) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < L) v = *reinterpret_cast<const f32x4*>(X + ((size_t)b * L + row) * 256 + c4);
+      unsigned h0, l0, h1, l1;
+      split2((f32x2){v[0], v[1]}, h0, l0);
+      split2((f32x2){v[2], v[3]}, h1, l1);
+      *reinterpret_cast<uint2*>(dst + row * XS + c4 * 2) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + 64 * XS + row * XS + c4 * 2) = make_uint2(l0, l1);
+    }
+  };
+  stage(a.Xkv, Lk, sKV);
+  if (!self) stage(a.Xq, Lq, sQ);
+  if (tid < 64) sM[tid] = (tid < Lk) ? (a.mask ? a.mask[(size_t)b * Lk + tid] : 0) : 1;
+  __syncthreads();
+  const bool two_q = Lq > 32, two_k = Lk > 32;
+  // row fragment (8 consecutive features of row 32 t + c, k step ks) and weight fragment (column block nb, k step ks)
+  auto rowf = [&](const unsigned char* sX, int t, int ks, f16x8& hi, f16x8& lo) {
+    hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sX + (t * 32 + c) * XS + ks * 32 + kg * 16));
+    lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sX + 64 * XS + (t * 32 + c) * XS + ks * 32 + kg * 16));
+  };
+  auto wf = [&](const unsigned short* W, size_t plane, int nb, int ks, f16x8& hi, f16x8& lo) {
+    const uint4* p0 = reinterpret_cast<const uint4*>(W) + ((size_t)nb * KS + ks) * 64 + lane;
+    const uint4* p1 = reinterpret_cast<const uint4*>(W + plane) + ((size_t)nb * KS + ks) * 64 + lane;
+    hi = __builtin_bit_cast(f16x8, *p0);
+    lo = __builtin_bit_cast(f16x8, *p1);
+  };
+  // transposed projection of one 32-token tile: lane = token, registers = dims of head h (+ bias, x scale), as split k-step fragments
+  auto proj_t = [&](const unsigned char* sX, int t, const unsigned short* W, size_t plane, int nb, const float* bias, float scale, f16x8 (&fh)[2], f16x8 (&fl)[2]) {
+    f32x16 acc = (f32x16){0};
+    f16x8 wh[2], wl[2];
+    wf(W, plane, nb, 0, wh[0], wl[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) wf(W, plane, nb, ks + 1, wh[(ks + 1) & 1], wl[(ks + 1) & 1]);
+      f16x8 xh, xl;
+      rowf(sX, t, ks, xh, xl);
+      acc = mfma3(wh[ks & 1], wl[ks & 1], xh, xl, acc);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * u + j, dim = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        x[j] = (acc[r] + (bias ? bias[nb * 32 + dim] : 0.0f)) * scale;
+      }
+      split8(x, fh[u], fl[u]);
+    }
+  };
+  f16x8 qh_[2][2], ql_[2][2], kh_[2][2], kl_[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t == 0 || two_q) proj_t(sQ, t, a.Wq, a.wq_plane, a.q_nb0 + h, a.bq, 0.17677669529663687f, qh_[t], ql_[t]);
+    if (t == 0 || two_k) proj_t(sKV, t, a.Wkv, a.wkv_plane, a.k_nb0 + h, a.bkv, 1.0f, kh_[t], kl_[t]);
+  }
+  f32x16 sc[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      sc[kt][qt] = (f32x16){0};
+      if ((kt == 0 || two_k) && (qt == 0 || two_q)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sc[kt][qt] = mfma3(kh_[kt][u], kl_[kt][u], qh_[qt][u], ql_[qt][u], sc[kt][qt]);
+      }
+    }
+  float inv[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    inv[qt] = 0.f;
+    if (qt == 1 && !two_q) continue;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two_k) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const float v = sM[key] ? -INFINITY : sc[kt][qt][r];
+        sc[kt][qt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two_k) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = (mx > -INFINITY) ? __expf(sc[kt][qt][r] - mx) : 0.f;
+        sc[kt][qt][r] = p;
+        den += p;
+      }
+    }
+    den += __shfl_xor(den, 32);
+    inv[qt] = den > 0.f ? 1.0f / den : 0.f;
+  }
+  // values of head h, one 32-key tile at a time: lane = dim, registers = keys; straight into O^T = V^T P^T
+  f32x16 oc[2] = {(f32x16){0}, (f32x16){0}};
+  const float bv = a.bkv ? a.bkv[(a.v_nb0 + h) * 32 + c] : 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    if (kt == 1 && !two_k) continue;
+    f32x16 va = (f32x16){0};
+    f16x8 wh[2], wl[2];
+    wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, 0, wh[0], wl[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, ks + 1, wh[(ks + 1) & 1], wl[(ks + 1) & 1]);
+      f16x8 xh, xl;
+      rowf(sKV, kt, ks, xh, xl);
+      va = mfma3(xh, xl, wh[ks & 1], wl[ks & 1], va);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float vx[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vx[j] = va[8 * u + j] + bv;
+      f16x8 vh, vl;
+      split8(vx, vh, vl);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        if (qt == 1 && !two_q) continue;
+        float px[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) px[j] = sc[kt][qt][8 * u + j];
+        f16x8 ph, pl;
+        split8(px, ph, pl);
+        oc[qt] = mfma3(vh, vl, ph, pl, oc[qt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int query = 32 * qt + c;
+    if ((qt == 1 && !two_q) || query >= Lq) continue;
+    float* op = a.O + ((size_t)b * Lq + query) * a.ldo + h * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {oc[qt][4 * g] * inv[qt], oc[qt][4 * g + 1] * inv[qt], oc[qt][4 * g + 2] * inv[qt], oc[qt][4 * g + 3] * inv[qt]};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * kg) = v;
+    }
+  }
+}
+
+inline int launch_qkv_attention(hipStream_t st, int B, const QkvAttnArgs& a) {
+  const bool self = a.Xq == a.Xkv;
+  const size_t lds = (size_t)(self ? 1 : 2) * 2 * 64 * (256 + 8) * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+      return fail(GLAMR_E_HIP, "hipFuncSetAttribute(qkv_attention_kernel) failed");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(qkv_attention_kernel, dim3(B), dim3(512), lds, st, a);
+  return GLAMR_OK;
+}
+
 // LSTM recurrence (nn.LSTMCell semantics, gate order i f g o, hidden 128).  The input projections
 // G[t] = W_ih x_t + b_ih + b_hh are precomputed by a GEMM; this kernel adds W_hh h_{t-1} and applies the cell.
 // One 512-thread workgroup per (sequence, direction): thread r keeps row r of W_hh (128 floats) in registers.

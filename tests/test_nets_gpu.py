@@ -220,3 +220,28 @@ def test_split_gemm_path_matches_reference_at_batch_size(priors, golden):
     print('split GEMM (batch %d) vs reference: body pose %.2e, local trajectory %.2e, translation %.2e, orientation %.2e; vs the fp32 MFMA kernel %.2e' % ((B,) + e + (d,)))
     assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 2e-4 and e[3] < 2e-4
     assert torch.equal(out['pose'][0], out['pose'][B - 1])          # and every copy of the sequence gets the same bits
+
+
+def test_fused_layer_kernels_match_reference_at_batch_size(joint_model, golden):
+    """At M >= 2048 rows the transformer blocks run as fused kernels (qkv_attention_kernel: projections + attention with Q / K / V in
+    registers; rows_fused_kernel: out-projection + residual + LayerNorm, feed-forward with the hidden rows on chip).  The training-mode pass
+    of the infiller on the two reference windows replicated to 64 sequences must reproduce the reference's context, posterior, prior, sample
+    and output -- quantities that go through every fused block (encoder self-attention, decoder self- and cross-attention) -- to 1e-4."""
+    g = golden('nets_train')
+    x = mg.train_inputs()['infiller']
+    rep = {k: torch.tensor(np.concatenate([v] * 32, axis=0)) for k, v in x.items()}
+    inf = joint_model.mfiller
+    d = inf.init_batch_data(rep)
+    torch.manual_seed(1234)
+    eps2 = torch.randn((2, 128))                                 # the reference drew (2, 128) under this seed
+    d = inf._window_pass(d, 1, eps=eps2.repeat(32, 1).to(inf.device))
+    for i in (0, 1, 62, 63):
+        j = i % 2
+        for k in ('q_z_dist', 'p_z_dist'):
+            _close(d[k].mu[i], g['inf_%s_mu' % k][j], 1e-4, k + ' mu')
+            _close(d[k].logvar[i], g['inf_%s_logvar' % k][j], 1e-4, k + ' logvar')
+        _close(d['context'][:, i], g['inf_context'][:, j], 1e-4, 'context')
+        _close(d['q_z_samp'][i], g['inf_q_z_samp'][j], 1e-4, 'posterior sample')
+        _close(d['train_out_body_pose_tp'][:, i], g['inf_train_out_body_pose_tp'][:, j], 1e-4, 'train output')
+    e = max(_err(d['context'][:, i].cpu(), g['inf_context'][:, i % 2]) for i in range(64))
+    print('fused layers, 64 windows: context vs reference %.2e' % e)
