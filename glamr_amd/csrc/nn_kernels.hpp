@@ -261,8 +261,9 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
   const int K1 = a.K1, XS = (K1 + 8) * 2;                         // bytes per row of one X plane
   constexpr int HS = (256 + 8) * 2;                               // bytes per row of one hidden plane
   unsigned char* sX = smem;                                       // [2][64][XS]
-  unsigned char* sH = smem + 2 * 64 * XS;                         // [2][64][HS]; later the fp32 output rows [64][260]
-  float* sOut = reinterpret_cast<float*>(sH);
+  unsigned char* sH = smem + 2 * 64 * XS;                         // [2][64][HS] (two layers only)
+  // the fp32 output rows [64][260] reuse the hidden planes (two layers) or the X planes (one layer, K1 = 256: 67.6 KB -> two workgroups per CU)
+  float* sOut = reinterpret_cast<float*>(TWO ? sH : sX);
   // ---- X tile -> planes ---------------------------------------------------------------------------------------------------------
   for (int f = tid; f < 64 * (K1 / 4); f += 512) {
     const int row = f / (K1 / 4), c4 = (f % (K1 / 4)) * 4;
@@ -394,7 +395,10 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
   }
 }
 
-inline size_t rows_fused_lds(int K1) { return (size_t)2 * 64 * (K1 + 8) * 2 + (size_t)2 * 64 * (256 + 8) * 2; }
+inline size_t rows_fused_lds(int K1, bool two) {
+  const size_t x = (size_t)2 * 64 * (K1 + 8) * 2, h = (size_t)2 * 64 * (256 + 8) * 2;
+  return two ? x + h : (x > (size_t)64 * 260 * 4 ? x : (size_t)64 * 260 * 4);
+}
 
 // Multi-head attention for short sequences on the matrix cores: 8 heads x 32 dims, Lq, Lk <= 64; ONE wave per (sequence, head).
 //   S^T = K Q^T / sqrt(32)   A = K rows (m = key), B = Q rows (n = query)        -> lane owns a QUERY column, its 16 registers per tile are keys
@@ -899,7 +903,7 @@ inline int launch_rows(hipStream_t st, const float* X, int ldx, int M, int K1, c
   if (K1 % 32 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || (W1s && (K1 > 256 || K2 != 512)) || (!W1s && (K1 > 256 || K2 != K1)))
     return fail(GLAMR_E_INVALID, "fused rows: unsupported shape K1=%d K2=%d", K1, K2);
   RowsArgs a{X, ldx, M, K1, W1s, w1_plane, b1, rowbias, rpg, ldrb, W2s, w2_plane, K2, b2, act2, R, ldr, gamma, beta, Y, ldy};
-  const size_t lds = rows_fused_lds(K1);
+  const size_t lds = rows_fused_lds(K1, W1s != nullptr);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);

@@ -87,5 +87,29 @@ def calib():
     torch.cuda.synchronize()
 
 
+def priors():
+    """Matrix-pipe utilisation of the priors' kernels (one call of both networks on 1024 x 300 frames, tools/priors_ab.py)."""
+    os.makedirs(OUT, exist_ok=True)
+    cmd = 'python %s/tools/priors_ab.py' % ROOT
+    agg = {}
+    for tag, ctrs in (('mfma', ['MfmaUtil']), ('mops', ['SQ_INSTS_VALU_MFMA_MOPS_F16', 'SQ_INSTS_VALU_MFMA_MOPS_F32']), ('busy', ['SQ_BUSY_CU_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY'])):
+        for r in run_pass('pri_' + tag, ctrs, cmd):
+            name = r.get('Kernel_Name', '')
+            short = name.split('(')[0].replace('void ', '').replace('glamr::nn::', '').replace('(anonymous namespace)::', '')
+            a = agg.setdefault(short, {})
+            a.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+    with open(os.path.join(OUT, 'r02_pmc_priors.csv'), 'w') as f:
+        f.write('kernel,counter,dispatches,mean,sum\n')
+        for k in sorted(agg):
+            for cname, vals in sorted(agg[k].items()):
+                f.write('"%s",%s,%d,%.6g,%.6g\n' % (k, cname, len(vals), sum(vals) / len(vals), sum(vals)))
+    print(open(os.path.join(OUT, 'r02_pmc_priors.csv')).read())
+
+
 if __name__ == '__main__':
-    calib() if len(sys.argv) > 1 and sys.argv[1] == 'calib' else main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'calib':
+        calib()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'priors':
+        priors()
+    else:
+        main()
