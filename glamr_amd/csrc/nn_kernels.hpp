@@ -602,14 +602,15 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnArgs a) {
   // transposed projection of one 32-token tile: lane = token, registers = dims of head h (+ bias, x scale), as split k-step fragments
   auto proj_t = [&](const unsigned char* sX, int t, const unsigned short* W, size_t plane, int nb, const float* bias, float scale, f16x8 (&fh)[2], f16x8 (&fl)[2]) {
     f32x16 acc = (f32x16){0};
-    f16x8 wh[2], wl[2];
-    wf(W, plane, nb, 0, wh[0], wl[0]);
+    f16x8 wh[4], wl[4];                              // weight fragments three k steps ahead (an L2 round trip is ~3 x 3 MFMAs long)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wf(W, plane, nb, d, wh[d], wl[d]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) wf(W, plane, nb, ks + 1, wh[(ks + 1) & 1], wl[(ks + 1) & 1]);
+      if (ks + 3 < KS) wf(W, plane, nb, ks + 3, wh[(ks + 3) & 3], wl[(ks + 3) & 3]);
       f16x8 xh, xl;
       rowf(sX, t, ks, xh, xl);
-      acc = mfma3(wh[ks & 1], wl[ks & 1], xh, xl, acc);
+      acc = mfma3(wh[ks & 3], wl[ks & 3], xh, xl, acc);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -678,14 +679,15 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnArgs a) {
   for (int kt = 0; kt < 2; ++kt) {
     if (kt == 1 && !two_k) continue;
     f32x16 va = (f32x16){0};
-    f16x8 wh[2], wl[2];
-    wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, 0, wh[0], wl[0]);
+    f16x8 wh[4], wl[4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, d, wh[d], wl[d]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, ks + 1, wh[(ks + 1) & 1], wl[(ks + 1) & 1]);
+      if (ks + 3 < KS) wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, ks + 3, wh[(ks + 3) & 3], wl[(ks + 3) & 3]);
       f16x8 xh, xl;
       rowf(sKV, kt, ks, xh, xl);
-      va = mfma3(xh, xl, wh[ks & 1], wl[ks & 1], va);
+      va = mfma3(xh, xl, wh[ks & 3], wl[ks & 3], va);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
