@@ -109,6 +109,27 @@ struct DeviceRT {
     for (int w = 0; w < nw; ++w) s += r[w];
     return s;
   }
+  // N block-wide sums at once (two barriers in all instead of two per value): v[k] <- sum over the workgroup of v[k]
+  template <int N>
+  __device__ void reduce_sum_n(float (&v)[N]) const {
+    static_assert(N * 16 <= RT_SCAN_FLOATS, "reduce_sum_n: scratch too small");
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    __syncthreads();                                   // the scan halves of `red` may still be read by a preceding scan
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+      for (int k = 0; k < N; ++k) red[k * 16 + wave] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += red[k * 16 + w];
+      v[k] = s;
+    }
+    __syncthreads();                                   // before anybody overwrites `red` again
+  }
   // in-place inclusive prefix (or suffix) sum over a[i*stride], i in [0,n); ends with a barrier
   __device__ void scan(float* a, int n, int stride, bool reverse) const {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -586,16 +586,19 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int r = 0; r < 3; ++r) { sc.ps[p].oc6[t * 6 + r] = Rb[r * 3 + 0]; sc.ps[p].oc6[t * 6 + 3 + r] = Rb[r * 3 + 1]; }
     }
   // per-joint sum over visible frames of thresholded score^2 (first_frame_only broadcasting of kp_2d, loss_func.py:27-33)
-  for (int p = 0; p < P; ++p)
-    for (int j = 0; j < NJ; ++j) {
-      float c = 0.f;
-      for (int t = rt.tid(); frame_in(t, T); t += fstep) {
+  for (int p = 0; p < P; ++p) {
+    float cj[NJ];
+    for (int j = 0; j < NJ; ++j) cj[j] = 0.f;
+    for (int t = rt.tid(); frame_in(t, T); t += fstep) {
+      if (sc.pc[p].vis[t] == 0.f) continue;
+      for (int j = 0; j < NJ; ++j) {
         const float sj = sc.pc[p].kp_score[(size_t)t * NJ + j];
-        if (sc.pc[p].vis[t] != 0.f && sj >= st.kp_min_conf) c += sj * sj;
+        if (sj >= st.kp_min_conf) cj[j] += sj * sj;
       }
-      c = rt.reduce_sum(c);
-      if (rt.tid() == 0) sc.ps[p].kp_wsum[j] = c;
     }
+    rt.reduce_sum_n(cj);                               // all 26 sums with one exchange (26 separate block reductions were 52 barriers)
+    if (rt.tid() == 0) for (int j = 0; j < NJ; ++j) sc.ps[p].kp_wsum[j] = cj[j];
+  }
   rt.sync();
   // scored joints and their compact per-frame table (joint position, 2-D target, residual weight), on chip when it fits
   if (rt.tid() == 0)

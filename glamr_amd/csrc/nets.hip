@@ -16,6 +16,8 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 using namespace glamr;
 using namespace glamr::nn;
@@ -127,6 +129,14 @@ struct glamr_nets {
   Lin te_out1, te_out2, te_f1, te_f2, te_qz;
   float* rest_joints = nullptr; int32_t* parents = nullptr;
   std::vector<void*> allocs;
+  // glamr_nets_infer launch sequences captured as HIP graphs, keyed by batch geometry + every buffer address of the call
+  struct GraphKey {
+    int v[5]; const void* p[9];
+    bool operator<(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) < 0; }
+  };
+  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
+  std::map<GraphKey, GraphEntry> graphs;
+  std::mutex graph_mu;
 };
 
 namespace {
@@ -819,6 +829,27 @@ int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const in
 
 }  // namespace
 
+namespace {
+// the launch sequence of glamr_nets_infer (w.lens already holds the lengths)
+int enqueue_infer(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, int n_win, int n_win_max, bool do_infill, bool do_traj, const float* body_pose,
+                  const float* visible, const float* motion_eps, const float* traj_eps, float* out_pose, float* out_local_traj, float* out_trans,
+                  float* out_orient) {
+  hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(XLD), 0, st, body_pose, max_len, w.Tpad, w.pose);
+  // ---- motion infiller: autoregressive windows [30 i, 30 i + 50) ------------------------------------------------------------
+  for (int i = 0; do_infill && i < n_win; ++i) {
+    const int s = i * CUR;
+    hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(XLD), 0, st, w.pose, visible, w.lens, w.Tpad, max_len, s, w.x, w.mask);
+    RC(infiller_window(h, st, w, B, GLAMR_VAE_INFER, motion_eps + (size_t)i * NZ, n_win_max * NZ, nullptr, nullptr));
+    hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(XLD), 0, st, w.y, 128, w.lens, w.Tpad, s, w.pose);
+  }
+  if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(XLD), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
+  if (!do_traj) return GLAMR_OK;
+  // ---- trajectory predictor -----------------------------------------------------------------------------------------------------
+  hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + 63) / 64), dim3(64), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
+  return traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr);
+}
+}  // namespace
+
 extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t* lens_host, const float* body_pose, const float* visible,
                                 const float* motion_eps, int n_win_max, const float* traj_eps, float* out_pose, float* out_local_traj,
                                 float* out_trans, float* out_orient, int flags, void* workspace, void* stream_) {
@@ -837,23 +868,53 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   hipStream_t st = static_cast<hipStream_t>(stream_);
   Ws w = ws_layout(B, max_len, static_cast<char*>(workspace));
   GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(XLD), 0, st, body_pose, max_len, w.Tpad, w.pose);
-
-  // ---- motion infiller: autoregressive windows [30 i, 30 i + 50) ------------------------------------------------------------
-  for (int i = 0; do_infill && i < n_win; ++i) {
-    const int s = i * CUR;
-    hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(XLD), 0, st, w.pose, visible, w.lens, w.Tpad, max_len, s, w.x, w.mask);
-    RC(infiller_window(h, st, w, B, GLAMR_VAE_INFER, motion_eps + (size_t)i * NZ, n_win_max * NZ, nullptr, nullptr));
-    hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(XLD), 0, st, w.y, 128, w.lens, w.Tpad, s, w.pose);
+  auto enqueue = [&]() -> int {
+    return enqueue_infer(h, st, w, B, max_len, n_win, n_win_max, do_infill, do_traj, body_pose, visible, motion_eps, traj_eps, out_pose, out_local_traj, out_trans,
+                         out_orient);
+  };
+  // A batch is ~450 kernel launches.  The same call (same geometry, same buffers -- a caching allocator hands the same blocks back in
+  // steady state) seen twice is captured into a HIP graph and replayed from then on: one launch on the host instead of 450, which is
+  // what keeps the step time when the host is slow or shared.  Anything unexpected falls back to the plain launches.
+  static const bool no_graph = std::getenv("GLAMR_NETS_NO_GRAPH") != nullptr;
+  if (!no_graph) {
+    glamr_nets::GraphKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.v[0] = B; key.v[1] = max_len; key.v[2] = n_win; key.v[3] = flags; key.v[4] = n_win_max;
+    const void* ptrs[9] = {body_pose, visible, motion_eps, traj_eps, out_pose, out_local_traj, out_trans, out_orient, workspace};
+    for (int i = 0; i < 9; ++i) key.p[i] = ptrs[i];
+    std::lock_guard<std::mutex> lock(h->graph_mu);
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end() && h->graphs.size() < 24) it = h->graphs.emplace(key, glamr_nets::GraphEntry()).first;
+    if (it != h->graphs.end()) {
+      glamr_nets::GraphEntry& e = it->second;
+      if (e.exec) {
+        GLAMR_HIP_CHECK(hipGraphLaunch(e.exec, st));
+        return GLAMR_OK;
+      }
+      ++e.seen;
+      if ((e.seen == 2 || (e.seen == 1 && (flags & GLAMR_NETS_PERSISTENT))) && st != nullptr) {      // (the legacy default stream cannot be captured)
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+          (void)hipGetLastError();                       // not capturable: clear the error, keep the plain launches for this key
+        } else {
+          const int rc = enqueue();
+          const hipError_t e_in = hipPeekAtLastError();
+          hipGraph_t g = nullptr;
+          const hipError_t ec = hipStreamEndCapture(st, &g);
+          if (std::getenv("GLAMR_DEBUG_GRAPH")) std::fprintf(stderr, "graph capture: rc=%d in-capture error=%s end=%s B=%d max_len=%d flags=%d\n", rc, hipGetErrorString(e_in), hipGetErrorString(ec), B, max_len, flags);
+          hipGraphExec_t exec = nullptr;
+          if (rc == GLAMR_OK && ec == hipSuccess && g && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            hipGraphDestroy(g);
+            e.exec = exec;
+            GLAMR_HIP_CHECK(hipGraphLaunch(e.exec, st));
+            return GLAMR_OK;
+          }
+          if (g) hipGraphDestroy(g);
+          (void)hipGetLastError();                 // capture failed: nothing was launched; run the plain sequence below and never retry this key
+        }
+      }
+    }
   }
-  if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(XLD), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
-  if (!do_traj) { GLAMR_HIP_CHECK(hipGetLastError()); return GLAMR_OK; }
-
-  // ---- trajectory predictor -----------------------------------------------------------------------------------------------------
-  hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + 63) / 64), dim3(64), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
-  RC(traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr));
-  GLAMR_HIP_CHECK(hipGetLastError());
-  return GLAMR_OK;
+  return enqueue();
 }
 
 extern "C" int glamr_nets_infiller_window(glamr_nets* h, int B, int mode, const glamr_infiller_io* io, void* workspace, void* stream_) {

@@ -514,8 +514,11 @@ class GlobalReconOptimizer:
         packed.t['n_persons'] = rin.n_persons
         packed.t['seq_len'] = rin.seq_len
         f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        # inputs / outputs / workspace of the priors live at fixed addresses (two sets per stream): the library replays the call as a HIP graph
+        nw = num_windows(int(rin.lens.max()))
+        rs = self.mt_model.handle.resident_set(n_slots, T, nw) if hasattr(self.mt_model, 'handle') else None
         pa_t = dict(visible_orig=f32(n_slots, T), smpl_pose=f32(n_slots, T, 69), smpl_beta=f32(n_slots, T, 10), trans_cam=f32(n_slots, T, 3),
-                    nets_pose=f32(n_slots, T, 69), nets_vis=f32(n_slots, T))
+                    nets_pose=rs['nets_pose'] if rs else f32(n_slots, T, 69), nets_vis=rs['nets_vis'] if rs else f32(n_slots, T))
         # the cached joints are produced in place by the skinning kernel: keep a placeholder until then
         packed.t['j_local'] = f32(1)
         raw = _lib.RawBatch()
@@ -530,10 +533,18 @@ class GlobalReconOptimizer:
         st = _lib.current_stream()
         _lib.check(L.glamr_init_prepare(ctypes.byref(raw), ctypes.byref(sb), ctypes.byref(pa), int(self.flag_filter_pose), _lib.ptr(ws), st))
         # motion priors on every person of every sequence in one call
-        nw = num_windows(int(rin.lens.max()))
-        meps = rin.meps if rin.meps is not None else torch.randn((n_slots, nw, NZ), device=dev)
-        teps = rin.teps if rin.teps is not None else torch.randn((n_slots, NZ), device=dev)
-        out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps)
+        if rs:
+            meps, teps = rs['meps'], rs['teps']
+            if rin.meps is not None:
+                meps.copy_(rin.meps)
+                teps.copy_(rin.teps)
+            else:
+                torch.randn(meps.shape, out=meps)
+                torch.randn(teps.shape, out=teps)
+        else:
+            meps = rin.meps if rin.meps is not None else torch.randn((n_slots, nw, NZ), device=dev)
+            teps = rin.teps if rin.teps is not None else torch.randn((n_slots, NZ), device=dev)
+        out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps, buffers=rs)
         _lib.check(L.glamr_init_scenes(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
                                        _lib.ptr(out['orient']), _lib.ptr(ws), st))
         # root-relative joints of every frame, cached for the whole optimisation

@@ -8,7 +8,7 @@ import torch
 from .. import _lib
 from .layouts import INFILLER_LAYOUT, TRAJPRED_LAYOUT
 
-NETS_INFILL, NETS_TRAJ = 1, 2
+NETS_INFILL, NETS_TRAJ, NETS_PERSISTENT = 1, 2, 4
 VAE_INFER, VAE_TRAIN, VAE_RECON = 0, 1, 2
 PAST, CUR, NZ = 10, 30, 128
 
@@ -50,27 +50,46 @@ class MotionPriorsHandle:
                                            _lib.ptr(np.ascontiguousarray(parents, dtype=np.int32))))
         self.h = h
 
-    def infer(self, body_pose, visible, lens, motion_eps=None, traj_eps=None, infill=True, traj=True):
-        """body_pose (B,T,69) fp32 device, visible (B,T) 1/0, lens list[int].  Returns dict of device tensors."""
+    def resident_set(self, B, T, n_win):
+        """Persistent buffers for the batched pipeline (GlobalReconOptimizer.init_resident): inputs, outputs and workspace of one
+        glamr_nets_infer call at FIXED addresses, one set per HIP stream and batch geometry.  The set is only ever reused by a later call on
+        the SAME stream, after everything that consumed it was enqueued there, so stream order keeps it safe; fixed addresses are what
+        lets the library replay the call's ~450 launches as one captured HIP graph."""
+        L = _lib.lib()
+        sid = torch.cuda.current_stream(self.device).cuda_stream
+        ring = self.__dict__.setdefault('_ring', {})
+        slot = ring.setdefault((sid, B, T, n_win), {'sets': [None]})
+        i = 0
+        if slot['sets'][i] is None:
+            f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+            slot['sets'][i] = dict(nets_pose=f32(B, T, 69), nets_vis=f32(B, T), meps=f32(B, n_win, NZ), teps=f32(B, NZ), pose=f32(B, T, 69),
+                                   local_traj=f32(B, T, 11), trans=f32(B, T, 3), orient=f32(B, T, 3),
+                                   ws=torch.empty(L.glamr_nets_workspace_bytes(self.h, B, T), dtype=torch.uint8, device=self.device))
+        return slot['sets'][i]
+
+    def infer(self, body_pose, visible, lens, motion_eps=None, traj_eps=None, infill=True, traj=True, buffers=None):
+        """body_pose (B,T,69) fp32 device, visible (B,T) 1/0, lens list[int].  Returns dict of device tensors.  `buffers`: a
+        resident_set() whose output / workspace tensors are used instead of fresh allocations."""
         L = _lib.lib()
         B, T = body_pose.shape[:2]
         dev = body_pose.device
         body_pose = body_pose.float().contiguous()
         lens_np = np.ascontiguousarray(lens, dtype=np.int32)
         out = {}
-        flags = (NETS_INFILL if infill else 0) | (NETS_TRAJ if traj else 0)
+        flags = (NETS_INFILL if infill else 0) | (NETS_TRAJ if traj else 0) | (NETS_PERSISTENT if buffers is not None else 0)
         n_win_max = 0
+        new = (lambda name, *shape: buffers[name]) if buffers is not None else (lambda name, *shape: torch.empty(shape, device=dev))
         if infill:
             visible = visible.float().contiguous()
             n_win_max = motion_eps.shape[1]
             motion_eps = motion_eps.float().contiguous()
-            out['pose'] = torch.empty((B, T, 69), device=dev)
+            out['pose'] = new('pose', B, T, 69)
         if traj:
             traj_eps = traj_eps.float().contiguous()
-            out['local_traj'] = torch.empty((B, T, 11), device=dev)
-            out['trans'] = torch.empty((B, T, 3), device=dev)
-            out['orient'] = torch.empty((B, T, 3), device=dev)
-        ws = torch.empty(L.glamr_nets_workspace_bytes(self.h, B, T), dtype=torch.uint8, device=dev)
+            out['local_traj'] = new('local_traj', B, T, 11)
+            out['trans'] = new('trans', B, T, 3)
+            out['orient'] = new('orient', B, T, 3)
+        ws = buffers['ws'] if buffers is not None else torch.empty(L.glamr_nets_workspace_bytes(self.h, B, T), dtype=torch.uint8, device=dev)
         _lib.check(L.glamr_nets_infer(self.h, B, T, _lib.ptr(lens_np), _lib.ptr(body_pose), _lib.ptr(visible) if infill else None,
                                       _lib.ptr(motion_eps) if infill else None, n_win_max, _lib.ptr(traj_eps) if traj else None,
                                       _lib.ptr(out.get('pose')), _lib.ptr(out.get('local_traj')), _lib.ptr(out.get('trans')),

@@ -98,6 +98,9 @@ size_t glamr_nets_workspace_bytes(const glamr_nets* h, int n_seq, int max_len);
  *          out_trans (n_seq, max_len, 3), out_orient (n_seq, max_len, 3) = infer_out_trans / infer_out_orient. */
 #define GLAMR_NETS_INFILL 1   /* run the motion infiller (MotionInfillerVAE.inference, multi_step) */
 #define GLAMR_NETS_TRAJ 2     /* run the trajectory predictor on the (infilled) body pose (TrajPredVAE.inference) */
+#define GLAMR_NETS_PERSISTENT 4   /* the caller promises that every buffer of this call (inputs, outputs, workspace) keeps its address and is
+                                     only reused on this stream: the ~450 launches are captured as a HIP graph at the first call and replayed
+                                     afterwards (without the flag: captured when the identical call is seen a second time) */
 int glamr_nets_infer(glamr_nets* h, int n_seq, int max_len, const int32_t* lens, const float* body_pose,
                      const float* visible, const float* motion_eps, int n_win_max, const float* traj_eps,
                      float* out_pose, float* out_local_traj, float* out_trans, float* out_orient,

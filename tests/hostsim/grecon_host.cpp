@@ -10,6 +10,7 @@ struct HostRT {
   int nthreads() const { return 1; }
   void sync() const {}
   float reduce_sum(float v) const { return v; }
+  template <int N> void reduce_sum_n(float (&)[N]) const {}
   template <bool LDS = false>
   void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) const {
     for (int c = 0; c < nch; ++c) scan(ch[c], n, stride, reverse);
