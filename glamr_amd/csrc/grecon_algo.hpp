@@ -158,7 +158,7 @@ struct PersonView {      // what the iteration loop needs of PersonConst + Perso
   float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc;
   const float *kpc, *kpc_ws;
 };
-template <int FAST>
+template <int FAST, bool AF = false>
 GLAMR_HD PersonView person_view(const Scene& sc, int p) {
   const PersonConst& c = sc.pc[p];
   const PersonState& s = sc.ps[p];
@@ -167,7 +167,9 @@ GLAMR_HD PersonView person_view(const Scene& sc, int p) {
   w.vis = glob(c.vis); w.j_local = glob(c.j_local); w.kp_2d = glob(c.kp_2d); w.kp_score = glob(c.kp_score); w.cam_K = glob(c.cam_K); w.prior = glob(c.prior);
   w.base_orient = glob(c.base_orient); w.base_trans = glob(c.base_trans); w.person2cam = glob(c.person2cam); w.dheading_mask = glob(c.dheading_mask);
   w.h_prior = glob(s.h_prior); w.oc6 = glob(s.oc6); w.kp_wsum = glob(s.kp_wsum); w.vis_rank = glob(c.vis_rank);
-  w.p = glob(s.p); w.m = glob(s.m); w.v = glob(s.v); w.g = glob(s.g);
+  w.p = glob(s.p); w.g = glob(s.g);
+  // Adam moments: in the on-chip arena for single-person scenes with the full arena (AF), else in the workspace
+  if (AF) { w.m = fastp<1>(s.m); w.v = fastp<1>(s.v); } else { w.m = glob(s.m); w.v = glob(s.v); }
   // first group (prefix sums, neighbour reads): on chip with either arena; second group (own-frame hand-over arrays): full arena only
   w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy);
   w.tw = fastp2<FAST>(s.tw); w.g_d6 = fastp2<FAST>(s.g_d6); w.g_tw = fastp2<FAST>(s.g_tw); w.Lc = fastp2<FAST>(s.Lc);
@@ -180,12 +182,13 @@ struct SceneView {
   float *cam_pose, *cam_inv, *cam_t, *g_cam, *g_caminv, *g_avg, *cp, *cm, *cv, *cg, *losses;
   int store_grad, rel_stride_p, rel_stride_t, TM;
 };
-template <int FAST>
+template <int FAST, bool AF = false>
 GLAMR_HD SceneView scene_view(const Scene& sc) {
   SceneView w;
   w.rel_cam = glob(sc.rel_cam); w.pair_first = glob(sc.pair_first); w.fill_src = glob(sc.fill_src); w.n_vis_persons = glob(sc.n_vis_persons);
   w.cam_pose = glob(sc.cam_pose); w.cam_inv = fastp<FAST>(sc.cam_inv); w.cam_t = fastp<FAST>(sc.cam_t); w.g_cam = glob(sc.g_cam); w.g_caminv = glob(sc.g_caminv); w.g_avg = glob(sc.g_avg);
-  w.cp = glob(sc.cp); w.cm = glob(sc.cm); w.cv = glob(sc.cv); w.cg = glob(sc.cg); w.losses = glob(sc.losses);
+  w.cp = glob(sc.cp); w.cg = glob(sc.cg); w.losses = glob(sc.losses);
+  if (AF) { w.cm = fastp<1>(sc.cm); w.cv = fastp<1>(sc.cv); } else { w.cm = glob(sc.cm); w.cv = glob(sc.cv); }
   w.store_grad = uni(sc.store_grad); w.rel_stride_p = uni(sc.rel_stride_p); w.rel_stride_t = uni(sc.rel_stride_t); w.TM = uni(sc.TM);
   return w;
 }
@@ -361,7 +364,13 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
 
 // on-chip arena: mode 1 (full) = every exchange / hand-over array; mode 2 (lite) = only the arrays other threads read (prefix sums,
 // cos/sin, world rotation columns, camera) -- 14 instead of 38 floats per person-frame, for scenes with many persons or frames
-GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len, int mode = 1) { return (size_t)(15 + (mode == 1 ? 38 : 14) * max_persons) * max_len; }
+// Single-person scenes with the full arena also keep the Adam moments m, v on chip (they are read and written by every iteration: 38 KB of
+// the 58 KB an iteration used to write through to memory): the camera block compacted to 9 T (the camera parameters and the camera residuals
+// are never optimised together and share it) + the person block (11 T + 4), twice.
+GLAMR_HD size_t scene_adam_floats(int max_len) { return (size_t)2 * (9 * (size_t)max_len + 11 * (size_t)max_len + 4); }
+GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len, int mode = 1) {
+  return (size_t)(15 + (mode == 1 ? 38 : 14) * max_persons) * max_len + ((mode == 1 && max_persons == 1) ? scene_adam_floats(max_len) : 0);
+}
 
 GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
   glamr_param_layout l;
@@ -389,7 +398,11 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   float* f = fast;
   auto takef = [&](size_t n) { if (!fast) return take(n); float* r = f; f += n; return r; };
   auto takef2 = [&](size_t n) { if (!fast || fast_mode != 1) return take(n); float* r = f; f += n; return r; };      // second group
-  sc.cm = take(l.person0); sc.cv = take(l.person0);
+  const bool adam_fast = fast && fast_mode == 1 && b.max_persons == 1;
+  auto takea = [&](size_t n) { if (!adam_fast) return take(n); float* r = f; f += n; return r; };
+  // the moments of the camera block use a COMPACT index: camera parameters i, camera residuals i - 9 T (see cam_mv_index)
+  float* cm_ws = take(l.person0); float* cv_ws = take(l.person0);
+  sc.cm = adam_fast ? takea(9 * TM) : cm_ws; sc.cv = adam_fast ? takea(9 * TM) : cv_ws;
   float* cg_ws = take(l.person0);
   sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : cg_ws;
   sc.cam_inv = takef(12 * TM); sc.cam_t = takef(3 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
@@ -400,7 +413,8 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     PersonConst& c = sc.pc[p];
     PersonState& s = sc.ps[p];
     s.p = sc.cp + l.person0 + (size_t)p * l.person_stride;
-    s.m = take(l.person_stride); s.v = take(l.person_stride);
+    float* m_ws = take(l.person_stride); float* v_ws = take(l.person_stride);
+    s.m = adam_fast ? takea(l.person_stride) : m_ws; s.v = adam_fast ? takea(l.person_stride) : v_ws;
     float* g_ws = take(l.person_stride);
     s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
     s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef2(3 * TM); s.g_d6 = takef2(6 * TM); s.g_tw = takef2(3 * TM);
@@ -539,6 +553,7 @@ template <class RT> GLAMR_HD void trace_hook(RT&, int, Scene&, long) {}
 
 template <int FAST, bool SINGLE, int CAM, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
+  constexpr bool AF = FAST == 1 && SINGLE;          // Adam moments on chip (assemble_scene: adam_fast)
   // Frame loops of the full-arena instances make ONE pass (the launcher only selects them when every frame has its own thread): with
   // a step the compiler can see is larger than any sequence the loop is an `if`, and no per-array 64-bit induction pointers stay
   // live across the whole body (two registers each, a few dozen arrays).
@@ -563,7 +578,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     n_exist += (float)n;
     n_exist_m1 += (float)(n - 1);
   }
-  for (int i = rt.tid(); i < l.person0; i += rt.nthreads()) { sc.cm[i] = 0.f; sc.cv[i] = 0.f; sc.cg[i] = 0.f; }
+  for (int i = rt.tid(); i < l.person0; i += rt.nthreads()) { sc.cg[i] = 0.f; if (i < l.cam_inv_rot_res) { sc.cm[i] = 0.f; sc.cv[i] = 0.f; } }      // moments: compact 9 T
   for (int p = 0; p < P; ++p)
     for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) { sc.ps[p].m[i] = 0.f; sc.ps[p].v[i] = 0.f; sc.ps[p].g[i] = 0.f; }
   if (var_cam) {
@@ -643,7 +658,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   double b1p = 1.0, b2p = 1.0;
   int n_done = 0;
   const int n_eval = niters > 0 ? niters : 1;
-  const SceneView sh = scene_view<FAST>(sc);
+  const SceneView sh = scene_view<FAST, AF>(sc);
   // One evaluation (+ update).  Instantiated twice: the iterations that only update (no reported values, no outputs) and the LAST
   // evaluation, which also writes the outputs and reduces the loss values -- keeping that code (axis-angle conversions, all 26
   // joints, 13 accumulators) out of the hot instance keeps its registers out of it too.
@@ -669,59 +684,59 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST>(sc, p);
+        const PersonView c = person_view<FAST, AF>(sc, p);
         float v = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const LocalRow L = local_row(c, l, t - c.fr_start);
-          store_row(person_view<FAST>(sc, p).Lc, sh.TM, t, L);
+          store_row(person_view<FAST, AF>(sc, p).Lc, sh.TM, t, L);
           // atan2(sin h, cos h) of the reference (:401-405) only wraps h into (-pi, pi]: done arithmetically
           v = L.h - 6.28318530717958647692f * rintf(L.h * 0.15915494309189533577f);
         }
-        person_view<FAST>(sc, p).theta[t] = v;
+        person_view<FAST, AF>(sc, p).theta[t] = v;
       }
     {
       float* ch[8];
-      for (int p = 0; p < P; ++p) ch[p] = person_view<FAST>(sc, p).theta;
+      for (int p = 0; p < P; ++p) ch[p] = person_view<FAST, AF>(sc, p).theta;
       rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false);
     }
     // own element of the prefix sum is final: its cos / sin serve phases B, C and I (this frame's and the next frame's)
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         float sn, cs;
-        rm::sincos_(person_view<FAST>(sc, p).theta[t], sn, cs);
-        person_view<FAST>(sc, p).csn[t * 2 + 0] = cs;
-        person_view<FAST>(sc, p).csn[t * 2 + 1] = sn;
+        rm::sincos_(person_view<FAST, AF>(sc, p).theta[t], sn, cs);
+        person_view<FAST, AF>(sc, p).csn[t * 2 + 0] = cs;
+        person_view<FAST, AF>(sc, p).csn[t * 2 + 1] = sn;
       }
     rt.sync();
     GLAMR_MARK(rt, 0);
     // ---- B: planar displacement in world axes -------------------------------------------------------------------------
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST>(sc, p);
+        const PersonView c = person_view<FAST, AF>(sc, p);
         float dx = 0.f, dy = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const int e = t - c.fr_start;
-          const LocalRow L = load_row(person_view<FAST>(sc, p).Lc, sh.TM, t);
+          const LocalRow L = load_row(person_view<FAST, AF>(sc, p).Lc, sh.TM, t);
           dx = L.dx; dy = L.dy;
           if (e > 0) {
-            const float cs = person_view<FAST>(sc, p).csn[(t - 1) * 2 + 0], sn = person_view<FAST>(sc, p).csn[(t - 1) * 2 + 1];
+            const float cs = person_view<FAST, AF>(sc, p).csn[(t - 1) * 2 + 0], sn = person_view<FAST, AF>(sc, p).csn[(t - 1) * 2 + 1];
             dx = L.dx * cs - L.dy * sn;
             dy = L.dx * sn + L.dy * cs;
           }
         }
-        person_view<FAST>(sc, p).xy[t * 2 + 0] = dx;
-        person_view<FAST>(sc, p).xy[t * 2 + 1] = dy;
+        person_view<FAST, AF>(sc, p).xy[t * 2 + 0] = dx;
+        person_view<FAST, AF>(sc, p).xy[t * 2 + 1] = dy;
       }
     {
       float* ch[16];
-      for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST>(sc, p).xy; ch[2 * p + 1] = person_view<FAST>(sc, p).xy + 1; }
+      for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST, AF>(sc, p).xy; ch[2 * p + 1] = person_view<FAST, AF>(sc, p).xy + 1; }
       rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, false);
     }
     GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
     for (int t = rt.tid(); frame_in(t, T); t += fstep) {
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST>(sc, p);
+        const PersonView c = person_view<FAST, AF>(sc, p);
         const PersonView& s = c;
         float c1[3], c2[3], tb[3], phi = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
@@ -782,11 +797,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float avg[12];
         for (int k = 0; k < 12; ++k) avg[k] = 0.f;
         for (int p = 0; p < P; ++p) {
-          if (person_view<FAST>(sc, p).vis[src] == 0.f) continue;
+          if (person_view<FAST, AF>(sc, p).vis[src] == 0.f) continue;
           float Tw[12], Rk[9], C[12];
-          cols_to_R(person_view<FAST>(sc, p).d6 + src * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST>(sc, p).tw[src * 3 + i]; }
-          mul34(Tw, person_view<FAST>(sc, p).person2cam + (size_t)src * 12, C);
+          cols_to_R(person_view<FAST, AF>(sc, p).d6 + src * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST, AF>(sc, p).tw[src * 3 + i]; }
+          mul34(Tw, person_view<FAST, AF>(sc, p).person2cam + (size_t)src * 12, C);
           for (int k = 0; k < 12; ++k) avg[k] += C[k];
         }
         const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
@@ -832,7 +847,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = Mi[j * 4 + i]; M[i * 4 + 3] = sh.cam_t[t * 3 + i]; }
       get_R(M, Rc);
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST>(sc, p);
+        const PersonView c = person_view<FAST, AF>(sc, p);
         const PersonView& s = c;
         const float* tw = s.tw + t * 3;
         float K[9], tgt[6];
@@ -1038,7 +1053,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     if (!SINGLE && on(GLAMR_LOSS_REL_TRANSFORM) && P > 1)
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
-          const PersonView s = person_view<FAST>(sc, p);
+          const PersonView s = person_view<FAST, AF>(sc, p);
           if (s.vis[t] == 0.f) continue;
           float Rk[9], gRk[9], g_tw[3] = {0, 0, 0}, g6[6];
           for (int k = 0; k < 9; ++k) gRk[k] = 0.f;
@@ -1070,11 +1085,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           float avg[12];
           for (int k = 0; k < 12; ++k) avg[k] = 0.f;
           for (int p = 0; p < P; ++p) {
-            if (person_view<FAST>(sc, p).vis[src] == 0.f) continue;
+            if (person_view<FAST, AF>(sc, p).vis[src] == 0.f) continue;
             float Tw[12], Rk[9], C[12];
-            cols_to_R(person_view<FAST>(sc, p).d6 + src * 6, Rk);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST>(sc, p).tw[src * 3 + i]; }
-            mul34(Tw, person_view<FAST>(sc, p).person2cam + (size_t)src * 12, C);
+            cols_to_R(person_view<FAST, AF>(sc, p).d6 + src * 6, Rk);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST, AF>(sc, p).tw[src * 3 + i]; }
+            mul34(Tw, person_view<FAST, AF>(sc, p).person2cam + (size_t)src * 12, C);
             for (int k = 0; k < 12; ++k) avg[k] += C[k];
           }
           const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
@@ -1091,9 +1106,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
           for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sh.cp[l.cam_inv_trans_res + t * 3 + k] * wreg;
         }
-        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k; if (sh.store_grad) sh.cg[i] = g_tres[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], g_tres[k], ac); }
+        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g_tres[k]; adam(sh.cp[i], sh.cm[j], sh.cv[j], g_tres[k], ac); }
         if (sh.n_vis_persons[t] == 0)
-          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], g6[k], ac); }
+          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i], sh.cm[j], sh.cv[j], g6[k], ac); }
       }
       rt.sync();
       for (int t = rt.tid(); frame_in(t, T); t += fstep) {
@@ -1107,17 +1122,17 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         const float inv_n = 1.0f / (float)sh.n_vis_persons[t];
         for (int k = 0; k < 12; ++k) ga[k] *= inv_n;
         for (int p = 0; p < P; ++p) {
-          if (person_view<FAST>(sc, p).vis[t] == 0.f) continue;
+          if (person_view<FAST, AF>(sc, p).vis[t] == 0.f) continue;
           float Tw[12], Rk[9], gTw[12];
           for (int k = 0; k < 12; ++k) gTw[k] = 0.f;
-          cols_to_R(person_view<FAST>(sc, p).d6 + t * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST>(sc, p).tw[t * 3 + i]; }
-          mul34_bwd(Tw, person_view<FAST>(sc, p).person2cam + (size_t)t * 12, ga, gTw, nullptr);
+          cols_to_R(person_view<FAST, AF>(sc, p).d6 + t * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST, AF>(sc, p).tw[t * 3 + i]; }
+          mul34_bwd(Tw, person_view<FAST, AF>(sc, p).person2cam + (size_t)t * 12, ga, gTw, nullptr);
           float gRk[9], g6[6];
           get_R(gTw, gRk);
-          fold_R_grad(person_view<FAST>(sc, p).d6 + t * 6, gRk, g6);
-          for (int k = 0; k < 6; ++k) person_view<FAST>(sc, p).g_d6[t * 6 + k] += g6[k];
-          for (int k = 0; k < 3; ++k) person_view<FAST>(sc, p).g_tw[t * 3 + k] += gTw[k * 4 + 3];
+          fold_R_grad(person_view<FAST, AF>(sc, p).d6 + t * 6, gRk, g6);
+          for (int k = 0; k < 6; ++k) person_view<FAST, AF>(sc, p).g_d6[t * 6 + k] += g6[k];
+          for (int k = 0; k < 3; ++k) person_view<FAST, AF>(sc, p).g_tw[t * 3 + k] += gTw[k * 4 + 3];
         }
       }
       // the fold writes g_d6 / g_tw of frame t from thread t only: the owner continues without a barrier
@@ -1129,7 +1144,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const int i = l.cam_inv_trans_res + t * 3 + k;
           const float g = 2.0f * FPS * FPS * sh.cp[i] * wreg;
           if (sh.store_grad) sh.cg[i] = g;
-          adam(sh.cp[i], sh.cm[i], sh.cv[i], g, ac);
+          adam(sh.cp[i], sh.cm[i - l.cam_inv_rot_res], sh.cv[i - l.cam_inv_rot_res], g, ac);
         }
     }
     GLAMR_MARK(rt, 5);
@@ -1140,7 +1155,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST>(sc, p);
+        const PersonView c = person_view<FAST, AF>(sc, p);
         const PersonView& s = c;
         const bool ex = t >= c.fr_start && t < c.fr_end;
         const int e = t - c.fr_start;
@@ -1195,7 +1210,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     if (update) {
       {
         float* ch[16];
-        for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST>(sc, p).g_xy; ch[2 * p + 1] = person_view<FAST>(sc, p).g_xy + 1; }
+        for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST, AF>(sc, p).g_xy; ch[2 * p + 1] = person_view<FAST, AF>(sc, p).g_xy + 1; }
         rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, true);
       }
       rt.sync();
@@ -1203,7 +1218,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       // ---- I: reverse of B ----------------------------------------------------------------------------------------------
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
-          const PersonView c = person_view<FAST>(sc, p);
+          const PersonView c = person_view<FAST, AF>(sc, p);
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start, n = c.fr_end - c.fr_start;
@@ -1239,14 +1254,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         }
       {
         float* ch[8];
-        for (int p = 0; p < P; ++p) ch[p] = person_view<FAST>(sc, p).g_theta;
+        for (int p = 0; p < P; ++p) ch[p] = person_view<FAST, AF>(sc, p).g_theta;
         rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, true);
       }
       GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
-          const PersonView c = person_view<FAST>(sc, p);
+          const PersonView c = person_view<FAST, AF>(sc, p);
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start;
@@ -1269,8 +1284,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     // regulariser values that do not depend on being optimised (reported every evaluation)
     if (last) {
       for (int p = 0; p < P && !update; ++p) {
-        const PersonView s = person_view<FAST>(sc, p);
-        const int n = person_view<FAST>(sc, p).fr_end - person_view<FAST>(sc, p).fr_start;
+        const PersonView s = person_view<FAST, AF>(sc, p);
+        const int n = person_view<FAST, AF>(sc, p).fr_end - person_view<FAST, AF>(sc, p).fr_start;
         for (int e = rt.tid() + 1; e < n; e += rt.nthreads()) {
           if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[l.local_dxy + e * 2 + k] * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
           if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { float sv, cv; rm::sincos_(s.p[l.local_dheading + e], sv, cv); const float a = (cv - 1.0f) * FPS, b = sv * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
