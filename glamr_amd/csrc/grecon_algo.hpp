@@ -57,7 +57,8 @@ struct PersonConst {
 };
 
 struct PersonState {
-  float* p;                           // parameter block of this person (glamr_param_layout offsets)
+  float* p;                           // parameter block of this person (glamr_param_layout offsets): the batch array, or its on-chip copy
+  float* p_g;                         // the batch array itself
   float* m; float* v; float* g;       // Adam moments, gradient (same layout)
   float* theta; float* xy;            // [T], [T][2] scan buffers
   float* csn;                         // [T][2] cos, sin of theta[t] (read by the neighbouring frame in phases B and I)
@@ -93,6 +94,8 @@ struct Scene {
   float* g_cam; float* g_caminv;      // [T][12]
   float* g_avg;                       // [T][12] (cam-from-person)
   float* cp; float* cm; float* cv; float* cg;   // scene-level parameter block (camera), moments, gradient
+  float* cp_g;                        // the batch array; cp is it, or (on-chip Adam state) a COMPACT 9 T copy: camera parameters when the
+                                      // stage optimises them, else the camera residuals shifted down by 9 T
   float* losses;                      // [GLAMR_NUM_LOSSES]
   int store_grad;
   int rel_stride_p, rel_stride_t;     // padded person count / frame count of rel_cam
@@ -167,9 +170,9 @@ GLAMR_HD PersonView person_view(const Scene& sc, int p) {
   w.vis = glob(c.vis); w.j_local = glob(c.j_local); w.kp_2d = glob(c.kp_2d); w.kp_score = glob(c.kp_score); w.cam_K = glob(c.cam_K); w.prior = glob(c.prior);
   w.base_orient = glob(c.base_orient); w.base_trans = glob(c.base_trans); w.person2cam = glob(c.person2cam); w.dheading_mask = glob(c.dheading_mask);
   w.h_prior = glob(s.h_prior); w.oc6 = glob(s.oc6); w.kp_wsum = glob(s.kp_wsum); w.vis_rank = glob(c.vis_rank);
-  w.p = glob(s.p); w.g = glob(s.g);
-  // Adam moments: in the on-chip arena for single-person scenes with the full arena (AF), else in the workspace
-  if (AF) { w.m = fastp<1>(s.m); w.v = fastp<1>(s.v); } else { w.m = glob(s.m); w.v = glob(s.v); }
+  w.g = glob(s.g);
+  // parameters + Adam moments: in the on-chip arena for single-person scenes with the full arena (AF), else batch array / workspace
+  if (AF) { w.p = fastp<1>(s.p); w.m = fastp<1>(s.m); w.v = fastp<1>(s.v); } else { w.p = glob(s.p); w.m = glob(s.m); w.v = glob(s.v); }
   // first group (prefix sums, neighbour reads): on chip with either arena; second group (own-frame hand-over arrays): full arena only
   w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy);
   w.tw = fastp2<FAST>(s.tw); w.g_d6 = fastp2<FAST>(s.g_d6); w.g_tw = fastp2<FAST>(s.g_tw); w.Lc = fastp2<FAST>(s.Lc);
@@ -179,7 +182,7 @@ GLAMR_HD PersonView person_view(const Scene& sc, int p) {
 }
 struct SceneView {
   const float* rel_cam; const int* pair_first; const int* fill_src; const int* n_vis_persons;
-  float *cam_pose, *cam_inv, *cam_t, *g_cam, *g_caminv, *g_avg, *cp, *cm, *cv, *cg, *losses;
+  float *cam_pose, *cam_inv, *cam_t, *g_cam, *g_caminv, *g_avg, *cp, *cpg, *cm, *cv, *cg, *losses;
   int store_grad, rel_stride_p, rel_stride_t, TM;
 };
 template <int FAST, bool AF = false>
@@ -187,8 +190,8 @@ GLAMR_HD SceneView scene_view(const Scene& sc) {
   SceneView w;
   w.rel_cam = glob(sc.rel_cam); w.pair_first = glob(sc.pair_first); w.fill_src = glob(sc.fill_src); w.n_vis_persons = glob(sc.n_vis_persons);
   w.cam_pose = glob(sc.cam_pose); w.cam_inv = fastp<FAST>(sc.cam_inv); w.cam_t = fastp<FAST>(sc.cam_t); w.g_cam = glob(sc.g_cam); w.g_caminv = glob(sc.g_caminv); w.g_avg = glob(sc.g_avg);
-  w.cp = glob(sc.cp); w.cg = glob(sc.cg); w.losses = glob(sc.losses);
-  if (AF) { w.cm = fastp<1>(sc.cm); w.cv = fastp<1>(sc.cv); } else { w.cm = glob(sc.cm); w.cv = glob(sc.cv); }
+  w.cpg = glob(sc.cp_g); w.cg = glob(sc.cg); w.losses = glob(sc.losses);
+  if (AF) { w.cp = fastp<1>(sc.cp); w.cm = fastp<1>(sc.cm); w.cv = fastp<1>(sc.cv); } else { w.cp = glob(sc.cp); w.cm = glob(sc.cm); w.cv = glob(sc.cv); }
   w.store_grad = uni(sc.store_grad); w.rel_stride_p = uni(sc.rel_stride_p); w.rel_stride_t = uni(sc.rel_stride_t); w.TM = uni(sc.TM);
   return w;
 }
@@ -364,10 +367,10 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
 
 // on-chip arena: mode 1 (full) = every exchange / hand-over array; mode 2 (lite) = only the arrays other threads read (prefix sums,
 // cos/sin, world rotation columns, camera) -- 14 instead of 38 floats per person-frame, for scenes with many persons or frames
-// Single-person scenes with the full arena also keep the Adam moments m, v on chip (they are read and written by every iteration: 38 KB of
-// the 58 KB an iteration used to write through to memory): the camera block compacted to 9 T (the camera parameters and the camera residuals
+// Single-person scenes with the full arena also keep the parameters and the Adam moments p, m, v on chip (read and written by every
+// iteration: the 58 KB an iteration used to write through to memory; they go back to the batch array once, when the stage ends): the camera block compacted to 9 T (the camera parameters and the camera residuals
 // are never optimised together and share it) + the person block (11 T + 4), twice.
-GLAMR_HD size_t scene_adam_floats(int max_len) { return (size_t)2 * (9 * (size_t)max_len + 11 * (size_t)max_len + 4); }
+GLAMR_HD size_t scene_adam_floats(int max_len) { return (size_t)3 * (9 * (size_t)max_len + 11 * (size_t)max_len + 4); }
 GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len, int mode = 1) {
   return (size_t)(15 + (mode == 1 ? 38 : 14) * max_persons) * max_len + ((mode == 1 && max_persons == 1) ? scene_adam_floats(max_len) : 0);
 }
@@ -389,7 +392,8 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   sc.P = n_persons; sc.T = seq_len; sc.lay = &l; sc.st = st;
   sc.rel_cam = b.rel_transform_cam ? b.rel_transform_cam + (size_t)si * b.max_persons * b.max_persons * TM * 12 : nullptr;
   sc.cam_pose = b.cam_pose + (size_t)si * TM * 12;
-  sc.cp = b.params + (size_t)si * l.scene_stride;
+  sc.cp_g = b.params + (size_t)si * l.scene_stride;
+  sc.cp = sc.cp_g;
   sc.losses = b.losses + (size_t)si * GLAMR_NUM_LOSSES;
   sc.store_grad = grads_out != nullptr;
   float* w = ws;
@@ -403,6 +407,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   // the moments of the camera block use a COMPACT index: camera parameters i, camera residuals i - 9 T (see cam_mv_index)
   float* cm_ws = take(l.person0); float* cv_ws = take(l.person0);
   sc.cm = adam_fast ? takea(9 * TM) : cm_ws; sc.cv = adam_fast ? takea(9 * TM) : cv_ws;
+  if (adam_fast) sc.cp = takea(9 * TM);
   float* cg_ws = take(l.person0);
   sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : cg_ws;
   sc.cam_inv = takef(12 * TM); sc.cam_t = takef(3 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
@@ -412,9 +417,11 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     const size_t slot = (size_t)si * b.max_persons + p;
     PersonConst& c = sc.pc[p];
     PersonState& s = sc.ps[p];
-    s.p = sc.cp + l.person0 + (size_t)p * l.person_stride;
+    s.p_g = sc.cp_g + l.person0 + (size_t)p * l.person_stride;
+    s.p = s.p_g;
     float* m_ws = take(l.person_stride); float* v_ws = take(l.person_stride);
     s.m = adam_fast ? takea(l.person_stride) : m_ws; s.v = adam_fast ? takea(l.person_stride) : v_ws;
+    if (adam_fast) s.p = takea(l.person_stride);
     float* g_ws = take(l.person_stride);
     s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
     s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef2(3 * TM); s.g_d6 = takef2(6 * TM); s.g_tw = takef2(3 * TM);
@@ -553,7 +560,7 @@ template <class RT> GLAMR_HD void trace_hook(RT&, int, Scene&, long) {}
 
 template <int FAST, bool SINGLE, int CAM, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
-  constexpr bool AF = FAST == 1 && SINGLE;          // Adam moments on chip (assemble_scene: adam_fast)
+  constexpr bool AF = FAST == 1 && SINGLE;          // parameters + Adam moments on chip (assemble_scene: adam_fast)
   // Frame loops of the full-arena instances make ONE pass (the launcher only selects them when every frame has its own thread): with
   // a step the compiler can see is larger than any sequence the loop is an `if`, and no per-array 64-bit induction pointers stay
   // live across the whole body (two registers each, a few dozen arrays).
@@ -581,6 +588,13 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   for (int i = rt.tid(); i < l.person0; i += rt.nthreads()) { sc.cg[i] = 0.f; if (i < l.cam_inv_rot_res) { sc.cm[i] = 0.f; sc.cv[i] = 0.f; } }      // moments: compact 9 T
   for (int p = 0; p < P; ++p)
     for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) { sc.ps[p].m[i] = 0.f; sc.ps[p].v[i] = 0.f; sc.ps[p].g[i] = 0.f; }
+  const int rs = AF ? l.cam_inv_rot_res : 0;          // index shift of the camera residuals in the on-chip (compact) camera block
+  if (AF) {
+    // parameters on chip: the person block as it is; the camera block = the residuals unless the stage optimises the camera itself (then
+    // it is initialised from the camera poses right below)
+    for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) sc.ps[0].p[i] = sc.ps[0].p_g[i];
+    if (!var_cam) for (int i = rt.tid(); i < l.cam_inv_rot_res; i += rt.nthreads()) sc.cp[i] = sc.cp_g[l.cam_inv_rot_res + i];
+  }
   if (var_cam) {
     const int rows = fixed_cam ? 1 : T;
     for (int t = rt.tid(); t < rows; t += rt.nthreads()) {
@@ -808,10 +822,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         for (int k = 0; k < 12; ++k) avg[k] = avg[k] * inv_n;   // sum(...) / num_persons  (:492)
         float r6[6];
         for (int r = 0; r < 3; ++r) { r6[r] = avg[r * 4 + 0]; r6[3 + r] = avg[r * 4 + 1]; }
-        if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) r6[k] += sh.cp[l.cam_inv_rot_res + t * 6 + k];
+        if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) r6[k] += sh.cp[l.cam_inv_rot_res - rs + t * 6 + k];
         float R[9];
         rm::rot6d_to_rotmat(r6, R);
-        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sh.cp[l.cam_inv_trans_res + t * 3 + i]; }
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sh.cp[l.cam_inv_trans_res - rs + t * 3 + i]; }
         invert34(Mi, M);
         for (int k = 0; k < 12; ++k) sh.cam_inv[(size_t)t * 12 + k] = Mi[k];
         for (int k = 0; k < 3; ++k) sh.cam_t[t * 3 + k] = M[k * 4 + 3];
@@ -1046,7 +1060,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         }
       }
       if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
-        for (int k = 0; k < 3; ++k) { const float r = sh.cp[l.cam_inv_trans_res + t * 3 + k] * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r; }
+        for (int k = 0; k < 3; ++k) {      // (with the camera optimised the on-chip block holds the camera, the residuals stay in the batch array)
+          const float r = (var_cam ? sh.cpg[l.cam_inv_trans_res + t * 3 + k] : sh.cp[l.cam_inv_trans_res - rs + t * 3 + k]) * FPS;
+          if (last) lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r;
+        }
     }
     // relative transform between persons on co-visible frames (loss_func.py:248-271), in a loop of its own: its ~100 live values
     // are then not allocated alongside the keypoint / camera terms above.  Own frame only -> no barrier; the fold is linear.
@@ -1094,7 +1111,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           }
           const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
           for (int r = 0; r < 3; ++r) { avg6[r] = avg[r * 4 + 0] * inv_n; avg6[3 + r] = avg[r * 4 + 1] * inv_n; }
-          if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) avg6[k] += sh.cp[l.cam_inv_rot_res + t * 6 + k];
+          if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) avg6[k] += sh.cp[l.cam_inv_rot_res - rs + t * 6 + k];
         }
         float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
         get_R(gMi, gR);
@@ -1104,11 +1121,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float g_tres[3] = {gMi[3], gMi[7], gMi[11]};
         if (active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
           const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
-          for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sh.cp[l.cam_inv_trans_res + t * 3 + k] * wreg;
+          for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sh.cp[l.cam_inv_trans_res - rs + t * 3 + k] * wreg;
         }
-        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g_tres[k]; adam(sh.cp[i], sh.cm[j], sh.cv[j], g_tres[k], ac); }
+        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g_tres[k]; adam(sh.cp[i - rs], sh.cm[j], sh.cv[j], g_tres[k], ac); }
         if (sh.n_vis_persons[t] == 0)
-          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i], sh.cm[j], sh.cv[j], g6[k], ac); }
+          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i - rs], sh.cm[j], sh.cv[j], g6[k], ac); }
       }
       rt.sync();
       for (int t = rt.tid(); frame_in(t, T); t += fstep) {
@@ -1142,9 +1159,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int k = 0; k < 3; ++k) {
           const int i = l.cam_inv_trans_res + t * 3 + k;
-          const float g = 2.0f * FPS * FPS * sh.cp[i] * wreg;
+          const float g = 2.0f * FPS * FPS * sh.cp[i - rs] * wreg;
           if (sh.store_grad) sh.cg[i] = g;
-          adam(sh.cp[i], sh.cm[i - l.cam_inv_rot_res], sh.cv[i - l.cam_inv_rot_res], g, ac);
+          adam(sh.cp[i - rs], sh.cm[i - l.cam_inv_rot_res], sh.cv[i - l.cam_inv_rot_res], g, ac);
         }
     }
     GLAMR_MARK(rt, 5);
@@ -1318,6 +1335,19 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   evaluate(std::true_type{});
   trace_hook(rt, n_eval - 1, sc, 0);
   rt.sync();
+  if (AF) {      // the on-chip parameters go back to the batch array, once
+    for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) sc.ps[0].p_g[i] = sc.ps[0].p[i];
+    if (var_cam) {
+      const int rows = fixed_cam ? 1 : T;
+      for (int t = rt.tid(); t < rows; t += rt.nthreads()) {
+        for (int k = 0; k < 6; ++k) sc.cp_g[l.cam_rot6d + t * 6 + k] = sc.cp[l.cam_rot6d + t * 6 + k];
+        for (int k = 0; k < 3; ++k) sc.cp_g[l.cam_trans + t * 3 + k] = sc.cp[l.cam_trans + t * 3 + k];
+      }
+    } else {
+      for (int i = rt.tid(); i < l.cam_inv_rot_res; i += rt.nthreads()) sc.cp_g[l.cam_inv_rot_res + i] = sc.cp[i];
+    }
+    rt.sync();
+  }
   GLAMR_MARK_END(rt);
 }
 
