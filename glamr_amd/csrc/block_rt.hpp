@@ -15,7 +15,21 @@ __device__ unsigned long long g_phase_ticks[16];     // 100 MHz ticks per phase,
 
 struct DeviceRT {
   float* red;   // LDS scratch of RT_RED_FLOATS floats
+  float* ws = nullptr;   // this workgroup's workspace slice (constant-layout instances address their arrays relative to it)
   int gen = 0;
+  static constexpr bool one_thread_per_frame = true;     // the launcher gives full-arena instances a thread per frame
+  // base of the dynamic LDS arena: a link-time constant, so `arena() + compile-time offset` needs no register
+  static __device__ __forceinline__ float* arena() {
+    extern __shared__ __attribute__((aligned(16))) float glamr_dynamic_lds[];
+    return glamr_dynamic_lds;
+  }
+  __device__ __forceinline__ float* workspace() const {      // uniform, pinned to scalar registers: loads take it as their scalar base
+    const unsigned long long v = reinterpret_cast<unsigned long long>(ws);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    __attribute__((address_space(1))) float* g = (__attribute__((address_space(1))) float*)(((unsigned long long)hi << 32) | lo);
+    asm("" : "+s"(g));
+    return (float*)g;
+  }
 #ifdef GLAMR_PHASE_TIMING
   unsigned long long t_last = 0, acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __device__ void mark_begin() { t_last = wall_clock64(); }

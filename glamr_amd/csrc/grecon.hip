@@ -38,9 +38,10 @@ struct KernelArgs {
   const float* adam_tab;               // per-iteration Adam scalars formed on the host (workspace header) or null
   int use_lds;
   unsigned fast_floats;
+  int layout_len;      // frames the arena / workspace arrays are laid out for (0 = the batch's max_len)
 };
 
-template <int FAST, bool SINGLE, int CAM>
+template <int FAST, bool SINGLE, int CAM, int TMC = 0>
 __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon_stage_kernel(KernelArgs a) {
   __shared__ float red[RT_RED_FLOATS];
   __shared__ Scene sc;
@@ -53,12 +54,12 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
     s_st = a.st;
     s_lay = a.lay;
     assemble_scene(a.b, s_lay, &s_st, si, a.b.n_persons[si], a.b.seq_len[si], a.workspace + (size_t)si * a.ws_floats_per_scene, a.grads_out, sc,
-                   a.use_lds ? arena : nullptr, a.fast_floats, a.use_lds);
+                   a.use_lds ? arena : nullptr, a.fast_floats, a.use_lds, a.layout_len);
     sc.adam_tab = a.adam_tab;
   }
   __syncthreads();
-  glamr::DeviceRT rt{red};
-  run_scene<FAST, SINGLE, CAM>(rt, sc, a.st, a.lay);
+  glamr::DeviceRT rt{red, a.workspace + (size_t)si * a.ws_floats_per_scene};
+  run_scene<FAST, SINGLE, CAM, TMC>(rt, sc, a.st, a.lay);
   if (threadIdx.x == 0) atomicMax(a.stamps + 1, (unsigned long long)wall_clock64());
 }
 
@@ -79,7 +80,7 @@ constexpr size_t GLAMR_GRECON_WS_HEADER = 256;
 
 extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len) {
   if (n_scenes <= 0 || max_persons < 1 || max_persons > 8 || max_len < 2) return 0;
-  return GLAMR_GRECON_WS_HEADER + (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, max_len), 64) * sizeof(float);
+  return GLAMR_GRECON_WS_HEADER + (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, layout_frames(max_persons, max_len)), 64) * sizeof(float);
 }
 
 extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out,
@@ -127,7 +128,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     }
     ka.adam_tab = dtab;
   }
-  ka.ws_floats_per_scene = align_up(scene_workspace_floats(batch->max_persons, batch->max_len), 64);
+  ka.ws_floats_per_scene = align_up(scene_workspace_floats(batch->max_persons, layout_frames(batch->max_persons, batch->max_len)), 64);
   ka.grads_out = grads_out;
   int threads = (batch->max_len + 63) / 64 * 64;
   if (threads > MAX_THREADS) threads = MAX_THREADS;
@@ -156,12 +157,20 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     const size_t v = (size_t)std::atoi(e) * 1024;
     LDS_BUDGET = v < 16384 ? (size_t)16384 : (v > LDS_MAX ? LDS_MAX : v);
   }
-  const size_t full = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
+  // constant-layout instance (every array address of the loop a compile-time constant): one person, 257..320 frames, a thread per
+  // frame, the full arena of the 320-frame layout fits, and the caller does not ask for the gradient record
+  const int lay_len = layout_frames(batch->max_persons, batch->max_len);
+  const bool no_const_layout = std::getenv("GLAMR_GRECON_NO_CONST_LAYOUT") != nullptr;      // development aid / A-B tests (read per launch)
+  const bool const_layout = lay_len == GLAMR_CONST_LAYOUT_FRAMES && !grads_out && !no_const_layout && batch->max_len <= threads &&
+                            scene_fast_floats(1, lay_len, 1) * sizeof(float) <= LDS_BUDGET;
+  ka.layout_len = const_layout ? lay_len : 0;
+  const int arena_len = const_layout ? lay_len : batch->max_len;
+  const size_t full = scene_fast_floats(batch->max_persons, arena_len, 1) * sizeof(float);
   const size_t lite = scene_fast_floats(batch->max_persons, batch->max_len, 2) * sizeof(float);
   // 1 full arena (single-pass instances: needs a thread per frame), 2 lite arena, 0 everything in the workspace
   ka.use_lds = (full <= LDS_BUDGET && batch->max_len <= threads) ? 1 : (lite <= LDS_BUDGET ? 2 : 0);
   const size_t base = ka.use_lds == 1 ? full : lite;
-  const size_t want = base + (size_t)NJ * 6 * batch->max_persons * batch->max_len * sizeof(float);
+  const size_t want = base + (size_t)NJ * 6 * batch->max_persons * arena_len * sizeof(float);
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
   ka.fast_floats = (unsigned)(dyn / sizeof(float));
   // SINGLE needs every scene of the batch to hold exactly one person: max_persons == 1 guarantees it
@@ -173,7 +182,10 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   };
   int rc;
   const int cam = camera_mode(*stage);      // per-camera-mode instances: 24.1 vs 26.1 us per iteration (1 person), 61.8 vs 66.2 (2 persons, main stage)
-  if (ka.use_lds == 1 && single)
+  constexpr int CL = GLAMR_CONST_LAYOUT_FRAMES;
+  if (ka.use_lds == 1 && single && const_layout)
+    rc = cam == 1 ? launch(grecon_stage_kernel<1, true, 1, CL>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, true, 2, CL>, dyn) : launch(grecon_stage_kernel<1, true, 0, CL>, dyn);
+  else if (ka.use_lds == 1 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<1, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, true, 2>, dyn) : launch(grecon_stage_kernel<1, true, 0>, dyn);
   else if (ka.use_lds == 1)
     rc = cam == 1 ? launch(grecon_stage_kernel<1, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, false, 2>, dyn) : launch(grecon_stage_kernel<1, false, 0>, dyn);

@@ -76,6 +76,8 @@ struct PersonState {
   int njc; int jidx[NJ];              // joints whose residual weight is non-zero somewhere
   float* h_prior;                     // [T] row e: heading angle of the prior row, atan2s(sin, cos)  (constant per stage)
   float* oc6;                         // [T][6] first two columns of aa2R_k(orient_cam) (cam_traj_rot target, constant)
+  float *in_vis, *in_cam_K, *in_prior, *in_base_orient, *in_base_trans, *in_person2cam, *in_dmask;   // workspace copies of the stage-constant
+                                      // inputs the loop reads (constant-layout instances read them at constant offsets)
 };
 
 struct Scene {
@@ -100,7 +102,8 @@ struct Scene {
   int store_grad;
   int rel_stride_p, rel_stride_t;     // padded person count / frame count of rel_cam
   float* fast_free; size_t fast_left; // unused tail of the on-chip arena (claimed by setup for kpc when it fits)
-  int TM;                             // padded frame count (array strides)
+  int TM;                             // frame count the arena / workspace arrays are laid out for (their strides); >= the batch's max_len
+  float* ws;                          // this scene's workspace slice
   const float* adam_tab;              // [niters][2] per-iteration (-lr / (1 - beta1^t), sqrt(1 - beta2^t)) formed on the host, or null
 };
 
@@ -161,41 +164,11 @@ struct PersonView {      // what the iteration loop needs of PersonConst + Perso
   float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc;
   const float *kpc, *kpc_ws;
 };
-template <int FAST, bool AF = false>
-GLAMR_HD PersonView person_view(const Scene& sc, int p) {
-  const PersonConst& c = sc.pc[p];
-  const PersonState& s = sc.ps[p];
-  PersonView w;
-  w.fr_start = uni(c.fr_start); w.fr_end = uni(c.fr_end); w.njc = uni(s.njc); w.njc_fast = uni(s.njc_fast);
-  w.vis = glob(c.vis); w.j_local = glob(c.j_local); w.kp_2d = glob(c.kp_2d); w.kp_score = glob(c.kp_score); w.cam_K = glob(c.cam_K); w.prior = glob(c.prior);
-  w.base_orient = glob(c.base_orient); w.base_trans = glob(c.base_trans); w.person2cam = glob(c.person2cam); w.dheading_mask = glob(c.dheading_mask);
-  w.h_prior = glob(s.h_prior); w.oc6 = glob(s.oc6); w.kp_wsum = glob(s.kp_wsum); w.vis_rank = glob(c.vis_rank);
-  w.g = glob(s.g);
-  // parameters + Adam moments: in the on-chip arena for single-person scenes with the full arena (AF), else batch array / workspace
-  if (AF) { w.p = fastp<1>(s.p); w.m = fastp<1>(s.m); w.v = fastp<1>(s.v); } else { w.p = glob(s.p); w.m = glob(s.m); w.v = glob(s.v); }
-  // first group (prefix sums, neighbour reads): on chip with either arena; second group (own-frame hand-over arrays): full arena only
-  w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy);
-  w.tw = fastp2<FAST>(s.tw); w.g_d6 = fastp2<FAST>(s.g_d6); w.g_tw = fastp2<FAST>(s.g_tw); w.Lc = fastp2<FAST>(s.Lc);
-  w.orient_world = glob(s.orient_world); w.trans_world = glob(s.trans_world); w.kp_2d_pred = glob(s.kp_2d_pred); w.orient_cam_in_world = glob(s.orient_cam_in_world);
-  w.kpc = fastp<FAST>(s.kpc); w.kpc_ws = glob(s.kpc_ws);      // kpc is only dereferenced for the njc_fast joints that are on chip
-  return w;
-}
 struct SceneView {
   const float* rel_cam; const int* pair_first; const int* fill_src; const int* n_vis_persons;
   float *cam_pose, *cam_inv, *cam_t, *g_cam, *g_caminv, *g_avg, *cp, *cpg, *cm, *cv, *cg, *losses;
   int store_grad, rel_stride_p, rel_stride_t, TM;
 };
-template <int FAST, bool AF = false>
-GLAMR_HD SceneView scene_view(const Scene& sc) {
-  SceneView w;
-  w.rel_cam = glob(sc.rel_cam); w.pair_first = glob(sc.pair_first); w.fill_src = glob(sc.fill_src); w.n_vis_persons = glob(sc.n_vis_persons);
-  w.cam_pose = glob(sc.cam_pose); w.cam_inv = fastp<FAST>(sc.cam_inv); w.cam_t = fastp<FAST>(sc.cam_t); w.g_cam = glob(sc.g_cam); w.g_caminv = glob(sc.g_caminv); w.g_avg = glob(sc.g_avg);
-  w.cpg = glob(sc.cp_g); w.cg = glob(sc.cg); w.losses = glob(sc.losses);
-  if (AF) { w.cp = fastp<1>(sc.cp); w.cm = fastp<1>(sc.cm); w.cv = fastp<1>(sc.cv); } else { w.cp = glob(sc.cp); w.cm = glob(sc.cm); w.cv = glob(sc.cv); }
-  w.store_grad = uni(sc.store_grad); w.rel_stride_p = uni(sc.rel_stride_p); w.rel_stride_t = uni(sc.rel_stride_t); w.TM = uni(sc.TM);
-  return w;
-}
-
 // ---- small helpers ---------------------------------------------------------------------------------------------------
 
 GLAMR_HD float gmof(float x, float sigma2) { return sigma2 * x * x / (sigma2 + x * x); }
@@ -347,7 +320,8 @@ GLAMR_HD void fold_R_grad(const float* d6, const float gR[9], float g6[6]) {
 
 // ---- layout of the parameter vector and of the per-scene workspace ------------------------------------------------------
 
-GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) {
+GLAMR_HD constexpr glamr_param_layout make_layout(int max_persons, int max_len) {
+  glamr_param_layout l{};
   const int T = max_len;
   l.cam_rot6d = 0;
   l.cam_trans = l.cam_rot6d + 6 * T;
@@ -363,73 +337,178 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
   l.world_dheading = l.local_rot + 6 * T;
   l.person_stride = l.world_dheading + T;
   l.scene_stride = l.person0 + max_persons * l.person_stride;
+  return l;
 }
+GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) { l = make_layout(max_persons, max_len); }
 
+// Where every per-scene array lives: float offsets into the on-chip arena (lds) or into the scene's workspace slice.  One function
+// for the binder (run time), the size queries, and -- with a frame count known at compile time -- the constant addresses of the
+// constant-layout instances.  `fast`: an arena exists; `fast_mode` 1 = full, 2 = lite.
+struct ArrOff { unsigned off; bool lds; };
+struct PersonOff {
+  ArrOff m_ws, v_ws, m, v, p, g_ws, theta, csn, xy, d6, tw, g_d6, g_tw, g_theta, g_xy, Lc, kpc_ws, vis_rank, kp_wsum, h_prior, oc6;
+  ArrOff in_vis, in_cam_K, in_prior, in_base_orient, in_base_trans, in_person2cam, in_dmask;      // stage-constant inputs, copied next to the rest
+};
+struct SceneOff {
+  ArrOff cm_ws, cv_ws, cm, cv, cp, cg_ws, cam_inv, cam_t, g_cam, g_caminv, g_avg, fill_src, n_vis_persons, pair_first;
+  PersonOff ps[8];
+  unsigned ws_end, fast_end;
+  bool adam_fast;
+};
+GLAMR_HD constexpr SceneOff scene_offsets(int max_persons, int max_len, bool fast, int fast_mode) {
+  SceneOff o{};
+  const glamr_param_layout l = make_layout(max_persons, max_len);
+  const unsigned TM = (unsigned)max_len, person0 = (unsigned)l.person0, pstride = (unsigned)l.person_stride;
+  unsigned w = 0, f = 0;
+  // arrays other threads read (neighbouring frames, prefix sums) go to the arena when there is one; the second group (own-frame
+  // hand-over arrays) only to the full arena; parameters and Adam moments only for single-person scenes with the full arena
+  const bool full = fast && fast_mode == 1;
+  o.adam_fast = full && max_persons == 1;
+  const bool af = o.adam_fast;
+  auto take = [&](unsigned n) { ArrOff r{w, false}; w += n; return r; };
+  auto lds = [&](unsigned n) { ArrOff r{f, true}; f += n; return r; };
+  auto takef = [&](unsigned n) { return fast ? lds(n) : take(n); };
+  auto takef2 = [&](unsigned n) { return full ? lds(n) : take(n); };
+  // the moments of the camera block use a COMPACT index: camera parameters i, camera residuals i - 9 T
+  o.cm_ws = take(person0); o.cv_ws = take(person0);
+  o.cm = af ? lds(9 * TM) : o.cm_ws; o.cv = af ? lds(9 * TM) : o.cv_ws;
+  if (af) o.cp = lds(9 * TM);
+  o.cg_ws = take(person0);
+  o.cam_inv = takef(12 * TM); o.cam_t = takef(3 * TM); o.g_cam = take(12 * TM); o.g_caminv = take(12 * TM); o.g_avg = take(12 * TM);
+  o.fill_src = take(TM); o.n_vis_persons = take(TM); o.pair_first = take(64);
+  for (int p = 0; p < max_persons; ++p) {
+    PersonOff& s = o.ps[p];
+    s.m_ws = take(pstride); s.v_ws = take(pstride);
+    s.m = af ? lds(pstride) : s.m_ws; s.v = af ? lds(pstride) : s.v_ws;
+    if (af) s.p = lds(pstride);
+    s.g_ws = take(pstride);
+    s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef2(3 * TM); s.g_d6 = takef2(6 * TM); s.g_tw = takef2(3 * TM);
+    s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef2(12 * TM);
+    s.kpc_ws = take(26 * 6 * TM);
+    s.vis_rank = take(TM); s.kp_wsum = take(32); s.h_prior = take(TM); s.oc6 = take(6 * TM);
+    s.in_vis = take(TM); s.in_cam_K = take(9 * TM); s.in_prior = take(11 * TM); s.in_base_orient = take(3 * TM); s.in_base_trans = take(3 * TM);
+    s.in_person2cam = take(12 * TM); s.in_dmask = take(TM);
+  }
+  o.ws_end = w; o.fast_end = f;
+  return o;
+}
 // on-chip arena: mode 1 (full) = every exchange / hand-over array; mode 2 (lite) = only the arrays other threads read (prefix sums,
-// cos/sin, world rotation columns, camera) -- 14 instead of 38 floats per person-frame, for scenes with many persons or frames
+// cos/sin, world rotation columns, camera) -- 14 instead of 38 floats per person-frame, for scenes with many persons or frames.
 // Single-person scenes with the full arena also keep the parameters and the Adam moments p, m, v on chip (read and written by every
-// iteration: the 58 KB an iteration used to write through to memory; they go back to the batch array once, when the stage ends): the camera block compacted to 9 T (the camera parameters and the camera residuals
-// are never optimised together and share it) + the person block (11 T + 4), twice.
-GLAMR_HD size_t scene_adam_floats(int max_len) { return (size_t)3 * (9 * (size_t)max_len + 11 * (size_t)max_len + 4); }
-GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len, int mode = 1) {
-  return (size_t)(15 + (mode == 1 ? 38 : 14) * max_persons) * max_len + ((mode == 1 && max_persons == 1) ? scene_adam_floats(max_len) : 0);
+// iteration: the 58 KB an iteration used to write through to memory; they go back to the batch array once, when the stage ends): the
+// camera block compacted to 9 T (the camera parameters and the camera residuals are never optimised together and share it) + the
+// person block (11 T + 4), three times.
+GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len, int mode = 1) { return scene_offsets(max_persons, max_len, true, mode).fast_end; }
+GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) { return scene_offsets(max_persons, max_len, false, 0).ws_end; }
+// Constant-layout instances: single-person scenes of 257..320 frames (BASELINE configs[1]: 300) lay their arena and workspace out for
+// 320 frames whatever the batch's padded length, so that every array address in the iteration loop is a compile-time constant
+constexpr int GLAMR_CONST_LAYOUT_FRAMES = 320;
+GLAMR_HD constexpr int layout_frames(int max_persons, int max_len) {
+  return (max_persons == 1 && max_len > 256 && max_len <= GLAMR_CONST_LAYOUT_FRAMES) ? GLAMR_CONST_LAYOUT_FRAMES : max_len;
 }
 
-GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) {
-  glamr_param_layout l;
-  param_layout(max_persons, max_len, l);
-  const size_t T = (size_t)max_len;
-  size_t n = 3 * (size_t)l.person0 + 4 * 12 * T + 3 * T + 2 * T + 64;                       // cm cv cg | cam_inv g_cam g_caminv g_avg | fill_src n_vis | pair_first
-  n += (size_t)max_persons * (3 * (size_t)l.person_stride + (1 + 2 + 2 + 6 + 3 + 6 + 3 + 1 + 2 + 12 + 6 * NJ + 1 + 1 + 6) * T + 32);   // m v g | theta csn xy d6 tw g_d6 g_tw g_theta g_xy Lc | kpc vis_rank h_prior oc6 | kp_wsum
-  return n;
+// ---- view builders --------------------------------------------------------------------------------------------------------
+// TMC > 0 (constant-layout instances: one person, full arena, Adam state on chip): every arena array is the arena's base -- a link-time
+// constant -- plus a compile-time offset, every workspace array the workspace base plus a compile-time offset, and the stage-constant
+// inputs are read from their workspace copies: nothing is fetched from the scene description and no pointer occupies a register.
+template <int FAST, bool AF = false, int TMC = 0, class RT>
+GLAMR_HD PersonView person_view(RT& rt, const Scene& sc, int p) {
+  const PersonConst& c = sc.pc[p];
+  const PersonState& s = sc.ps[p];
+  PersonView w;
+  w.fr_start = uni(c.fr_start); w.fr_end = uni(c.fr_end); w.njc = uni(s.njc); w.njc_fast = uni(s.njc_fast);
+  w.j_local = glob(c.j_local); w.kp_2d = glob(c.kp_2d); w.kp_score = glob(c.kp_score);      // last evaluation only
+  w.orient_world = glob(s.orient_world); w.trans_world = glob(s.trans_world); w.kp_2d_pred = glob(s.kp_2d_pred); w.orient_cam_in_world = glob(s.orient_cam_in_world);
+  if constexpr (TMC > 0) {
+    constexpr SceneOff o = scene_offsets(1, TMC, true, 1);
+    constexpr PersonOff q = o.ps[0];
+    float* const A = rt.arena();
+    float* const W = rt.workspace();
+    w.vis = W + q.in_vis.off; w.cam_K = W + q.in_cam_K.off; w.prior = W + q.in_prior.off; w.base_orient = W + q.in_base_orient.off;
+    w.base_trans = W + q.in_base_trans.off; w.person2cam = W + q.in_person2cam.off; w.dheading_mask = W + q.in_dmask.off;
+    w.h_prior = W + q.h_prior.off; w.oc6 = W + q.oc6.off; w.kp_wsum = W + q.kp_wsum.off; w.vis_rank = reinterpret_cast<const int*>(W + q.vis_rank.off);
+    w.g = nullptr;                                                        // gradients are not recorded by these instances
+    w.p = A + q.p.off; w.m = A + q.m.off; w.v = A + q.v.off;
+    w.theta = A + q.theta.off; w.csn = A + q.csn.off; w.xy = A + q.xy.off; w.d6 = A + q.d6.off; w.g_theta = A + q.g_theta.off; w.g_xy = A + q.g_xy.off;
+    w.tw = A + q.tw.off; w.g_d6 = A + q.g_d6.off; w.g_tw = A + q.g_tw.off; w.Lc = A + q.Lc.off;
+    w.kpc = A + o.fast_end; w.kpc_ws = W + q.kpc_ws.off;
+    return w;
+  } else {
+    w.vis = glob(c.vis); w.cam_K = glob(c.cam_K); w.prior = glob(c.prior);
+    w.base_orient = glob(c.base_orient); w.base_trans = glob(c.base_trans); w.person2cam = glob(c.person2cam); w.dheading_mask = glob(c.dheading_mask);
+    w.h_prior = glob(s.h_prior); w.oc6 = glob(s.oc6); w.kp_wsum = glob(s.kp_wsum); w.vis_rank = glob(c.vis_rank);
+    w.g = glob(s.g);
+    // parameters + Adam moments: in the on-chip arena for single-person scenes with the full arena (AF), else batch array / workspace
+    if (AF) { w.p = fastp<1>(s.p); w.m = fastp<1>(s.m); w.v = fastp<1>(s.v); } else { w.p = glob(s.p); w.m = glob(s.m); w.v = glob(s.v); }
+    // first group (prefix sums, neighbour reads): on chip with either arena; second group (own-frame hand-over arrays): full arena only
+    w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy);
+    w.tw = fastp2<FAST>(s.tw); w.g_d6 = fastp2<FAST>(s.g_d6); w.g_tw = fastp2<FAST>(s.g_tw); w.Lc = fastp2<FAST>(s.Lc);
+    w.kpc = fastp<FAST>(s.kpc); w.kpc_ws = glob(s.kpc_ws);      // kpc is only dereferenced for the njc_fast joints that are on chip
+    return w;
+  }
+}
+template <int FAST, bool AF = false, int TMC = 0, class RT>
+GLAMR_HD SceneView scene_view(RT& rt, const Scene& sc) {
+  SceneView w;
+  w.rel_cam = glob(sc.rel_cam); w.cam_pose = glob(sc.cam_pose); w.cpg = glob(sc.cp_g); w.losses = glob(sc.losses);
+  w.rel_stride_p = uni(sc.rel_stride_p); w.rel_stride_t = uni(sc.rel_stride_t);
+  if constexpr (TMC > 0) {
+    constexpr SceneOff o = scene_offsets(1, TMC, true, 1);
+    float* const A = rt.arena();
+    float* const W = rt.workspace();
+    w.pair_first = reinterpret_cast<const int*>(W + o.pair_first.off); w.fill_src = reinterpret_cast<const int*>(W + o.fill_src.off);
+    w.n_vis_persons = reinterpret_cast<const int*>(W + o.n_vis_persons.off);
+    w.cam_inv = A + o.cam_inv.off; w.cam_t = A + o.cam_t.off; w.g_cam = W + o.g_cam.off; w.g_caminv = W + o.g_caminv.off; w.g_avg = W + o.g_avg.off;
+    w.cp = A + o.cp.off; w.cm = A + o.cm.off; w.cv = A + o.cv.off;
+    w.cg = nullptr; w.store_grad = 0; w.TM = TMC;
+    return w;
+  } else {
+    w.pair_first = glob(sc.pair_first); w.fill_src = glob(sc.fill_src); w.n_vis_persons = glob(sc.n_vis_persons);
+    w.cam_inv = fastp<FAST>(sc.cam_inv); w.cam_t = fastp<FAST>(sc.cam_t); w.g_cam = glob(sc.g_cam); w.g_caminv = glob(sc.g_caminv); w.g_avg = glob(sc.g_avg);
+    w.cg = glob(sc.cg);
+    if (AF) { w.cp = fastp<1>(sc.cp); w.cm = fastp<1>(sc.cm); w.cv = fastp<1>(sc.cv); } else { w.cp = glob(sc.cp); w.cm = glob(sc.cm); w.cv = glob(sc.cv); }
+    w.store_grad = uni(sc.store_grad); w.TM = uni(sc.TM);
+    return w;
+  }
 }
 
 // Binds scene `si` of the batch to pointers (no computation).  `ws` = this scene's workspace slice.
 GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layout& l, const glamr_stage_desc* st, int si,
                              int n_persons, int seq_len, float* ws, float* grads_out, Scene& sc, float* fast = nullptr,
-                             size_t fast_floats = 0, int fast_mode = 1) {
-  const size_t TM = (size_t)b.max_len;
+                             size_t fast_floats = 0, int fast_mode = 1, int layout_len = 0) {
+  const size_t TM = (size_t)b.max_len;                                   // strides of the batch arrays
+  const int TML = layout_len > 0 ? layout_len : b.max_len;               // strides of the arena / workspace arrays
+  const SceneOff o = scene_offsets(b.max_persons, TML, fast != nullptr, fast_mode);
+  auto at = [&](const ArrOff& a) { return (a.lds ? fast : ws) + a.off; };
+  auto ati = [&](const ArrOff& a) { return reinterpret_cast<int*>(at(a)); };
   sc.P = n_persons; sc.T = seq_len; sc.lay = &l; sc.st = st;
   sc.rel_cam = b.rel_transform_cam ? b.rel_transform_cam + (size_t)si * b.max_persons * b.max_persons * TM * 12 : nullptr;
   sc.cam_pose = b.cam_pose + (size_t)si * TM * 12;
   sc.cp_g = b.params + (size_t)si * l.scene_stride;
-  sc.cp = sc.cp_g;
+  sc.cp = o.adam_fast ? at(o.cp) : sc.cp_g;
   sc.losses = b.losses + (size_t)si * GLAMR_NUM_LOSSES;
   sc.store_grad = grads_out != nullptr;
-  float* w = ws;
-  auto take = [&](size_t n) { float* r = w; w += n; return r; };
-  // arrays other threads read (neighbouring frames, prefix sums) go to the on-chip arena when the caller provides one
-  float* f = fast;
-  auto takef = [&](size_t n) { if (!fast) return take(n); float* r = f; f += n; return r; };
-  auto takef2 = [&](size_t n) { if (!fast || fast_mode != 1) return take(n); float* r = f; f += n; return r; };      // second group
-  const bool adam_fast = fast && fast_mode == 1 && b.max_persons == 1;
-  auto takea = [&](size_t n) { if (!adam_fast) return take(n); float* r = f; f += n; return r; };
-  // the moments of the camera block use a COMPACT index: camera parameters i, camera residuals i - 9 T (see cam_mv_index)
-  float* cm_ws = take(l.person0); float* cv_ws = take(l.person0);
-  sc.cm = adam_fast ? takea(9 * TM) : cm_ws; sc.cv = adam_fast ? takea(9 * TM) : cv_ws;
-  if (adam_fast) sc.cp = takea(9 * TM);
-  float* cg_ws = take(l.person0);
-  sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : cg_ws;
-  sc.cam_inv = takef(12 * TM); sc.cam_t = takef(3 * TM); sc.g_cam = take(12 * TM); sc.g_caminv = take(12 * TM); sc.g_avg = take(12 * TM);
-  sc.fill_src = reinterpret_cast<int*>(take(TM)); sc.n_vis_persons = reinterpret_cast<int*>(take(TM));
-  sc.pair_first = reinterpret_cast<int*>(take(64));
+  sc.cm = at(o.cm); sc.cv = at(o.cv);
+  sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : at(o.cg_ws);
+  sc.cam_inv = at(o.cam_inv); sc.cam_t = at(o.cam_t); sc.g_cam = at(o.g_cam); sc.g_caminv = at(o.g_caminv); sc.g_avg = at(o.g_avg);
+  sc.fill_src = ati(o.fill_src); sc.n_vis_persons = ati(o.n_vis_persons); sc.pair_first = ati(o.pair_first);
   for (int p = 0; p < b.max_persons; ++p) {
     const size_t slot = (size_t)si * b.max_persons + p;
+    const PersonOff& q = o.ps[p];
     PersonConst& c = sc.pc[p];
     PersonState& s = sc.ps[p];
     s.p_g = sc.cp_g + l.person0 + (size_t)p * l.person_stride;
-    s.p = s.p_g;
-    float* m_ws = take(l.person_stride); float* v_ws = take(l.person_stride);
-    s.m = adam_fast ? takea(l.person_stride) : m_ws; s.v = adam_fast ? takea(l.person_stride) : v_ws;
-    if (adam_fast) s.p = takea(l.person_stride);
-    float* g_ws = take(l.person_stride);
-    s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : g_ws;
-    s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef2(3 * TM); s.g_d6 = takef2(6 * TM); s.g_tw = takef2(3 * TM);
-    s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef2(12 * TM);
-    s.kpc_ws = take((size_t)NJ * 6 * TM); s.kpc = s.kpc_ws; s.njc = 0; s.njc_fast = 0;
-    c.vis_rank = reinterpret_cast<int*>(take(TM));
-    s.kp_wsum = take(32);
-    s.h_prior = take(TM); s.oc6 = take(6 * TM);
+    s.p = o.adam_fast ? at(q.p) : s.p_g;
+    s.m = at(q.m); s.v = at(q.v);
+    s.g = grads_out ? sc.cg + l.person0 + (size_t)p * l.person_stride : at(q.g_ws);
+    s.theta = at(q.theta); s.csn = at(q.csn); s.xy = at(q.xy); s.d6 = at(q.d6); s.tw = at(q.tw); s.g_d6 = at(q.g_d6); s.g_tw = at(q.g_tw);
+    s.g_theta = at(q.g_theta); s.g_xy = at(q.g_xy); s.Lc = at(q.Lc);
+    s.kpc_ws = at(q.kpc_ws); s.kpc = s.kpc_ws; s.njc = 0; s.njc_fast = 0;
+    c.vis_rank = ati(q.vis_rank);
+    s.kp_wsum = at(q.kp_wsum);
+    s.h_prior = at(q.h_prior); s.oc6 = at(q.oc6);
+    s.in_vis = at(q.in_vis); s.in_cam_K = at(q.in_cam_K); s.in_prior = at(q.in_prior); s.in_base_orient = at(q.in_base_orient);
+    s.in_base_trans = at(q.in_base_trans); s.in_person2cam = at(q.in_person2cam); s.in_dmask = at(q.in_dmask);
     c.fr_start = b.fr_start[slot]; c.fr_end = b.fr_end[slot];
     c.vis = b.vis + slot * TM;
     c.j_local = b.j_local + slot * TM * NJ * 3;
@@ -447,9 +526,10 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     s.kp_2d_pred = b.kp_2d_pred + slot * TM * NJ * 2;
     s.orient_cam_in_world = b.orient_cam_in_world + slot * TM * 3;
   }
-  sc.fast_free = fast ? f : nullptr;
-  sc.fast_left = fast ? fast_floats - (size_t)(f - fast) : 0;
-  sc.TM = (int)TM;
+  sc.fast_free = fast ? fast + o.fast_end : nullptr;
+  sc.fast_left = fast ? fast_floats - (size_t)o.fast_end : 0;
+  sc.TM = TML;
+  sc.ws = ws;
   sc.adam_tab = nullptr;
   // rel_transform_cam is indexed with the padded person count
   sc.rel_stride_p = b.max_persons;
@@ -491,8 +571,8 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
 
 // loss_func.py:248-271 for person p at frame t (both ordered pairs it takes part in).  Returns the unweighted sum of squares of the
 // pairs (p, o) and adds the gradient w.r.t. p's world transform [Rk | tw].
-template <int FAST>
-GLAMR_HD float rel_transform_term(const Scene& sc, const SceneView& sh, const glamr_stage_desc& st, int P, int p, int t, const float* Rk,
+template <int FAST, class RT>
+GLAMR_HD float rel_transform_term(RT& rt, const Scene& sc, const SceneView& sh, const glamr_stage_desc& st, int P, int p, int t, const float* Rk,
                                            const float* tw, float w_rel, float* gRk, float* g_tw) {
   float value = 0.f;
     float Ti[12];
@@ -502,10 +582,10 @@ GLAMR_HD float rel_transform_term(const Scene& sc, const SceneView& sh, const gl
     float gTi[12];
     for (int k = 0; k < 12; ++k) gTi[k] = 0.f;
     for (int o = 0; o < P; ++o) {
-      if (o == p || person_view<FAST>(sc, o).vis[t] == 0.f) continue;
+      if (o == p || person_view<FAST>(rt, sc, o).vis[t] == 0.f) continue;
       float To[12], Ro[9];
-      cols_to_R(person_view<FAST>(sc, o).d6 + t * 6, Ro);
-      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view<FAST>(sc, o).tw[t * 3 + i]; }
+      cols_to_R(person_view<FAST>(rt, sc, o).d6 + t * 6, Ro);
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view<FAST>(rt, sc, o).tw[t * 3 + i]; }
       float Toinv[12];
       invert34(To, Toinv);
       // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
@@ -558,13 +638,31 @@ inline int camera_mode(const glamr_stage_desc& st) {
 template <class RT> GLAMR_HD auto trace_hook(RT& rt, int it, Scene& sc, int) -> decltype(rt.trace(it, sc), void()) { rt.trace(it, sc); }
 template <class RT> GLAMR_HD void trace_hook(RT&, int, Scene&, long) {}
 
-template <int FAST, bool SINGLE, int CAM, class RT>
+// person parameter block from one layout to another, segment by segment (layouts of different frame counts: the shorter segment)
+template <class RT>
+GLAMR_HD void copy_person_block(RT& rt, float* dst, const glamr_param_layout& ld, const float* src, const glamr_param_layout& ls) {
+  const int so[8] = {ls.local_xy, ls.local_heading, ls.local_dxy, ls.local_dheading, ls.local_z, ls.local_rot, ls.world_dheading, ls.person_stride};
+  const int dof[8] = {ld.local_xy, ld.local_heading, ld.local_dxy, ld.local_dheading, ld.local_z, ld.local_rot, ld.world_dheading, ld.person_stride};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int ns = so[k + 1] - so[k], nd = dof[k + 1] - dof[k], n = ns < nd ? ns : nd;
+    for (int i = rt.tid(); i < n; i += rt.nthreads()) dst[dof[k] + i] = src[so[k] + i];
+  }
+}
+
+// TMC > 0: constant-layout instance (see the view builders): arena / workspace arrays laid out for TMC frames, on-chip parameter blocks in
+// the parameter layout of TMC frames (`lo`; the batch arrays keep the batch's own layout `l`).
+template <int TMC> struct OnChipLayout { static constexpr glamr_param_layout value = make_layout(1, TMC > 0 ? TMC : 2); };
+template <int FAST, bool SINGLE, int CAM, int TMC = 0, class RT>
 GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const glamr_param_layout& l) {
   constexpr bool AF = FAST == 1 && SINGLE;          // parameters + Adam moments on chip (assemble_scene: adam_fast)
+  static_assert(TMC == 0 || AF, "constant layouts are for single-person scenes with the full arena");
+  const glamr_param_layout& lo = TMC > 0 ? OnChipLayout<TMC>::value : l;      // layout of the on-chip parameter / moment blocks
+  auto pv = [&](int p) { return person_view<FAST, AF, TMC>(rt, sc, p); };
   // Frame loops of the full-arena instances make ONE pass (the launcher only selects them when every frame has its own thread): with
   // a step the compiler can see is larger than any sequence the loop is an `if`, and no per-array 64-bit induction pointers stay
   // live across the whole body (two registers each, a few dozen arrays).
-  const int fstep = FAST == 1 ? (1 << 20) : rt.nthreads();
+  const int fstep = (FAST == 1 && RT::one_thread_per_frame) ? (1 << 20) : rt.nthreads();
   const int T = sc.T, P = SINGLE ? 1 : sc.P;
   const bool var_cam = CAM != 0 ? true : (bool)(st.var_mask & GLAMR_VAR_CAM);
   const bool fixed_cam = CAM == 2 ? true : (CAM == 1 ? false : (bool)(st.flags & GLAMR_FLAG_FIXED_CAM));
@@ -585,24 +683,44 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     n_exist += (float)n;
     n_exist_m1 += (float)(n - 1);
   }
-  for (int i = rt.tid(); i < l.person0; i += rt.nthreads()) { sc.cg[i] = 0.f; if (i < l.cam_inv_rot_res) { sc.cm[i] = 0.f; sc.cv[i] = 0.f; } }      // moments: compact 9 T
-  for (int p = 0; p < P; ++p)
-    for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) { sc.ps[p].m[i] = 0.f; sc.ps[p].v[i] = 0.f; sc.ps[p].g[i] = 0.f; }
-  const int rs = AF ? l.cam_inv_rot_res : 0;          // index shift of the camera residuals in the on-chip (compact) camera block
+  for (int i = rt.tid(); i < l.person0; i += rt.nthreads()) sc.cg[i] = 0.f;
+  for (int i = rt.tid(); i < lo.cam_inv_rot_res; i += rt.nthreads()) { sc.cm[i] = 0.f; sc.cv[i] = 0.f; }      // moments: compact 9 T
+  for (int p = 0; p < P; ++p) {
+    for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) sc.ps[p].g[i] = 0.f;
+    for (int i = rt.tid(); i < lo.person_stride; i += rt.nthreads()) { sc.ps[p].m[i] = 0.f; sc.ps[p].v[i] = 0.f; }
+  }
+  const int rs = AF ? lo.cam_inv_rot_res : 0;          // index shift of the camera residuals in the on-chip (compact) camera block
+  const int Tb = l.cam_trans / 6;                      // frames of the batch layout
   if (AF) {
     // parameters on chip: the person block as it is; the camera block = the residuals unless the stage optimises the camera itself (then
     // it is initialised from the camera poses right below)
-    for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) sc.ps[0].p[i] = sc.ps[0].p_g[i];
-    if (!var_cam) for (int i = rt.tid(); i < l.cam_inv_rot_res; i += rt.nthreads()) sc.cp[i] = sc.cp_g[l.cam_inv_rot_res + i];
+    copy_person_block(rt, sc.ps[0].p, lo, sc.ps[0].p_g, l);
+    if (!var_cam) {
+      for (int i = rt.tid(); i < 6 * Tb; i += rt.nthreads()) sc.cp[i] = sc.cp_g[l.cam_inv_rot_res + i];
+      for (int i = rt.tid(); i < 3 * Tb; i += rt.nthreads()) sc.cp[lo.cam_trans + i] = sc.cp_g[l.cam_inv_trans_res + i];
+    }
+  }
+  if (TMC > 0) {
+    // stage-constant inputs next to the rest of the workspace: the loop reads them at constant offsets (a missing heading mask = zeros)
+    const PersonConst& c = sc.pc[0];
+    PersonState& s = sc.ps[0];
+    for (int t = rt.tid(); frame_in(t, T); t += fstep) {
+      s.in_vis[t] = c.vis[t];
+      s.in_dmask[t] = c.dheading_mask ? c.dheading_mask[t] : 0.f;
+      for (int k = 0; k < 9; ++k) s.in_cam_K[t * 9 + k] = c.cam_K[(size_t)t * 9 + k];
+      for (int k = 0; k < 11; ++k) s.in_prior[t * 11 + k] = c.prior[(size_t)t * 11 + k];
+      for (int k = 0; k < 3; ++k) { s.in_base_orient[t * 3 + k] = c.base_orient[t * 3 + k]; s.in_base_trans[t * 3 + k] = c.base_trans[t * 3 + k]; }
+      for (int k = 0; k < 12; ++k) s.in_person2cam[t * 12 + k] = c.person2cam[(size_t)t * 12 + k];
+    }
   }
   if (var_cam) {
     const int rows = fixed_cam ? 1 : T;
     for (int t = rt.tid(); t < rows; t += rt.nthreads()) {
       const float* M = sc.cam_pose + (size_t)t * 12;
       for (int r = 0; r < 3; ++r) {
-        sc.cp[l.cam_rot6d + t * 6 + r] = M[r * 4 + 0];
-        sc.cp[l.cam_rot6d + t * 6 + 3 + r] = M[r * 4 + 1];
-        sc.cp[l.cam_trans + t * 3 + r] = M[r * 4 + 3];
+        sc.cp[lo.cam_rot6d + t * 6 + r] = M[r * 4 + 0];
+        sc.cp[lo.cam_rot6d + t * 6 + 3 + r] = M[r * 4 + 1];
+        sc.cp[lo.cam_trans + t * 3 + r] = M[r * 4 + 3];
       }
     }
   }
@@ -672,7 +790,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   double b1p = 1.0, b2p = 1.0;
   int n_done = 0;
   const int n_eval = niters > 0 ? niters : 1;
-  const SceneView sh = scene_view<FAST, AF>(sc);
+  const SceneView sh = scene_view<FAST, AF, TMC>(rt, sc);
   // One evaluation (+ update).  Instantiated twice: the iterations that only update (no reported values, no outputs) and the LAST
   // evaluation, which also writes the outputs and reduces the loss values -- keeping that code (axis-angle conversions, all 26
   // joints, 13 accumulators) out of the hot instance keeps its registers out of it too.
@@ -698,59 +816,59 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST, AF>(sc, p);
+        const PersonView c = pv(p);
         float v = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
-          const LocalRow L = local_row(c, l, t - c.fr_start);
-          store_row(person_view<FAST, AF>(sc, p).Lc, sh.TM, t, L);
+          const LocalRow L = local_row(c, lo, t - c.fr_start);
+          store_row(pv(p).Lc, sh.TM, t, L);
           // atan2(sin h, cos h) of the reference (:401-405) only wraps h into (-pi, pi]: done arithmetically
           v = L.h - 6.28318530717958647692f * rintf(L.h * 0.15915494309189533577f);
         }
-        person_view<FAST, AF>(sc, p).theta[t] = v;
+        pv(p).theta[t] = v;
       }
     {
       float* ch[8];
-      for (int p = 0; p < P; ++p) ch[p] = person_view<FAST, AF>(sc, p).theta;
+      for (int p = 0; p < P; ++p) ch[p] = pv(p).theta;
       rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false);
     }
     // own element of the prefix sum is final: its cos / sin serve phases B, C and I (this frame's and the next frame's)
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         float sn, cs;
-        rm::sincos_(person_view<FAST, AF>(sc, p).theta[t], sn, cs);
-        person_view<FAST, AF>(sc, p).csn[t * 2 + 0] = cs;
-        person_view<FAST, AF>(sc, p).csn[t * 2 + 1] = sn;
+        rm::sincos_(pv(p).theta[t], sn, cs);
+        pv(p).csn[t * 2 + 0] = cs;
+        pv(p).csn[t * 2 + 1] = sn;
       }
     rt.sync();
     GLAMR_MARK(rt, 0);
     // ---- B: planar displacement in world axes -------------------------------------------------------------------------
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST, AF>(sc, p);
+        const PersonView c = pv(p);
         float dx = 0.f, dy = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const int e = t - c.fr_start;
-          const LocalRow L = load_row(person_view<FAST, AF>(sc, p).Lc, sh.TM, t);
+          const LocalRow L = load_row(pv(p).Lc, sh.TM, t);
           dx = L.dx; dy = L.dy;
           if (e > 0) {
-            const float cs = person_view<FAST, AF>(sc, p).csn[(t - 1) * 2 + 0], sn = person_view<FAST, AF>(sc, p).csn[(t - 1) * 2 + 1];
+            const float cs = pv(p).csn[(t - 1) * 2 + 0], sn = pv(p).csn[(t - 1) * 2 + 1];
             dx = L.dx * cs - L.dy * sn;
             dy = L.dx * sn + L.dy * cs;
           }
         }
-        person_view<FAST, AF>(sc, p).xy[t * 2 + 0] = dx;
-        person_view<FAST, AF>(sc, p).xy[t * 2 + 1] = dy;
+        pv(p).xy[t * 2 + 0] = dx;
+        pv(p).xy[t * 2 + 1] = dy;
       }
     {
       float* ch[16];
-      for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST, AF>(sc, p).xy; ch[2 * p + 1] = person_view<FAST, AF>(sc, p).xy + 1; }
+      for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).xy; ch[2 * p + 1] = pv(p).xy + 1; }
       rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, false);
     }
     GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
     for (int t = rt.tid(); frame_in(t, T); t += fstep) {
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST, AF>(sc, p);
+        const PersonView c = pv(p);
         const PersonView& s = c;
         float c1[3], c2[3], tb[3], phi = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
@@ -766,7 +884,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           for (int k = 0; k < 3; ++k) { c1[k] = Rb[k * 3 + 0]; c2[k] = Rb[k * 3 + 1]; tb[k] = c.base_trans[t * 3 + k]; }
         }
         float sn = 0.f, cs = 1.f;
-        if (has_wd) { phi += s.p[l.world_dheading + t]; rm::sincos_(phi, sn, cs); }
+        if (has_wd) { phi += s.p[lo.world_dheading + t]; rm::sincos_(phi, sn, cs); }
         else if (t >= c.fr_start && t < c.fr_end) { cs = s.csn[t * 2 + 0]; sn = s.csn[t * 2 + 1]; }
         float w1[3], w2[3];
         rotz2(cs, sn, c1, w1);
@@ -791,8 +909,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         if (var_cam) {
           const int row = fixed_cam ? 0 : t;
           float R[9];
-          rm::rot6d_to_rotmat(sh.cp + l.cam_rot6d + row * 6, R);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sh.cp[l.cam_trans + row * 3 + i]; }
+          rm::rot6d_to_rotmat(sh.cp + lo.cam_rot6d + row * 6, R);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sh.cp[lo.cam_trans + row * 3 + i]; }
         } else {
           for (int k = 0; k < 12; ++k) M[k] = sh.cam_pose[(size_t)t * 12 + k];
         }
@@ -811,21 +929,21 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float avg[12];
         for (int k = 0; k < 12; ++k) avg[k] = 0.f;
         for (int p = 0; p < P; ++p) {
-          if (person_view<FAST, AF>(sc, p).vis[src] == 0.f) continue;
+          if (pv(p).vis[src] == 0.f) continue;
           float Tw[12], Rk[9], C[12];
-          cols_to_R(person_view<FAST, AF>(sc, p).d6 + src * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST, AF>(sc, p).tw[src * 3 + i]; }
-          mul34(Tw, person_view<FAST, AF>(sc, p).person2cam + (size_t)src * 12, C);
+          cols_to_R(pv(p).d6 + src * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = pv(p).tw[src * 3 + i]; }
+          mul34(Tw, pv(p).person2cam + (size_t)src * 12, C);
           for (int k = 0; k < 12; ++k) avg[k] += C[k];
         }
         const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
         for (int k = 0; k < 12; ++k) avg[k] = avg[k] * inv_n;   // sum(...) / num_persons  (:492)
         float r6[6];
         for (int r = 0; r < 3; ++r) { r6[r] = avg[r * 4 + 0]; r6[3 + r] = avg[r * 4 + 1]; }
-        if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) r6[k] += sh.cp[l.cam_inv_rot_res - rs + t * 6 + k];
+        if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) r6[k] += sh.cp[lo.cam_inv_rot_res - rs + t * 6 + k];
         float R[9];
         rm::rot6d_to_rotmat(r6, R);
-        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sh.cp[l.cam_inv_trans_res - rs + t * 3 + i]; }
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mi[i * 4 + j] = R[i * 3 + j]; Mi[i * 4 + 3] = avg[i * 4 + 3] + sh.cp[lo.cam_inv_trans_res - rs + t * 3 + i]; }
         invert34(Mi, M);
         for (int k = 0; k < 12; ++k) sh.cam_inv[(size_t)t * 12 + k] = Mi[k];
         for (int k = 0; k < 3; ++k) sh.cam_t[t * 3 + k] = M[k * 4 + 3];
@@ -861,7 +979,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = Mi[j * 4 + i]; M[i * 4 + 3] = sh.cam_t[t * 3 + i]; }
       get_R(M, Rc);
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST, AF>(sc, p);
+        const PersonView c = pv(p);
         const PersonView& s = c;
         const float* tw = s.tw + t * 3;
         float K[9], tgt[6];
@@ -1019,7 +1137,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       // the camera's parameter state is requested here: the smoothness terms below cover the latency
       AdamRegs<6> a_rot;
       AdamRegs<3> a_tr;
-      if (own_cam) { a_rot.load(sh.cp, sh.cm, sh.cv, l.cam_rot6d + t * 6); a_tr.load(sh.cp, sh.cm, sh.cv, l.cam_trans + t * 3); }
+      if (own_cam) { a_rot.load(sh.cp, sh.cm, sh.cv, lo.cam_rot6d + t * 6); a_tr.load(sh.cp, sh.cm, sh.cv, lo.cam_trans + t * 3); }
       // camera-only terms on the camera-to-world transform  (loss_func.py:76-114)
       if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i)
@@ -1049,19 +1167,19 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
         get_R(gC, gR);
         if (fixed_cam) {
-          rm::rot6d_to_rotmat_bwd(sh.cp + l.cam_rot6d + row * 6, gR, g6);
+          rm::rot6d_to_rotmat_bwd(sh.cp + lo.cam_rot6d + row * 6, gR, g6);
           for (int k = 0; k < 6; ++k) gfix[k] += g6[k];
           for (int k = 0; k < 3; ++k) gfix[6 + k] += gC[k * 4 + 3];
         } else {
           rm::rot6d_to_rotmat_bwd(a_rot.P, gR, g6);
           const float gt3[3] = {gC[3], gC[7], gC[11]};
-          a_rot.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, l.cam_rot6d + t * 6, g6, ac);
-          a_tr.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, l.cam_trans + t * 3, gt3, ac);
+          a_rot.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, lo.cam_rot6d + t * 6, g6, ac);
+          a_tr.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, lo.cam_trans + t * 3, gt3, ac);
         }
       }
       if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
         for (int k = 0; k < 3; ++k) {      // (with the camera optimised the on-chip block holds the camera, the residuals stay in the batch array)
-          const float r = (var_cam ? sh.cpg[l.cam_inv_trans_res + t * 3 + k] : sh.cp[l.cam_inv_trans_res - rs + t * 3 + k]) * FPS;
+          const float r = (var_cam ? sh.cpg[l.cam_inv_trans_res + t * 3 + k] : sh.cp[lo.cam_inv_trans_res - rs + t * 3 + k]) * FPS;
           if (last) lsum[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] += r * r;
         }
     }
@@ -1070,12 +1188,12 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     if (!SINGLE && on(GLAMR_LOSS_REL_TRANSFORM) && P > 1)
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
-          const PersonView s = person_view<FAST, AF>(sc, p);
+          const PersonView s = pv(p);
           if (s.vis[t] == 0.f) continue;
           float Rk[9], gRk[9], g_tw[3] = {0, 0, 0}, g6[6];
           for (int k = 0; k < 9; ++k) gRk[k] = 0.f;
           cols_to_R(s.d6 + t * 6, Rk);
-          const float v = rel_transform_term<FAST>(sc, sh, st, P, p, t, Rk, s.tw + t * 3, w_rel, gRk, g_tw);
+          const float v = rel_transform_term<FAST>(rt, sc, sh, st, P, p, t, Rk, s.tw + t * 3, w_rel, gRk, g_tw);
           if (last) lsum[GLAMR_LOSS_REL_TRANSFORM] += v;
           fold_R_grad(s.d6 + t * 6, gRk, g6);
           for (int k = 0; k < 6; ++k) s.g_d6[t * 6 + k] += g6[k];
@@ -1085,8 +1203,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     if (update && var_cam && fixed_cam) {
       for (int k = 0; k < 9; ++k) gfix[k] = rt.reduce_sum(gfix[k]);
       if (rt.tid() == 0) {
-        for (int k = 0; k < 6; ++k) { const int i = l.cam_rot6d + k; if (sh.store_grad) sh.cg[i] = gfix[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[k], ac); }
-        for (int k = 0; k < 3; ++k) { const int i = l.cam_trans + k; if (sh.store_grad) sh.cg[i] = gfix[6 + k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[6 + k], ac); }
+        for (int k = 0; k < 6; ++k) { const int i = lo.cam_rot6d + k; if (sh.store_grad) sh.cg[i] = gfix[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[k], ac); }
+        for (int k = 0; k < 3; ++k) { const int i = lo.cam_trans + k; if (sh.store_grad) sh.cg[i] = gfix[6 + k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[6 + k], ac); }
       }
     } else if (update && cam_from_person) {
       // ---- G (camera derived from the persons): gradient of every frame's averaged transform, folded onto its source frame ----
@@ -1102,16 +1220,16 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           float avg[12];
           for (int k = 0; k < 12; ++k) avg[k] = 0.f;
           for (int p = 0; p < P; ++p) {
-            if (person_view<FAST, AF>(sc, p).vis[src] == 0.f) continue;
+            if (pv(p).vis[src] == 0.f) continue;
             float Tw[12], Rk[9], C[12];
-            cols_to_R(person_view<FAST, AF>(sc, p).d6 + src * 6, Rk);
-            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST, AF>(sc, p).tw[src * 3 + i]; }
-            mul34(Tw, person_view<FAST, AF>(sc, p).person2cam + (size_t)src * 12, C);
+            cols_to_R(pv(p).d6 + src * 6, Rk);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = pv(p).tw[src * 3 + i]; }
+            mul34(Tw, pv(p).person2cam + (size_t)src * 12, C);
             for (int k = 0; k < 12; ++k) avg[k] += C[k];
           }
           const float inv_n = 1.0f / (float)sh.n_vis_persons[src];
           for (int r = 0; r < 3; ++r) { avg6[r] = avg[r * 4 + 0] * inv_n; avg6[3 + r] = avg[r * 4 + 1] * inv_n; }
-          if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) avg6[k] += sh.cp[l.cam_inv_rot_res - rs + t * 6 + k];
+          if (sh.n_vis_persons[t] == 0) for (int k = 0; k < 6; ++k) avg6[k] += sh.cp[lo.cam_inv_rot_res - rs + t * 6 + k];
         }
         float gR[9], g6[6] = {0, 0, 0, 0, 0, 0};
         get_R(gMi, gR);
@@ -1121,11 +1239,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float g_tres[3] = {gMi[3], gMi[7], gMi[11]};
         if (active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
           const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
-          for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sh.cp[l.cam_inv_trans_res - rs + t * 3 + k] * wreg;
+          for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sh.cp[lo.cam_inv_trans_res - rs + t * 3 + k] * wreg;
         }
-        for (int k = 0; k < 3; ++k) { const int i = l.cam_inv_trans_res + t * 3 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g_tres[k]; adam(sh.cp[i - rs], sh.cm[j], sh.cv[j], g_tres[k], ac); }
+        for (int k = 0; k < 3; ++k) { const int i = lo.cam_inv_trans_res + t * 3 + k, j = i - lo.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g_tres[k]; adam(sh.cp[i - rs], sh.cm[j], sh.cv[j], g_tres[k], ac); }
         if (sh.n_vis_persons[t] == 0)
-          for (int k = 0; k < 6; ++k) { const int i = l.cam_inv_rot_res + t * 6 + k, j = i - l.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i - rs], sh.cm[j], sh.cv[j], g6[k], ac); }
+          for (int k = 0; k < 6; ++k) { const int i = lo.cam_inv_rot_res + t * 6 + k, j = i - lo.cam_inv_rot_res; if (sh.store_grad) sh.cg[i] = g6[k]; adam(sh.cp[i - rs], sh.cm[j], sh.cv[j], g6[k], ac); }
       }
       rt.sync();
       for (int t = rt.tid(); frame_in(t, T); t += fstep) {
@@ -1139,17 +1257,17 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         const float inv_n = 1.0f / (float)sh.n_vis_persons[t];
         for (int k = 0; k < 12; ++k) ga[k] *= inv_n;
         for (int p = 0; p < P; ++p) {
-          if (person_view<FAST, AF>(sc, p).vis[t] == 0.f) continue;
+          if (pv(p).vis[t] == 0.f) continue;
           float Tw[12], Rk[9], gTw[12];
           for (int k = 0; k < 12; ++k) gTw[k] = 0.f;
-          cols_to_R(person_view<FAST, AF>(sc, p).d6 + t * 6, Rk);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = person_view<FAST, AF>(sc, p).tw[t * 3 + i]; }
-          mul34_bwd(Tw, person_view<FAST, AF>(sc, p).person2cam + (size_t)t * 12, ga, gTw, nullptr);
+          cols_to_R(pv(p).d6 + t * 6, Rk);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tw[i * 4 + j] = Rk[i * 3 + j]; Tw[i * 4 + 3] = pv(p).tw[t * 3 + i]; }
+          mul34_bwd(Tw, pv(p).person2cam + (size_t)t * 12, ga, gTw, nullptr);
           float gRk[9], g6[6];
           get_R(gTw, gRk);
-          fold_R_grad(person_view<FAST, AF>(sc, p).d6 + t * 6, gRk, g6);
-          for (int k = 0; k < 6; ++k) person_view<FAST, AF>(sc, p).g_d6[t * 6 + k] += g6[k];
-          for (int k = 0; k < 3; ++k) person_view<FAST, AF>(sc, p).g_tw[t * 3 + k] += gTw[k * 4 + 3];
+          fold_R_grad(pv(p).d6 + t * 6, gRk, g6);
+          for (int k = 0; k < 6; ++k) pv(p).g_d6[t * 6 + k] += g6[k];
+          for (int k = 0; k < 3; ++k) pv(p).g_tw[t * 3 + k] += gTw[k * 4 + 3];
         }
       }
       // the fold writes g_d6 / g_tw of frame t from thread t only: the owner continues without a barrier
@@ -1158,10 +1276,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int k = 0; k < 3; ++k) {
-          const int i = l.cam_inv_trans_res + t * 3 + k;
+          const int i = lo.cam_inv_trans_res + t * 3 + k;
           const float g = 2.0f * FPS * FPS * sh.cp[i - rs] * wreg;
           if (sh.store_grad) sh.cg[i] = g;
-          adam(sh.cp[i - rs], sh.cm[i - l.cam_inv_rot_res], sh.cv[i - l.cam_inv_rot_res], g, ac);
+          adam(sh.cp[i - rs], sh.cm[i - lo.cam_inv_rot_res], sh.cv[i - lo.cam_inv_rot_res], g, ac);
         }
     }
     GLAMR_MARK(rt, 5);
@@ -1172,7 +1290,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
-        const PersonView c = person_view<FAST, AF>(sc, p);
+        const PersonView c = pv(p);
         const PersonView& s = c;
         const bool ex = t >= c.fr_start && t < c.fr_end;
         const int e = t - c.fr_start;
@@ -1183,14 +1301,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         AdamRegs<1> a_wd;
         AdamRegs<6> a_rot;
         AdamRegs<1> a_z;
-        if (upd_wd) a_wd.load(s.p, s.m, s.v, l.world_dheading + t);
-        if (upd_rot) a_rot.load(s.p, s.m, s.v, l.local_rot + e * 6); else if (ex) for (int k = 0; k < 6; ++k) a_rot.P[k] = s.p[l.local_rot + e * 6 + k];
-        if (upd_z) a_z.load(s.p, s.m, s.v, l.local_z + e); else if (ex) a_z.P[0] = s.p[l.local_z + e];
+        if (upd_wd) a_wd.load(s.p, s.m, s.v, lo.world_dheading + t);
+        if (upd_rot) a_rot.load(s.p, s.m, s.v, lo.local_rot + e * 6); else if (ex) for (int k = 0; k < 6; ++k) a_rot.P[k] = s.p[lo.local_rot + e * 6 + k];
+        if (upd_z) a_z.load(s.p, s.m, s.v, lo.local_z + e); else if (ex) a_z.P[0] = s.p[lo.local_z + e];
         // R_w = Rz(phi) [b2 b3 | .]:  d/dphi = J R_w with J = [[0,-1,0],[1,0,0],[0,0,0]]
         const float* d6 = s.d6 + t * 6;
         const float* g6 = s.g_d6 + t * 6;
         const float gphi = (g6[1] * d6[0] - g6[0] * d6[1]) + (g6[4] * d6[3] - g6[3] * d6[4]);
-        if (upd_wd) { const float gw[1] = {gphi}; a_wd.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.world_dheading + t, gw, ac); }
+        if (upd_wd) { const float gw[1] = {gphi}; a_wd.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.world_dheading + t, gw, ac); }
         if (!ex) { s.g_theta[t] = 0.f; s.g_xy[t * 2 + 0] = 0.f; s.g_xy[t * 2 + 1] = 0.f; continue; }
         const LocalRow L = load_row(s.Lc, sh.TM, t);
         const float cs = s.Lc[10 * sh.TM + t], sn = s.Lc[11 * sh.TM + t];
@@ -1215,19 +1333,19 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             if (on(GLAMR_LOSS_LOCAL_ROT_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_ROT_REG] += r * r;
             g6r[k] = gr6[k] + 2.0f * FPS * r * w_rot;
           }
-          if (upd_rot) a_rot.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.local_rot + e * 6, g6r, ac);
+          if (upd_rot) a_rot.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_rot + e * 6, g6r, ac);
         }
         {
           const float r = a_z.P[0] * FPS;
           if (on(GLAMR_LOSS_LOCAL_Z_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_Z_REG] += r * r;
           const float gz[1] = {s.g_tw[t * 3 + 2] + 2.0f * FPS * r * w_z};
-          if (upd_z) a_z.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.local_z + e, gz, ac);
+          if (upd_z) a_z.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_z + e, gz, ac);
         }
       }
     if (update) {
       {
         float* ch[16];
-        for (int p = 0; p < P; ++p) { ch[2 * p] = person_view<FAST, AF>(sc, p).g_xy; ch[2 * p + 1] = person_view<FAST, AF>(sc, p).g_xy + 1; }
+        for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).g_xy; ch[2 * p + 1] = pv(p).g_xy + 1; }
         rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, true);
       }
       rt.sync();
@@ -1235,13 +1353,13 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       // ---- I: reverse of B ----------------------------------------------------------------------------------------------
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
-          const PersonView c = person_view<FAST, AF>(sc, p);
+          const PersonView c = pv(p);
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start, n = c.fr_end - c.fr_start;
           const bool upd_dxy = e > 0 && (st.var_mask & GLAMR_VAR_LOCAL_DXY);
           AdamRegs<2> a_dxy;
-          if (upd_dxy) a_dxy.load(s.p, s.m, s.v, l.local_dxy + e * 2); else if (e > 0) for (int k = 0; k < 2; ++k) a_dxy.P[k] = s.p[l.local_dxy + e * 2 + k];
+          if (upd_dxy) a_dxy.load(s.p, s.m, s.v, lo.local_dxy + e * 2); else if (e > 0) for (int k = 0; k < 2; ++k) a_dxy.P[k] = s.p[lo.local_dxy + e * 2 + k];
           // contribution of d[e+1] = Rot(theta[e]) L[e+1].xy to g_theta[e]
           if (e + 1 < n) {
             const LocalRow Ln = load_row(s.Lc, sh.TM, t + 1);
@@ -1258,7 +1376,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const float g[2] = {gx, gy};
           if (e == 0) {
             if (st.var_mask & GLAMR_VAR_LOCAL_XY)
-              for (int k = 0; k < 2; ++k) { const int i = l.local_xy + k; if (sh.store_grad) s.g[i] = g[k]; adam(s.p[i], s.m[i], s.v[i], g[k], ac); }
+              for (int k = 0; k < 2; ++k) { const int i = lo.local_xy + k; if (sh.store_grad) s.g[i] = g[k]; adam(s.p[i], s.m[i], s.v[i], g[k], ac); }
           } else {
             float g2[2];
             for (int k = 0; k < 2; ++k) {
@@ -1266,27 +1384,27 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
               if (on(GLAMR_LOSS_LOCAL_DXY_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r;
               g2[k] = g[k] + 2.0f * FPS * r * w_dxy;
             }
-            if (upd_dxy) a_dxy.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, l.local_dxy + e * 2, g2, ac);
+            if (upd_dxy) a_dxy.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_dxy + e * 2, g2, ac);
           }
         }
       {
         float* ch[8];
-        for (int p = 0; p < P; ++p) ch[p] = person_view<FAST, AF>(sc, p).g_theta;
+        for (int p = 0; p < P; ++p) ch[p] = pv(p).g_theta;
         rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, true);
       }
       GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
-          const PersonView c = person_view<FAST, AF>(sc, p);
+          const PersonView c = pv(p);
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start;
           const float gh = s.g_theta[t];
           if (e == 0) {
-            if (st.var_mask & GLAMR_VAR_LOCAL_HEADING) { const int i = l.local_heading; if (sh.store_grad) s.g[i] = gh; adam(s.p[i], s.m[i], s.v[i], gh, ac); }
+            if (st.var_mask & GLAMR_VAR_LOCAL_HEADING) { const int i = lo.local_heading; if (sh.store_grad) s.g[i] = gh; adam(s.p[i], s.m[i], s.v[i], gh, ac); }
           } else {
-            const int i = l.local_dheading + e;
+            const int i = lo.local_dheading + e;
             const float v = s.p[i];
             float sv, cv;
             rm::sincos_(v, sv, cv);
@@ -1301,11 +1419,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     // regulariser values that do not depend on being optimised (reported every evaluation)
     if (last) {
       for (int p = 0; p < P && !update; ++p) {
-        const PersonView s = person_view<FAST, AF>(sc, p);
-        const int n = person_view<FAST, AF>(sc, p).fr_end - person_view<FAST, AF>(sc, p).fr_start;
+        const PersonView s = pv(p);
+        const int n = pv(p).fr_end - pv(p).fr_start;
         for (int e = rt.tid() + 1; e < n; e += rt.nthreads()) {
-          if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[l.local_dxy + e * 2 + k] * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
-          if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { float sv, cv; rm::sincos_(s.p[l.local_dheading + e], sv, cv); const float a = (cv - 1.0f) * FPS, b = sv * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
+          if (on(GLAMR_LOSS_LOCAL_DXY_REG)) for (int k = 0; k < 2; ++k) { const float r = s.p[lo.local_dxy + e * 2 + k] * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r; }
+          if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { float sv, cv; rm::sincos_(s.p[lo.local_dheading + e], sv, cv); const float a = (cv - 1.0f) * FPS, b = sv * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
         }
       }
       // block-reduce and normalise the reported (unweighted) loss values
@@ -1336,15 +1454,16 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   trace_hook(rt, n_eval - 1, sc, 0);
   rt.sync();
   if (AF) {      // the on-chip parameters go back to the batch array, once
-    for (int i = rt.tid(); i < l.person_stride; i += rt.nthreads()) sc.ps[0].p_g[i] = sc.ps[0].p[i];
+    copy_person_block(rt, sc.ps[0].p_g, l, sc.ps[0].p, lo);
     if (var_cam) {
       const int rows = fixed_cam ? 1 : T;
       for (int t = rt.tid(); t < rows; t += rt.nthreads()) {
-        for (int k = 0; k < 6; ++k) sc.cp_g[l.cam_rot6d + t * 6 + k] = sc.cp[l.cam_rot6d + t * 6 + k];
-        for (int k = 0; k < 3; ++k) sc.cp_g[l.cam_trans + t * 3 + k] = sc.cp[l.cam_trans + t * 3 + k];
+        for (int k = 0; k < 6; ++k) sc.cp_g[l.cam_rot6d + t * 6 + k] = sc.cp[lo.cam_rot6d + t * 6 + k];
+        for (int k = 0; k < 3; ++k) sc.cp_g[l.cam_trans + t * 3 + k] = sc.cp[lo.cam_trans + t * 3 + k];
       }
     } else {
-      for (int i = rt.tid(); i < l.cam_inv_rot_res; i += rt.nthreads()) sc.cp_g[l.cam_inv_rot_res + i] = sc.cp[i];
+      for (int i = rt.tid(); i < 6 * Tb; i += rt.nthreads()) sc.cp_g[l.cam_inv_rot_res + i] = sc.cp[i];
+      for (int i = rt.tid(); i < 3 * Tb; i += rt.nthreads()) sc.cp_g[l.cam_inv_trans_res + i] = sc.cp[lo.cam_trans + i];
     }
     rt.sync();
   }

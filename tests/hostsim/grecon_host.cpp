@@ -6,6 +6,10 @@
 using namespace glamr::grecon;
 
 struct HostRT {
+  static constexpr bool one_thread_per_frame = false;
+  float* arena_ = nullptr; float* ws_ = nullptr;      // only the constant-layout instances ask for them
+  float* arena() const { return arena_; }
+  float* workspace() const { return ws_; }
   int tid() const { return 0; }
   int nthreads() const { return 1; }
   void sync() const {}
@@ -74,6 +78,37 @@ extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_
     Scene sc;
     assemble_scene(*b, l, st, si, b->n_persons[si], b->seq_len[si], ws.data(), grads_out, sc);
     run_one(rt, b, st, l, sc, si);
+  }
+  return 0;
+}
+
+// The full-arena single-person instances (parameters + Adam moments in the arena) with the arena in host memory; layout_len > 0 = the
+// constant-layout instance (arena / workspace laid out for GLAMR_CONST_LAYOUT_FRAMES frames, on-chip parameter blocks in that layout).
+// Must give the results of hostsim_grecon_run_stage to the bit: same arithmetic, different addresses.
+extern "C" int hostsim_grecon_run_stage_arena(const glamr_scene_batch* b, const glamr_stage_desc* st, int const_layout) {
+  if (b->max_persons != 1) return -1;
+  constexpr int CL = GLAMR_CONST_LAYOUT_FRAMES;
+  if (const_layout && layout_frames(1, b->max_len) != CL) return -2;
+  const int lay_len = const_layout ? CL : b->max_len;
+  glamr_param_layout l;
+  param_layout(1, b->max_len, l);
+  std::vector<float> ws(scene_workspace_floats(1, lay_len));
+  const size_t fast_floats = scene_fast_floats(1, lay_len, 1) + (size_t)2 * 6 * lay_len;      // room for two keypoint rows "on chip"
+  std::vector<float> arena(fast_floats);
+  std::vector<float> tab(2 * (size_t)(st->niters > 0 ? st->niters : 1));
+  for (int i = 0; i < st->niters; ++i) adam_coef_host(st->lr, i + 1, &tab[2 * (size_t)i]);
+  HostRT rt;
+  rt.arena_ = arena.data(); rt.ws_ = ws.data();
+  for (int si = 0; si < b->n_scenes; ++si) {
+    Scene sc;
+    assemble_scene(*b, l, st, si, 1, b->seq_len[si], ws.data(), nullptr, sc, arena.data(), fast_floats, 1, const_layout ? CL : 0);
+    sc.adam_tab = st->niters > 0 ? tab.data() : nullptr;
+    const int cam = camera_mode(*st);
+    if (const_layout) {
+      if (cam == 1) run_scene<1, true, 1, CL>(rt, sc, *st, l); else if (cam == 2) run_scene<1, true, 2, CL>(rt, sc, *st, l); else run_scene<1, true, 0, CL>(rt, sc, *st, l);
+    } else {
+      if (cam == 1) run_scene<1, true, 1>(rt, sc, *st, l); else if (cam == 2) run_scene<1, true, 2>(rt, sc, *st, l); else run_scene<1, true, 0>(rt, sc, *st, l);
+    }
   }
   return 0;
 }

@@ -42,3 +42,44 @@ def test_full_schedule_detection_gap_follows_the_reference(asset_root, golden):
         w = 6 if name == 'cam_rot6d' else 3
         got = packed.t['params'][0, l[name]:l[name] + w * 300].numpy().reshape(300, w)
         assert np.abs(got - g[key]).max() < 1e-3, name          # cameras of the UNSEEN frames included
+
+
+def test_arena_and_constant_layout_instances_equal_the_plain_one(asset_root):
+    """The single-person full-arena instances keep parameters and Adam moments in the arena (copied in when the stage starts, back when it
+    ends); the constant-layout instance also lays the arena, the workspace and the on-chip parameter blocks out for 320 frames whatever
+    the batch's padded length.  Same arithmetic at different addresses: both must reproduce the plain instance TO THE BIT -- checked on
+    the CPU runtime (arena in host memory) on BASELINE configs[1]'s detection-gap input, first stage + 40 iterations of the main one."""
+    import ctypes
+    import numpy as np
+    import torch
+    from oracle.port import build
+    from glamr_amd import _lib
+    from glamr_amd.global_recon import packing
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.utils import synth
+    from tests import hostsim
+    lib = hostsim.build('grecon_host')
+    plain = lib.hostsim_grecon_run_stage
+    plain.argtypes = [ctypes.POINTER(_lib.SceneBatch), ctypes.POINTER(_lib.StageDesc), ctypes.c_void_p]
+    arena = lib.hostsim_grecon_run_stage_arena
+    arena.argtypes = [ctypes.POINTER(_lib.SceneBatch), ctypes.POINTER(_lib.StageDesc), ctypes.c_int]
+    cfg = get_config('glamr_dynamic')
+    in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=synth.make_smpl_model())
+    ora = build.load_optimizer(asset_root, cfg)
+    data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 0))
+    jl = gc.j_local_from_oracle(ora.smpl, data)
+    results = []
+    for mode in (None, 0, 1):
+        packed = packing.PackedScenes([data], [jl], torch.device('cpu'))
+        for name, spec in cfg['opt_stage_specs'].items():
+            sd = packing.stage_desc(spec, cfg['grecon_model_specs'], False)
+            sd.niters = min(int(sd.niters), 40)
+            sb = packed.struct()
+            if mode is None:
+                assert plain(ctypes.byref(sb), ctypes.byref(sd), None) == 0
+            else:
+                assert arena(ctypes.byref(sb), ctypes.byref(sd), mode) == 0
+        results.append({k: packed.t[k].numpy().copy() for k in ('params', 'kp_2d_pred', 'cam_pose', 'orient_world', 'trans_world', 'losses')})
+    for k, ref in results[0].items():
+        for other, what in ((results[1], 'arena'), (results[2], 'constant layout')):
+            assert np.array_equal(ref, other[k]), (k, what, np.abs(ref - other[k]).max())
