@@ -386,7 +386,7 @@ def run(argv=None):
                                     '= %d of %d CUs busy in the optimiser stage' % (args.total, NUM_FRAMES, CFG_ID, iters, world, B, min(B, n_cus), n_cus)),
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
                        'streams_per_gpu': len(streams)},
-            'roofline': {'kernel': 'grecon_stage_kernel<1,true,1>', 'bound': 'hbm', 'real_bound': 'latency / issue (one workgroup per scene, state on chip)',
+            'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'hbm', 'real_bound': 'latency / issue (one workgroup per scene, state on chip)',
                          'us_per_scene_iteration': us_scene_iter, 'dependent_boundary_floor_us': DEPENDENT_BOUNDARY_US,
                          'times_above_floor': us_scene_iter / DEPENDENT_BOUNDARY_US,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'frac_is_notional': True,

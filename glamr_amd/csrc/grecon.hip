@@ -24,7 +24,7 @@ constexpr int MAX_THREADS = GLAMR_GRECON_MAX_THREADS;
 #define GLAMR_GRECON_WAVES_PER_EU 2
 #endif
 #ifndef GLAMR_GRECON_LDS_KB
-#define GLAMR_GRECON_LDS_KB 150
+#define GLAMR_GRECON_LDS_KB 153
 #endif
 
 struct KernelArgs {
@@ -150,15 +150,15 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   const int wgs_per_cu = 4 * GLAMR_GRECON_WAVES_PER_EU / (threads / 64);
   const size_t full_arena = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
   if (wgs_per_cu > 1 && batch->n_scenes > n_cus) {
-    const size_t share = (size_t)160 * 1024 / wgs_per_cu - 6 * 1024;      // 5.7 KB of static LDS per workgroup
+    const size_t share = (size_t)160 * 1024 / wgs_per_cu - 6400;      // 6.2 KB of static LDS per workgroup (scene description, scan scratch)
     if (full_arena <= share && batch->max_len <= threads) LDS_BUDGET = share;
   }
   if (const char* e = std::getenv("GLAMR_GRECON_LDS_KB_RT")) {      // development aid (tools/overlap_probe.py)
     const size_t v = (size_t)std::atoi(e) * 1024;
     LDS_BUDGET = v < 16384 ? (size_t)16384 : (v > LDS_MAX ? LDS_MAX : v);
   }
-  // constant-layout instance (every array address of the loop a compile-time constant): one person, 257..320 frames, a thread per
-  // frame, the full arena of the 320-frame layout fits, and the caller does not ask for the gradient record
+  // constant-layout instance (every array address of the loop a compile-time constant): one person, 257..304 frames, a thread per
+  // frame, the full arena of the 304-frame layout fits, and the caller does not ask for the gradient record
   const int lay_len = layout_frames(batch->max_persons, batch->max_len);
   const bool no_const_layout = std::getenv("GLAMR_GRECON_NO_CONST_LAYOUT") != nullptr;      // development aid / A-B tests (read per launch)
   const bool const_layout = lay_len == GLAMR_CONST_LAYOUT_FRAMES && !grads_out && !no_const_layout && batch->max_len <= threads &&

@@ -38,6 +38,9 @@ namespace glamr {
 namespace grecon {
 
 constexpr int NJ = 26;
+#ifndef GLAMR_KP_DEPTH
+#define GLAMR_KP_DEPTH 3      // keypoint rows requested ahead of the one being processed (grecon_algo.hpp phase E)
+#endif
 constexpr float FPS = 30.0f;
 
 struct PersonConst {
@@ -400,9 +403,10 @@ GLAMR_HD constexpr SceneOff scene_offsets(int max_persons, int max_len, bool fas
 // person block (11 T + 4), three times.
 GLAMR_HD size_t scene_fast_floats(int max_persons, int max_len, int mode = 1) { return scene_offsets(max_persons, max_len, true, mode).fast_end; }
 GLAMR_HD size_t scene_workspace_floats(int max_persons, int max_len) { return scene_offsets(max_persons, max_len, false, 0).ws_end; }
-// Constant-layout instances: single-person scenes of 257..320 frames (BASELINE configs[1]: 300) lay their arena and workspace out for
-// 320 frames whatever the batch's padded length, so that every array address in the iteration loop is a compile-time constant
-constexpr int GLAMR_CONST_LAYOUT_FRAMES = 320;
+// Constant-layout instances: single-person scenes of 257..304 frames (BASELINE configs[1]: 300) lay their arena and workspace out for
+// 304 frames whatever the batch's padded length, so that every array address in the iteration loop is a compile-time constant
+// (304 and not 320: the arena then still has room for two rows of the keypoint table)
+constexpr int GLAMR_CONST_LAYOUT_FRAMES = 304;
 GLAMR_HD constexpr int layout_frames(int max_persons, int max_len) {
   return (max_persons == 1 && max_len > 256 && max_len <= GLAMR_CONST_LAYOUT_FRAMES) ? GLAMR_CONST_LAYOUT_FRAMES : max_len;
 }
@@ -1101,18 +1105,25 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             // the next joint's six values are fetched while the current one is processed (the rows that do not fit on chip come
             // from the workspace: hundreds of cycles each with one or two waves per SIMD to hide them)
             const int njc = s.njc, nf = s.njc_fast, TMs = sh.TM;
-            float nx[6];
-            auto fetch = [&](int jj) {
+            // A ring of KP_DEPTH joints in flight: a row from the workspace takes 300-400 ns to arrive and a joint ~120 ns to process
+            constexpr int KD = GLAMR_KP_DEPTH;
+            float nx[KD][6];
+            auto fetch = [&](int jj, float (&dst)[6]) {
               const float* o = (jj < nf ? s.kpc : s.kpc_ws) + (size_t)jj * 6 * TMs + t;
-              for (int k = 0; k < 6; ++k) nx[k] = o[k * TMs];
+              for (int k = 0; k < 6; ++k) dst[k] = o[k * TMs];
             };
             auto run = [&](int lo, int hi) {
-              if (lo < hi) fetch(lo);
-              for (int jj = lo; jj < hi; ++jj) {
-                const float cur[6] = {nx[0], nx[1], nx[2], nx[3], nx[4], nx[5]};
-                if (jj + 1 < hi) fetch(jj + 1);
-                if (cur[5] == 0.f) continue;
-                joint(cur, cur[3], cur[4], cur[5], 0.f, -1);
+#pragma unroll
+              for (int d = 0; d < KD; ++d) if (lo + d < hi) fetch(lo + d, nx[d]);
+              for (int jj = lo; jj < hi; jj += KD) {
+#pragma unroll
+                for (int d = 0; d < KD; ++d) {
+                  if (jj + d >= hi) break;
+                  const float cur[6] = {nx[d][0], nx[d][1], nx[d][2], nx[d][3], nx[d][4], nx[d][5]};
+                  if (jj + d + KD < hi) fetch(jj + d + KD, nx[d]);
+                  if (cur[5] == 0.f) continue;
+                  joint(cur, cur[3], cur[4], cur[5], 0.f, -1);
+                }
               }
             };
             run(0, njc);

@@ -46,7 +46,7 @@ def test_full_schedule_detection_gap_follows_the_reference(asset_root, golden):
 
 def test_arena_and_constant_layout_instances_equal_the_plain_one(asset_root):
     """The single-person full-arena instances keep parameters and Adam moments in the arena (copied in when the stage starts, back when it
-    ends); the constant-layout instance also lays the arena, the workspace and the on-chip parameter blocks out for 320 frames whatever
+    ends); the constant-layout instance also lays the arena, the workspace and the on-chip parameter blocks out for 304 frames whatever
     the batch's padded length.  Same arithmetic at different addresses: both must reproduce the plain instance TO THE BIT -- checked on
     the CPU runtime (arena in host memory) on BASELINE configs[1]'s detection-gap input, first stage + 40 iterations of the main one."""
     import ctypes

@@ -7,7 +7,7 @@ Copy the json / csv into profiles/ (bench.py reads profiles/r02_pmc_stage_kernel
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
-KERNEL = 'grecon_stage_kernel<1, true, 1>'
+KERNEL = 'grecon_stage_kernel<1, true, 1, 304>'
 B, ITERS = 1024, 500
 
 

@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
 t0 = min(r['s'] for r in rows)
-stage = [r for r in rows if 'grecon_stage_kernel<1, true, 1>' in r['Kernel_Name']]
+stage = [r for r in rows if 'grecon_stage_kernel<1, true, 1' in r['Kernel_Name']]
 def key(n):
     for k, v in (('gemm_split_kernel<2>', 'gemm2'), ('gemm_split_kernel<1>', 'gemm1'), ('attention_kernel<50>', 'attn50'), ('grecon_stage', 'stage'), ('lstm', 'lstm')):
         if k in n:
