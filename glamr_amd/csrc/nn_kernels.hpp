@@ -788,26 +788,35 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
 }
 
 // The same recurrence for large batches, on the matrix cores: one 512-thread workgroup advances 16 sequences of one direction
-// together.  Per step, gates[16 x 512] = G[t] + h[16 x 128] . W_hh^T as v_mfma_f32_16x16x4_f32: wave w owns hidden units
-// [16 w, 16 w + 16) and therefore the four gate tiles {w, 8 + w, 16 + w, 24 + w}; its 4 x 32 B operands (W_hh fragments) stay in
-// 128 registers for the whole launch, the A operand (h, double-buffered in LDS) is fetched with 8 ds_read_b128 per step (lane =
-// sequence m, k quarter q reads k = 32 q + j for the j-th MFMA), and the cell update is lane-local: lane (n, q) holds the four gates
-// of hidden unit 16 w + n for sequences 4 q .. 4 q + 3.  One barrier per step.
+// together.  Per step, gates[16 x 512] = G[t] + h[16 x 128] . W_hh^T on the fp16 matrix cores with both operands split in two fp16
+// planes (hi + lo, three products per accumulator: fp32-grade results, see gemm_split_kernel) as v_mfma_f32_16x16x32_f16: wave w owns
+// hidden units [16 w, 16 w + 16) and therefore the four gate tiles {w, 8 + w, 16 + w, 24 + w}; its W_hh fragments (4 gates x 4 k steps
+// x 2 planes x 8 halves) stay in 128 registers for the whole launch; h lives in LDS ALREADY SPLIT (the lane that produces a value
+// writes its two halves), double-buffered, rows padded to 136 halves: the A operand of a step is 8 ds_read_b128 (lane = sequence
+// n, k quarter q supplies k = 32 q + 8 j .. + 7 to the j-th k step -- the same permutation of k on both operands).  The cell update is
+// lane-local: lane (n, q) holds the four gates of hidden unit 16 w + n for sequences 4 q .. 4 q + 3.  One barrier per step.
+// 48 MFMAs per wave-step instead of the 128 v_mfma_f32_16x16x4_f32 of the fp32 version (3.4 of 5.6 us per step were matrix time on
+// the ONE CU a workgroup owns); sigmoid / tanh through v_exp_f32 + v_rcp_f32 (1e-7 absolute, the parity bound of the priors is 1e-4).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
 __global__ __launch_bounds__(512) void lstm_mfma_kernel(LstmArgs a, int n_seq) {
-  __shared__ __attribute__((aligned(16))) float sh[2][16][132];
+  constexpr int HS = 136;                                                   // halves per LDS row
+  __shared__ __attribute__((aligned(16))) _Float16 sh[2][2][16][HS];        // [buffer][plane][sequence][unit]
   const int dir = blockIdx.y, s0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int u0 = wave * 16;
   const float* Whh = dir ? a.Whh_b : a.Whh_f;
-  float wreg[4][32];
+  f16x8 wh[4][4], wl[4][4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float* row = Whh + (size_t)(g * 128 + u0 + n) * 128 + q * 32;
 #pragma unroll
-    for (int j = 0; j < 32; j += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(row + j);
-      wreg[g][j] = v[0]; wreg[g][j + 1] = v[1]; wreg[g][j + 2] = v[2]; wreg[g][j + 3] = v[3];
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + j * 8), v1 = *reinterpret_cast<const f32x4*>(row + j * 8 + 4);
+      const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      split8(x, wh[g][j], wl[g][j]);
     }
   }
   int len[4], maxlen = 0;
@@ -821,7 +830,7 @@ __global__ __launch_bounds__(512) void lstm_mfma_kernel(LstmArgs a, int n_seq) {
     Hb[r] = a.H + (size_t)min(seq, n_seq - 1) * a.max_len * 256 + dir * 128 + u0 + n;
   }
   for (int m = 0; m < 16; ++m) { const int sq = s0 + m; if (sq < n_seq) maxlen = max(maxlen, a.lens[sq]); }
-  for (int i = tid; i < 2 * 16 * 132; i += 512) (&sh[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * 2 * 16 * HS; i += 512) (&sh[0][0][0][0])[i] = (_Float16)0.f;
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   float gnext[4][4];
   auto fetch_g = [&](int s) {
@@ -841,32 +850,41 @@ __global__ __launch_bounds__(512) void lstm_mfma_kernel(LstmArgs a, int n_seq) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){gnext[g][0], gnext[g][1], gnext[g][2], gnext[g][3]};
     if (s + 1 < maxlen) fetch_g(s + 1);
-    const float* hrow = &sh[cur][n][q * 32];                      // A operand: sequence n (= lane & 15), k quarter q
+    f16x8 ah[4], al[4];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + jj * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i], wreg[g][jj * 4 + i], acc[g], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      ah[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(&sh[cur][0][n][q * 32 + j * 8]));
+      al[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(&sh[cur][1][n][q * 32 + j * 8]));
     }
+    // the two small products first; consecutive MFMAs go to different accumulators (a dependent MFMA waits for the previous one)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[j], wh[g][j], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], wl[g][j], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], wh[g][j], acc[g], 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = 4 * q + r;
-      float hnew;
+      float hnew = 0.f;                                     // a finished sequence's state is never read again
       if (s < len[r]) {
-        const float ig = 1.0f / (1.0f + expf(-acc[0][r]));
-        const float fg = 1.0f / (1.0f + expf(-acc[1][r]));
-        const float gg = tanhf(acc[2][r]);
-        const float og = 1.0f / (1.0f + expf(-acc[3][r]));
+        const float ig = fast_sigmoid(acc[0][r]);
+        const float fg = fast_sigmoid(acc[1][r]);
+        const float gg = fast_tanh(acc[2][r]);
+        const float og = fast_sigmoid(acc[3][r]);
         c[r] = fg * c[r] + ig * gg;
-        hnew = og * tanhf(c[r]);
+        hnew = og * fast_tanh(c[r]);
         const int t = dir ? (len[r] - 1 - s) : s;
         Hb[r][(size_t)t * 256] = hnew;
-      } else {
-        hnew = sh[cur][m][u0 + n];
       }
-      sh[cur ^ 1][m][u0 + n] = hnew;
+      const _Float16 hh = (_Float16)hnew;
+      sh[cur ^ 1][0][m][u0 + n] = hh;
+      sh[cur ^ 1][1][m][u0 + n] = (_Float16)(hnew - (float)hh);
     }
     __syncthreads();
   }
