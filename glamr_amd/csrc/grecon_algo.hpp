@@ -379,7 +379,9 @@ GLAMR_HD constexpr SceneOff scene_offsets(int max_persons, int max_len, bool fas
   o.cg_ws = take(person0);
   o.cam_inv = takef(12 * TM); o.cam_t = takef(3 * TM); o.g_cam = take(12 * TM); o.g_caminv = take(12 * TM); o.g_avg = take(12 * TM);
   o.fill_src = take(TM); o.n_vis_persons = take(TM); o.pair_first = take(64);
-  for (int p = 0; p < max_persons; ++p) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {           // (fully unrolled: o.ps[p] is then addressed statically and the struct stays in registers)
+    if (p >= max_persons) break;
     PersonOff& s = o.ps[p];
     s.m_ws = take(pstride); s.v_ws = take(pstride);
     s.m = af ? lds(pstride) : s.m_ws; s.v = af ? lds(pstride) : s.v_ws;
@@ -496,7 +498,9 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : at(o.cg_ws);
   sc.cam_inv = at(o.cam_inv); sc.cam_t = at(o.cam_t); sc.g_cam = at(o.g_cam); sc.g_caminv = at(o.g_caminv); sc.g_avg = at(o.g_avg);
   sc.fill_src = ati(o.fill_src); sc.n_vis_persons = ati(o.n_vis_persons); sc.pair_first = ati(o.pair_first);
-  for (int p = 0; p < b.max_persons; ++p) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    if (p >= b.max_persons) break;
     const size_t slot = (size_t)si * b.max_persons + p;
     const PersonOff& q = o.ps[p];
     PersonConst& c = sc.pc[p];
@@ -1108,11 +1112,17 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             // A ring of KP_DEPTH joints in flight: a row from the workspace takes 300-400 ns to arrive and a joint ~120 ns to process
             constexpr int KD = GLAMR_KP_DEPTH;
             float nx[KD][6];
-            auto fetch = [&](int jj, float (&dst)[6]) {
-              const float* o = (jj < nf ? s.kpc : s.kpc_ws) + (size_t)jj * 6 * TMs + t;
+            // (two loops, one per memory: a pointer selected between the arena and the workspace would be a generic one -- flat loads
+            // with 64-bit per-lane addresses that wait on both memory counters)
+            auto fetch_chip = [&](int jj, float (&dst)[6]) {
+              const float* o = s.kpc + (size_t)jj * 6 * TMs + t;
               for (int k = 0; k < 6; ++k) dst[k] = o[k * TMs];
             };
-            auto run = [&](int lo, int hi) {
+            auto fetch_ws = [&](int jj, float (&dst)[6]) {
+              const float* o = s.kpc_ws + (size_t)jj * 6 * TMs + t;
+              for (int k = 0; k < 6; ++k) dst[k] = o[k * TMs];
+            };
+            auto run = [&](int lo, int hi, auto fetch) {
 #pragma unroll
               for (int d = 0; d < KD; ++d) if (lo + d < hi) fetch(lo + d, nx[d]);
               for (int jj = lo; jj < hi; jj += KD) {
@@ -1126,7 +1136,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
                 }
               }
             };
-            run(0, njc);
+            run(0, nf, fetch_chip);
+            run(nf, njc, fetch_ws);
           }
           if (w_kp != 0.f && kp_frame) push_back();
         }
