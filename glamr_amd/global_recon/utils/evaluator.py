@@ -268,52 +268,52 @@ class Evaluator:
             pd['aligned_eval_joints_world'], pd['aligned_eval_verts_world'] = j15[:, 1:], verts
 
     def compute_sequence_metrics(self, data, name=None, accumulate=True):
+        """One sequence: every configured metric as an AverageMeter weighted by the number of samples behind it (evaluator.py:329-339)."""
         self.prepare_seq(data)
         data['log'], data['name'] = self.log, name
-        metrics_dict = defaultdict(dict)
-        metrics_dict['seq_len'] = data['seq_len']
-        for metric, func in self.metrics_func.items():
-            val, info = func(data)
-            metrics_dict['metrics'][metric] = AverageMeter(val, info['num_data'])
+        meters = {}
+        for metric_name, metric in self.metrics_func.items():
+            value, info = metric(data)
+            meters[metric_name] = AverageMeter(value, info['num_data'])
+        result = defaultdict(dict, seq_len=data['seq_len'], metrics=meters)
         if accumulate:
-            self.update_accumulated_metrics(metrics_dict, name)
-        return metrics_dict
+            self.update_accumulated_metrics(result, name)
+        return result
 
     def update_accumulated_metrics(self, metrics_dict, name=None):
+        """Folds a sequence's meters into the running totals (evaluator.py:341-346); named sequences are also kept individually."""
         if name is not None:
             self.metrics_dict_collection[name] = metrics_dict
-        for metric in self.metrics_name:
-            self.acc_metrics_dict['metrics'][metric].update(metrics_dict['metrics'][metric].avg, metrics_dict['metrics'][metric].count)
+        totals, seq = self.acc_metrics_dict['metrics'], metrics_dict['metrics']
+        for key in self.metrics_name:
+            totals[key].update(seq[key].avg, seq[key].count)
         return self.acc_metrics_dict
 
     def metrics_from_multiple_seeds(self, metrics_dict_arr):
         """evaluator.py:352-379: best-of-seeds for the sample metric and PA-MPJPE-invis, mean over seeds otherwise."""
-        metrics_dict = defaultdict(dict)
-        metrics_dict['seq_len'] = metrics_dict_arr[0]['seq_len']
-        for metric in self.metrics_name:
-            num_data = metrics_dict_arr[0]['metrics'][metric].count
-            if 'sample' in metric or 'mean' in metric:
-                val_arr = np.stack([x['metrics'][metric].avg for x in metrics_dict_arr])
-                if num_data == 0:
-                    val = 0
-                else:
-                    val = (val_arr.min(axis=0) if 'sample' in metric else val_arr.mean(axis=0)).mean()
+        first = metrics_dict_arr[0]
+        combined = {}
+        for key in self.metrics_name:
+            count = first['metrics'][key].count
+            per_seed = [m['metrics'][key].avg for m in metrics_dict_arr]
+            if 'sample' in key or 'mean' in key:          # per-frame arrays: reduce over seeds first, then over frames
+                stacked = np.stack(per_seed)
+                reduced = stacked.min(axis=0) if 'sample' in key else stacked.mean(axis=0)
+                value = reduced.mean() if count != 0 else 0
             else:
-                val_arr = np.array([x['metrics'][metric].avg for x in metrics_dict_arr])
-                val = val_arr.min() if metric in self.seed_min_metrics else val_arr.mean()
-            metrics_dict['metrics'][metric] = AverageMeter(val, num_data)
-        return metrics_dict
+                per_seed = np.asarray(per_seed)
+                value = per_seed.min() if key in self.seed_min_metrics else per_seed.mean()
+            combined[key] = AverageMeter(value, count)
+        return defaultdict(dict, seq_len=first['seq_len'], metrics=combined)
 
     def print_metrics(self, metrics_dict=None, fmt='.3f', prefix='', print_accum=True):
-        if metrics_dict is None:
-            metrics_dict = self.acc_metrics_dict
-        parts = []
-        for x, y in metrics_dict['metrics'].items():
-            if isinstance(y.avg, np.ndarray):
-                continue
-            parts.append(('%s: %' + fmt + ' (%' + fmt + ')') % (x, y.avg, y.val) if print_accum else ('%s: %' + fmt) % (x, y.avg))
+        """One log line `<prefix><algo> --- name: running average (last value) ...` (evaluator.py:381-391); array-valued meters are skipped."""
+        meters = (self.acc_metrics_dict if metrics_dict is None else metrics_dict)['metrics']
+        number = '{:' + fmt + '}'
+        cell = ('{}: ' + number + ' (' + number + ')') if print_accum else ('{}: ' + number)
+        parts = [cell.format(key, m.avg, m.val) for key, m in meters.items() if not isinstance(m.avg, np.ndarray)]
         line = '%s%s --- %s' % (prefix, self.algo, ' '.join(parts))
-        if 'sample_PA-MPJPE-invis' not in metrics_dict['metrics']:
+        if 'sample_PA-MPJPE-invis' not in meters:
             line += ' sample_PA-MPJPE-invis: None (need multiple seeds)'
         (self.log.info if self.log is not None else print)(line)
         return line
