@@ -290,7 +290,7 @@ class GlobalReconOptimizer:
     # ------------------------------------------------------------------------------------------------------------------------
     # batched pipeline
     # ------------------------------------------------------------------------------------------------------------------------
-    def init_data_batch_host(self, in_dicts, latents=None):
+    def init_data_batch_host(self, in_dicts, latents=None, init_forward=True):
         """Host-side variant of init_data_batch (numpy; kept for cam_fix_frames other than the default and as a cross-check):
         host preprocessing + ONE batched prior inference + scene initialisation.  latents: optional list (per sequence) of
         {person idx: {'motion': (n_windows,128), 'traj': (1,128)}} replacing the Gaussian draws."""
@@ -499,7 +499,7 @@ class GlobalReconOptimizer:
                 si, pi = divmod(int(bad[0]), rin.P)
                 raise wire.WireFormatError('sequence %d (%s), person %r: %s' % (si, rin.meta[si]['seq_name'], rin.ids[si][pi] if pi < len(rin.ids[si]) else pi, msg))
 
-    def init_resident(self, rin):
+    def init_resident(self, rin, init_forward=True):
         """init_data (:76-248) on device-resident inputs: per-person preparation, motion priors, scene assembly, cached joints and
         the 'init' forward pass -- kernel launches only, nothing crosses PCIe.  Returns (datas, packed): `datas` are light
         per-sequence dictionaries that collect() completes from the device arrays."""
@@ -557,7 +557,10 @@ class GlobalReconOptimizer:
         if self.flag_init_cam_all_frames:
             sb = packed.struct()
             _lib.check(L.glamr_init_cam_all_frames(ctypes.byref(sb), st))
-            self._run(packed, self._forward_only_desc())
+            # the 'init' forward pass with the new cameras (:246) only produces outputs (projections, camera-relative orientation, loss
+            # values); a caller that runs the schedule right away overwrites every one of them with the first stage's last evaluation
+            if init_forward:
+                self._run(packed, self._forward_only_desc())
         packed.person_arrays = pa_t
         packed.exists = rin.exists
         packed.keepalive = (rin, ws, out)
@@ -565,11 +568,11 @@ class GlobalReconOptimizer:
         self.timings.update(priors=0.0, host_init=0.0, lbs_pack_init=time.time() - t1)
         return datas, packed
 
-    def init_data_batch(self, in_dicts, latents=None):
+    def init_data_batch(self, in_dicts, latents=None, init_forward=True):
         """init_data (:76-248) for a batch of host dictionaries: stage_inputs + init_resident."""
         if self.cam_fix_frames != [(0, None)]:
             return self.init_data_batch_host(in_dicts, latents)
-        return self.init_resident(self.stage_inputs(in_dicts, latents))
+        return self.init_resident(self.stage_inputs(in_dicts, latents), init_forward=init_forward)
 
     _FETCH = ('fr_start', 'fr_end', 'vis', 'kp_2d', 'kp_score', 'cam_K', 'traj_local_pred', 'orient_cam', 'base_orient', 'base_trans', 'person2cam',
               'cam_pose', 'params', 'orient_world', 'trans_world', 'kp_2d_pred', 'orient_cam_in_world', 'losses')
@@ -688,6 +691,10 @@ class GlobalReconOptimizer:
             datas[si] = out
         return datas
 
+    def _schedule_overwrites_init(self):
+        """True when the configured schedule has at least one stage: its last evaluation rewrites all outputs of the 'init' forward pass."""
+        return len(self.opt_stage_specs) > 0
+
     def _forward_only_desc(self):
         first = next(iter(self.opt_stage_specs.values()))
         sd = packing.stage_desc(first, self.specs, has_world_dheading=False, niters=0)
@@ -730,7 +737,7 @@ class GlobalReconOptimizer:
     def optimize_resident(self, rin, max_iters=None):
         """HBM in, HBM out: init_data + the full schedule on a ResidentInputs batch.  Returns (datas, packed) with every result
         (optimised variables, world trajectories, projections, camera) in packed.t on the device; collect() brings them to the host."""
-        datas, packed = self.init_resident(rin)
+        datas, packed = self.init_resident(rin, init_forward=not self._schedule_overwrites_init())
         self.run_schedule(packed, max_iters)
         return datas, packed
 
@@ -780,7 +787,7 @@ class GlobalReconOptimizer:
         while rin is not None:
             with torch.cuda.stream(compute):
                 compute.wait_event(rin.upload_done)
-                datas, packed = self.init_resident(rin)
+                datas, packed = self.init_resident(rin, init_forward=not self._schedule_overwrites_init())
                 self.run_schedule(packed, max_iters)
                 done = torch.cuda.Event()
                 done.record()
@@ -795,7 +802,7 @@ class GlobalReconOptimizer:
 
     def optimize_batch(self, in_dicts, latents=None, max_iters=None):
         """Host dictionaries in, host dictionaries out (optimize() of the reference for a batch of independent sequences)."""
-        datas, packed = self.init_data_batch(in_dicts, latents)
+        datas, packed = self.init_data_batch(in_dicts, latents, init_forward=not self._schedule_overwrites_init())
         t0 = time.time()
         self.run_schedule(packed, max_iters)
         torch.cuda.synchronize(self.device)
