@@ -31,6 +31,10 @@ class RawBatch(Structure):
     _fields_ = [('n_slots', c_int32), ('max_len', c_int32)] + [(n, c_void_p) for n in ('seq_len', 'exist', 'rotmats', 'betas', 'root_trans', 'kp_2d')]
 
 
+class HostStaging(Structure):
+    _fields_ = [(n, c_void_p) for n in ('exist', 'rot', 'betas', 'trans', 'K', 'kp')]
+
+
 class PersonArrays(Structure):
     _fields_ = [(n, c_void_p) for n in ('visible_orig', 'smpl_pose', 'smpl_beta', 'trans_cam', 'nets_pose', 'nets_vis')]
 
@@ -68,6 +72,7 @@ _SIGNATURES = {
     'glamr_nets_traj_clip': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(TrajIO), c_void_p, c_void_p]),
     'glamr_traj_local_to_global_workspace_bytes': (c_size_t, [c_int, c_int]),
     'glamr_traj_local_to_global': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'glamr_host_scatter': (c_int, [c_int, c_void_p, c_int, POINTER(HostStaging), c_void_p, c_void_p, c_int]),
     'glamr_init_workspace_bytes': (c_size_t, [c_int, c_int]),
     'glamr_init_prepare': (c_int, [POINTER(RawBatch), POINTER(SceneBatch), POINTER(PersonArrays), c_int, c_void_p, c_void_p]),
     'glamr_init_scenes': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays)] + [c_void_p] * 6),

@@ -394,56 +394,44 @@ class GlobalReconOptimizer:
         return p
 
     def _scatter_inputs(self, in_dicts, ids, P, h):
-        """Per-detection HybrIK arrays -> their frame rows in the staging arrays `h` (numpy views).  Returns (seq_len per slot, length of
-        the existing range per slot, {(sequence, person id): exist array}).  Detections are copied run by run (a sequence with one
-        detection gap = two block copies per array; block copies are several times faster than indexed scatters); the rotation matrices
-        -- 0.86 of the 1.1 KB per frame -- are block-copied by a few worker threads (numpy releases the GIL while it copies a block of that
-        size), the small arrays inline: handing THEM to the threads as well makes the threads fight over the GIL for microsecond-sized
-        copies (measured 97 ms instead of 60 for 1024 sequences)."""
+        """Per-detection HybrIK arrays -> their frame rows in the staging arrays `h` (numpy views): glamr_host_scatter, a few host threads
+        doing block copies without the GIL (numpy on one thread took 60-130 ms per 1024 sequences depending on the box, a Python thread
+        pool was slower still).  This loop only collects the nine numbers per person the library needs.  Returns (seq_len per slot,
+        length of the existing range per slot, {(sequence, person id): exist array})."""
+        import ctypes
         n_slots = len(in_dicts) * P
+        T = h['exist'].shape[1]
         seq_len_slot = np.zeros(n_slots, np.int32)
         lens = np.full(n_slots, 11, np.int32)
         exists = {}
-        T = h['exist'].shape[1]
-        h_exist, h_betas, h_trans = h['exist'], h['betas'], h['trans']
-        h_rot, h_K, h_kp = h['rot'].reshape(n_slots, T, 54, 4), h['K'].reshape(n_slots, T, 3, 3), h['kp'].reshape(n_slots, T, 24, 2)
-        jobs = []
+        table = np.zeros((n_slots, 9), np.int64)
+        keep = []                                                  # converted copies must outlive the call
+        f32, f64 = np.dtype(np.float32), np.dtype(np.float64)
+
+        def addr(a, width):
+            if type(a) is not np.ndarray or a.dtype != f32 or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                keep.append(a)
+            if a.size != nv * width:
+                raise ValueError('a per-detection array has %d values, expected %d x %d' % (a.size, nv, width))
+            return a.__array_interface__['data'][0]
         for si, d in enumerate(in_dicts):
             est = d['est']
             for pi, idx in enumerate(ids[si]):
                 src = est[idx]
-                k = si * P + pi
                 ex = np.asarray(src['bboxes_dict']['exist'])
                 exists[(si, idx)] = ex
-                n_fr = ex.shape[0]
-                det = ex != 0
-                first, last = int(det.argmax()), n_fr - 1 - int(det[::-1].argmax())
+                exa = ex
+                if exa.dtype != f64 and exa.dtype != f32 or not exa.flags.c_contiguous:
+                    exa = np.ascontiguousarray(exa, dtype=np.float64)
+                    keep.append(exa)
                 nv = len(src['smpl_beta'])
-                seq_len_slot[k] = n_fr
-                lens[k] = last + 1 - first
-                h_exist[k, :n_fr] = ex
-                if last + 1 - first == nv:
-                    runs = ((first, 0, nv),)                   # (first frame, first detection, length)
-                else:
-                    vi = np.flatnonzero(det)
-                    cut = np.flatnonzero(np.diff(vi) > 1) + 1
-                    starts = [0] + cut.tolist() + [nv]
-                    runs = tuple((int(vi[a]), a, b - a) for a, b in zip(starts[:-1], starts[1:]))
-                rot = np.asarray(src['smpl_pose_quat_wroot']).reshape(nv, 54, 4)
-                betas, trans, K, kp = src['smpl_beta'], src['root_trans'], np.asarray(src['cam_K']).reshape(nv, 3, 3), np.asarray(src['kp_2d'])
-                for f0, d0, n in runs:
-                    jobs.append((h_rot[k, f0:f0 + n], rot[d0:d0 + n]))
-                    h_betas[k, f0:f0 + n] = betas[d0:d0 + n]
-                    h_trans[k, f0:f0 + n] = trans[d0:d0 + n]
-                    h_K[k, f0:f0 + n] = K[d0:d0 + n]
-                    h_kp[k, f0:f0 + n] = kp[d0:d0 + n, :24]
-        if jobs:
-            def work(chunk):
-                for dst, srcv in chunk:
-                    dst[...] = srcv
-            nthr = max(1, min(self._copy_threads(), len(jobs) // 64 + 1))
-            bounds = [len(jobs) * i // nthr for i in range(nthr + 1)]
-            list(self._pool().map(work, [jobs[bounds[i]:bounds[i + 1]] for i in range(nthr)]))
+                table[si * P + pi] = (exa.__array_interface__['data'][0], exa.dtype == f64, exa.shape[0], nv, addr(src['smpl_pose_quat_wroot'], 216),
+                                      addr(src['smpl_beta'], 10), addr(src['root_trans'], 3), addr(src['cam_K'], 9), addr(src['kp_2d'], 58))
+        # (rows left at zero = the empty person slots of scenes with fewer persons than the batch maximum: seq_len 0, nothing copied)
+        stg = _lib.HostStaging(*[ctypes.c_void_p(h[k].ctypes.data) for k in ('exist', 'rot', 'betas', 'trans', 'K', 'kp')])
+        _lib.check(_lib.lib().glamr_host_scatter(n_slots, ctypes.c_void_p(table.ctypes.data), T, ctypes.byref(stg), ctypes.c_void_p(seq_len_slot.ctypes.data),
+                                                 ctypes.c_void_p(lens.ctypes.data), self._copy_threads()))
         return seq_len_slot, lens, exists
 
     def stage_inputs(self, in_dicts, latents=None, validate=True):

@@ -289,6 +289,27 @@ typedef struct glamr_person_arrays {     /* per-person state that is not an inpu
   float* nets_vis;                       /* (n_slots, max_len) */
 } glamr_person_arrays;
 
+/* Host-side scatter of the HybrIK wire format (one array row per DETECTED frame, demo.py:317-354) into the frame-indexed staging arrays
+ * whose device copies glamr_raw_batch points at -- what the reference does person by person with fancy indexing inside init_data
+ * (global_recon_model.py:98-136).  All pointers are HOST pointers.  `table` has one row of nine int64 per person slot:
+ *   exist (address of bboxes_dict['exist']), exist_is_f64 (1: float64 as the reference stores it, 0: float32), n_frames, n_det (rows of
+ *   the per-detection arrays), then the addresses of smpl_pose_quat_wroot (n_det,216), smpl_beta (n_det,10), root_trans (n_det,3),
+ *   cam_K (n_det,9), kp_2d (n_det,29,2) -- float32, C-contiguous.
+ * A row whose `exist` address is 0 is an empty person slot (seq_len 0, nothing copied).
+ * Rows of undetected frames are left untouched (the device code never reads them); seq_len[k] = n_frames, exist_len[k] = last - first
+ * + 1 detected frame.  Persons are split over `threads` host threads.  Errors: a person without detections, or whose exist array marks a
+ * different number of frames than n_det. */
+typedef struct glamr_host_staging {
+  float* exist;                          /* (n_slots, max_len) */
+  float* rot;                            /* (n_slots, max_len, 216) */
+  float* betas;                          /* (n_slots, max_len, 10) */
+  float* trans;                          /* (n_slots, max_len, 3) */
+  float* K;                              /* (n_slots, max_len, 9) */
+  float* kp;                             /* (n_slots, max_len, 48): the first 24 of the 29 keypoints */
+} glamr_host_staging;
+int glamr_host_scatter(int n_persons, const int64_t* table, int max_len, const glamr_host_staging* staging, int32_t* seq_len,
+                       int32_t* exist_len, int threads);
+
 size_t glamr_init_workspace_bytes(int n_slots, int max_len);
 /* Fills vis, kp_2d, kp_score, orient_cam, base_orient, base_trans, fr_start, fr_end of `batch` (declared const there because the
  * optimiser only reads them) and every array of `pa`.  cam_K is written by the host directly. */

@@ -105,3 +105,52 @@ def test_lazy_dict_with_a_shared_factory():
     assert d['a'] == 'A' and d['a'] == 'A' and made == ['a']
     assert d.pop('b') == 'B' and 'b' not in d and len(d) == 2             # a popped key does not come back
     assert dict(d) == {'n': 3, 'a': 'A'}
+
+
+def test_host_scatter_matches_numpy_indexing():
+    """glamr_host_scatter (the library's multi-threaded scatter of per-detection rows to frame rows, host memory only) against plain
+    numpy fancy indexing: one run, two gaps, detections starting late, float32 `exist`, non-contiguous sources, an empty person slot."""
+    import ctypes
+    from glamr_amd import _lib
+    from glamr_amd.global_recon.models.global_recon_model import GlobalReconOptimizer as G
+    rng = np.random.RandomState(0)
+    T = 40
+
+    def person(exist, dtype=np.float64, strided=False):
+        nv = int((exist != 0).sum())
+        mk = lambda *shape: rng.rand(*shape).astype(np.float32)
+        rot = mk(nv, 54, 4)
+        if strided:
+            rot = np.asfortranarray(rot)
+        return {'bboxes_dict': {'exist': exist.astype(dtype)}, 'smpl_pose_quat_wroot': rot, 'smpl_beta': mk(nv, 10), 'root_trans': mk(nv, 3),
+                'cam_K': mk(nv, 3, 3), 'kp_2d': mk(nv, 29, 2)}
+    e0 = np.ones(T)
+    e1 = np.ones(T); e1[5:9] = 0; e1[20:31] = 0
+    e2 = np.zeros(33); e2[7:30] = 1
+    e3 = np.ones(T); e3[0] = 0; e3[-1] = 0
+    in_dicts = [{'est': {0: person(e0), 1: person(e1)}}, {'est': {4: person(e2, np.float32, strided=True)}}, {'est': {0: person(e3), 7: person(e0)}}]
+    ids = [list(d['est'].keys()) for d in in_dicts]
+    P, n = 2, 6
+    h = {'exist': np.full((n, T), -7, np.float32), 'rot': np.full((n, T, 216), -7, np.float32), 'betas': np.full((n, T, 10), -7, np.float32),
+         'trans': np.full((n, T, 3), -7, np.float32), 'K': np.full((n, T, 9), -7, np.float32), 'kp': np.full((n, T, 48), -7, np.float32)}
+    g = G.__new__(G)
+    seq_len, lens, exists = g._scatter_inputs(in_dicts, ids, P, h)
+    want = {k: np.full_like(v, -7) for k, v in h.items()}
+    for si, d in enumerate(in_dicts):
+        for pi, idx in enumerate(ids[si]):
+            src, k = d['est'][idx], si * P + pi
+            ex = src['bboxes_dict']['exist']
+            vi = np.flatnonzero(ex)
+            assert seq_len[k] == len(ex) and lens[k] == vi[-1] + 1 - vi[0] and exists[(si, idx)] is ex
+            want['exist'][k, :len(ex)] = ex
+            for dst, key, w in (('rot', 'smpl_pose_quat_wroot', 216), ('betas', 'smpl_beta', 10), ('trans', 'root_trans', 3), ('K', 'cam_K', 9)):
+                want[dst][k, vi] = np.asarray(src[key]).reshape(len(vi), w)
+            want['kp'][k, vi] = src['kp_2d'][:, :24].reshape(len(vi), 48)
+    assert seq_len[3] == 0                       # the empty slot of the one-person scene
+    for k in h:
+        assert np.array_equal(h[k], want[k]), k
+    # a person whose exist array disagrees with its rows is an error, not a silent mis-scatter
+    bad = person(e0)
+    bad['bboxes_dict']['exist'] = e1
+    with pytest.raises(RuntimeError):
+        g._scatter_inputs([{'est': {0: bad}}], [[0]], 1, h)
