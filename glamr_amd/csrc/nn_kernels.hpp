@@ -599,36 +599,46 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnArgs a) {
     hi = __builtin_bit_cast(f16x8, *p0);
     lo = __builtin_bit_cast(f16x8, *p1);
   };
-  // transposed projection of one 32-token tile: lane = token, registers = dims of head h (+ bias, x scale), as split k-step fragments
-  auto proj_t = [&](const unsigned char* sX, int t, const unsigned short* W, size_t plane, int nb, const float* bias, float scale, f16x8 (&fh)[2], f16x8 (&fl)[2]) {
-    f32x16 acc = (f32x16){0};
-    f16x8 wh[4], wl[4];                              // weight fragments three k steps ahead (an L2 round trip is ~3 x 3 MFMAs long)
+  // transposed projection of BOTH 32-token tiles in one pass over the weights: lane = token, registers = dims of head h (+ bias, x scale),
+  // as split k-step fragments.  One weight fragment feeds the two tiles (half the L2 requests of a pass per tile) and the two
+  // accumulators are independent MFMA chains (a dependent MFMA waits for the previous one to drain).
+  auto proj_t = [&](const unsigned char* sX, bool two, const unsigned short* W, size_t plane, int nb, const float* bias, float scale, f16x8 (&fh)[2][2], f16x8 (&fl)[2][2]) {
+    f32x16 acc[2] = {(f32x16){0}, (f32x16){0}};
+    f16x8 wh[4], wl[4];                              // weight fragments three k steps ahead (an L2 round trip is a few MFMAs long)
 #pragma unroll
     for (int d = 0; d < 3; ++d) wf(W, plane, nb, d, wh[d], wl[d]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (ks + 3 < KS) wf(W, plane, nb, ks + 3, wh[(ks + 3) & 3], wl[(ks + 3) & 3]);
-      f16x8 xh, xl;
-      rowf(sX, t, ks, xh, xl);
-      acc = mfma3(wh[ks & 3], wl[ks & 3], xh, xl, acc);
+      f16x8 xh[2], xl[2];
+      rowf(sX, 0, ks, xh[0], xl[0]);
+      if (two) rowf(sX, 1, ks, xh[1], xl[1]);
+      // small products first, the two tiles interleaved
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks & 3], xh[0], acc[0], 0, 0, 0);
+      if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks & 3], xh[1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 3], xl[0], acc[0], 0, 0, 0);
+      if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 3], xl[1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 3], xh[0], acc[0], 0, 0, 0);
+      if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 3], xh[1], acc[1], 0, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float x[8];
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && !two) continue;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * u + j, dim = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        x[j] = (acc[r] + (bias ? bias[nb * 32 + dim] : 0.0f)) * scale;
+      for (int u = 0; u < 2; ++u) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * u + j, dim = (r & 3) + 8 * (r >> 2) + 4 * kg;
+          x[j] = (acc[t][r] + (bias ? bias[nb * 32 + dim] : 0.0f)) * scale;
+        }
+        split8(x, fh[t][u], fl[t][u]);
       }
-      split8(x, fh[u], fl[u]);
     }
   };
   f16x8 qh_[2][2], ql_[2][2], kh_[2][2], kl_[2][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (t == 0 || two_q) proj_t(sQ, t, a.Wq, a.wq_plane, a.q_nb0 + h, a.bq, 0.17677669529663687f, qh_[t], ql_[t]);
-    if (t == 0 || two_k) proj_t(sKV, t, a.Wkv, a.wkv_plane, a.k_nb0 + h, a.bkv, 1.0f, kh_[t], kl_[t]);
-  }
+  proj_t(sQ, two_q, a.Wq, a.wq_plane, a.q_nb0 + h, a.bq, 0.17677669529663687f, qh_, ql_);
+  proj_t(sKV, two_k, a.Wkv, a.wkv_plane, a.k_nb0 + h, a.bkv, 1.0f, kh_, kl_);
   f32x16 sc[2][2];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
@@ -675,25 +685,33 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnArgs a) {
   // values of head h, one 32-key tile at a time: lane = dim, registers = keys; straight into O^T = V^T P^T
   f32x16 oc[2] = {(f32x16){0}, (f32x16){0}};
   const float bv = a.bkv ? a.bkv[(a.v_nb0 + h) * 32 + c] : 0.0f;
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-    if (kt == 1 && !two_k) continue;
-    f32x16 va = (f32x16){0};
+  f32x16 va[2] = {(f32x16){0}, (f32x16){0}};
+  {
     f16x8 wh[4], wl[4];
 #pragma unroll
     for (int d = 0; d < 3; ++d) wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, d, wh[d], wl[d]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (ks + 3 < KS) wf(a.Wkv, a.wkv_plane, a.v_nb0 + h, ks + 3, wh[(ks + 3) & 3], wl[(ks + 3) & 3]);
-      f16x8 xh, xl;
-      rowf(sKV, kt, ks, xh, xl);
-      va = mfma3(xh, xl, wh[ks & 3], wl[ks & 3], va);
+      f16x8 xh[2], xl[2];
+      rowf(sKV, 0, ks, xh[0], xl[0]);
+      if (two_k) rowf(sKV, 1, ks, xh[1], xl[1]);
+      va[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[0], wh[ks & 3], va[0], 0, 0, 0);
+      if (two_k) va[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[1], wh[ks & 3], va[1], 0, 0, 0);
+      va[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[0], wl[ks & 3], va[0], 0, 0, 0);
+      if (two_k) va[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[1], wl[ks & 3], va[1], 0, 0, 0);
+      va[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[0], wh[ks & 3], va[0], 0, 0, 0);
+      if (two_k) va[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[1], wh[ks & 3], va[1], 0, 0, 0);
     }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    if (kt == 1 && !two_k) continue;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       float vx[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) vx[j] = va[8 * u + j] + bv;
+      for (int j = 0; j < 8; ++j) vx[j] = va[kt][8 * u + j] + bv;
       f16x8 vh, vl;
       split8(vx, vh, vl);
 #pragma unroll
