@@ -637,8 +637,55 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnArgs a) {
     }
   };
   f16x8 qh_[2][2], ql_[2][2], kh_[2][2], kl_[2][2];
-  proj_t(sQ, two_q, a.Wq, a.wq_plane, a.q_nb0 + h, a.bq, 0.17677669529663687f, qh_, ql_);
-  proj_t(sKV, two_k, a.Wkv, a.wkv_plane, a.k_nb0 + h, a.bkv, 1.0f, kh_, kl_);
+#ifndef GLAMR_QKV_NO_FUSE_QK
+  if (self) {
+    // self-attention: queries and keys are projections of the SAME rows -- one pass, the row fragments read once for four chains
+    f32x16 acc[2][2] = {{(f32x16){0}, (f32x16){0}}, {(f32x16){0}, (f32x16){0}}};       // [q / k][tile]
+    f16x8 wh[2][4], wl[2][4];
+    const int nbq = a.q_nb0 + h, nbk = a.k_nb0 + h;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { wf(a.Wq, a.wq_plane, nbq, d, wh[0][d], wl[0][d]); wf(a.Wkv, a.wkv_plane, nbk, d, wh[1][d], wl[1][d]); }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 3 < KS) { wf(a.Wq, a.wq_plane, nbq, ks + 3, wh[0][(ks + 3) & 3], wl[0][(ks + 3) & 3]); wf(a.Wkv, a.wkv_plane, nbk, ks + 3, wh[1][(ks + 3) & 3], wl[1][(ks + 3) & 3]); }
+      f16x8 xh[2], xl[2];
+      rowf(sKV, 0, ks, xh[0], xl[0]);
+      if (two_k) rowf(sKV, 1, ks, xh[1], xl[1]);
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !two_k) continue;
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? wl[m][ks & 3] : wh[m][ks & 3], term == 1 ? xl[t] : xh[t], acc[m][t], 0, 0, 0);
+          }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two_k) continue;
+        const float* bias = m ? a.bkv : a.bq;
+        const int nb = m ? nbk : nbq;
+        const float scale = m ? 1.0f : 0.17677669529663687f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * u + j, dim = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            x[j] = (acc[m][t][r] + (bias ? bias[nb * 32 + dim] : 0.0f)) * scale;
+          }
+          if (m) split8(x, kh_[t][u], kl_[t][u]); else split8(x, qh_[t][u], ql_[t][u]);
+        }
+      }
+  } else
+#endif
+  {
+    proj_t(sQ, two_q, a.Wq, a.wq_plane, a.q_nb0 + h, a.bq, 0.17677669529663687f, qh_, ql_);
+    proj_t(sKV, two_k, a.Wkv, a.wkv_plane, a.k_nb0 + h, a.bkv, 1.0f, kh_, kl_);
+  }
   f32x16 sc[2][2];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
