@@ -70,10 +70,18 @@ std::vector<double> pos_code(int pos) {          // PositionalEncoding.original_
   return pe;
 }
 
+// every device allocation of a handle is recorded while glamr_nets_create runs, so that glamr_nets_destroy can release it
+thread_local std::vector<void*>* tl_allocs = nullptr;
+template <class T> int upload_t(T** dst, const T* host, size_t n) {
+  const int rc = upload(dst, host, n);
+  if (!rc && tl_allocs) tl_allocs->push_back(static_cast<void*>(*dst));
+  return rc;
+}
+
 int up_vec(float** dst, const std::vector<double>& v, size_t pad_to = 0) {
   std::vector<float> f(std::max(v.size(), pad_to), 0.0f);
   for (size_t i = 0; i < v.size(); ++i) f[i] = (float)v[i];
-  return upload(dst, f.data(), f.size());
+  return upload_t(dst, f.data(), f.size());
 }
 // upload W [N][K] padded to [ceil64(N)][ceil32(K)]
 int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
@@ -82,7 +90,7 @@ int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
   const int Np = (W.r + 63) / 64 * 64;
   std::vector<float> f((size_t)Np * L.K, 0.0f);
   for (int i = 0; i < W.r; ++i) for (int j = 0; j < W.c; ++j) f[(size_t)i * L.K + j] = (float)W.at(i, j);
-  int rc = upload(&L.W, f.data(), f.size());
+  int rc = upload_t(&L.W, f.data(), f.size());
   if (rc) return rc;
   {
     // fp32 ~ hi + lo in fp16 (round to nearest even; the remainder is exact in fp32), see nn_kernels.hpp
@@ -98,7 +106,7 @@ int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
         const size_t dst = (((size_t)(n / 32) * ksteps + k / 16) * 64 + (n % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8;
         planes[dst] = f16_bits(x); planes[f.size() + dst] = f16_bits(r1);
       }
-    if ((rc = upload(&L.Ws, planes.data(), planes.size()))) return rc;
+    if ((rc = upload_t(&L.Ws, planes.data(), planes.size()))) return rc;
   }
   if (bias) return up_vec(&L.b, *bias, Np);
   return GLAMR_OK;
@@ -364,6 +372,7 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
   glamr_nets* h = new (std::nothrow) glamr_nets();
   if (!h) return fail(GLAMR_E_NOMEM, "out of host memory");
   Blob I{ib, idesc, n_inf}, Tj{tb, tdesc, n_trj};
+  tl_allocs = &h->allocs;                          // (a failed create leaks what it uploaded so far: the handle is never returned)
   auto lin_plain = [&](Lin& L, const Blob& B, int iw) { const std::vector<double> bias = vec_of(B.get(iw + 1)); return up_lin(L, B.get(iw), &bias); };
   auto lnorm = [&](LN& n, const Blob& B, int i) { int rc = up_vec(&n.g, vec_of(B.get(i))); return rc ? rc : up_vec(&n.b, vec_of(B.get(i + 1))); };
 
@@ -525,15 +534,22 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
     }
     RC(tl(h->te_out1, 44)); RC(tl(h->te_out2, 46)); RC(tl(h->te_f1, 48)); RC(tl(h->te_f2, 50)); RC(tl(h->te_qz, 52));
   }
-  RC(upload(&h->rest_joints, fk_rest_joints, (size_t)72));
-  RC(upload(&h->parents, parents, (size_t)24));
+  RC(upload_t(&h->rest_joints, fk_rest_joints, (size_t)72));
+  RC(upload_t(&h->parents, parents, (size_t)24));
+  tl_allocs = nullptr;
   *out = h;
   return GLAMR_OK;
 }
 
 extern "C" int glamr_nets_destroy(glamr_nets* h) {
   if (!h) return GLAMR_OK;
-  delete h;     // device weights are released with the process; handles are created once per model
+  {
+    std::lock_guard<std::mutex> lock(h->graph_mu);
+    for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
+  }
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
   return GLAMR_OK;
 }
 

@@ -50,6 +50,14 @@ class MotionPriorsHandle:
                                            _lib.ptr(np.ascontiguousarray(parents, dtype=np.int32))))
         self.h = h
 
+    def close(self):
+        """Releases the device weights and the captured launch graphs of this handle (glamr_nets_destroy).  Pending work must have
+        completed; the handle cannot be used afterwards."""
+        h, self.h = self.__dict__.get('h'), None
+        if h:
+            torch.cuda.synchronize(self.device)
+            _lib.lib().glamr_nets_destroy(h)
+
     def resident_set(self, B, T, n_win):
         """Persistent buffers for the batched pipeline (GlobalReconOptimizer.init_resident): inputs, outputs and workspace of one
         glamr_nets_infer call at FIXED addresses, one set per HIP stream and batch geometry.  The set is only ever reused by a later call on

@@ -245,3 +245,38 @@ def test_fused_layer_kernels_match_reference_at_batch_size(joint_model, golden):
         _close(d['train_out_body_pose_tp'][:, i], g['inf_train_out_body_pose_tp'][:, j], 1e-4, 'train output')
     e = max(_err(d['context'][:, i].cpu(), g['inf_context'][:, i % 2]) for i in range(64))
     print('fused layers, 64 windows: context vs reference %.2e' % e)
+
+
+def test_handle_close_releases_device_memory(asset_root, priors):
+    """glamr_nets_destroy frees the weights (two fp16 planes + the fp32 copy of every layer) and the captured launch graphs of a
+    handle: creating, using and closing handles repeatedly must not grow the device footprint, and the surviving handle still works."""
+    from glamr_amd.models.priors import MotionPriorsHandle
+    from glamr_amd.utils import synth
+    sd = {}
+    for name, sub in (('inf', 'motion_filler/motion_infiller_demo'), ('trj', 'traj_pred/traj_pred_demo')):
+        path = sorted(glob.glob(os.path.join(asset_root, 'results', sub, 'version_*', 'checkpoints', '*best*.ckpt')))[-1]
+        sd[name] = torch.load(path, map_location='cpu', weights_only=False)['state_dict']
+    md = synth.make_smpl_model()
+    rest = (md['J_regressor'].astype(np.float64) @ md['v_template'].astype(np.float64)).astype(np.float32)
+    dev = torch.device('cuda:0')
+    from glamr_amd.models.priors import num_windows, NZ
+    pose = torch.zeros((2, 120, 69), device=dev)
+    vis = torch.ones((2, 120), device=dev)
+    meps = torch.zeros((2, num_windows(120), NZ), device=dev)
+    teps = torch.zeros((2, NZ), device=dev)
+
+    def cycle():
+        h = MotionPriorsHandle(sd['inf'], sd['trj'], rest, synth.SMPL_PARENTS, dev)
+        out = h.infer(pose, vis, [120, 120], motion_eps=meps, traj_eps=teps)
+        assert torch.isfinite(out['pose']).all()
+        h.close()
+        assert h.h is None
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    assert free0 - free1 < 8 << 20, 'three create / close cycles kept %.1f MB' % ((free0 - free1) / 2**20)
+    assert torch.isfinite(priors.infer(pose, vis, [120, 120], motion_eps=meps, traj_eps=teps)['pose']).all()
