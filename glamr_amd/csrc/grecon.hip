@@ -148,7 +148,9 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     return n;
   }();
   const int wgs_per_cu = 4 * GLAMR_GRECON_WAVES_PER_EU / (threads / 64);
-  const size_t full_arena = scene_fast_floats(batch->max_persons, batch->max_len, 1) * sizeof(float);
+  // (the exchange arrays alone -- arena mode 3: parameters and Adam moments then stay in the workspace; keeping them on chip as well,
+  // mode 1, needs 113 instead of 53 floats per frame and is what a scene that has its CU to itself gets)
+  const size_t full_arena = scene_fast_floats(batch->max_persons, batch->max_len, 3) * sizeof(float);
   if (wgs_per_cu > 1 && batch->n_scenes > n_cus) {
     const size_t share = (size_t)160 * 1024 / wgs_per_cu - 6400;      // 6.2 KB of static LDS per workgroup (scene description, scan scratch)
     if (full_arena <= share && batch->max_len <= threads) LDS_BUDGET = share;
@@ -167,9 +169,11 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   const int arena_len = const_layout ? lay_len : batch->max_len;
   const size_t full = scene_fast_floats(batch->max_persons, arena_len, 1) * sizeof(float);
   const size_t lite = scene_fast_floats(batch->max_persons, batch->max_len, 2) * sizeof(float);
-  // 1 full arena (single-pass instances: needs a thread per frame), 2 lite arena, 0 everything in the workspace
-  ka.use_lds = (full <= LDS_BUDGET && batch->max_len <= threads) ? 1 : (lite <= LDS_BUDGET ? 2 : 0);
-  const size_t base = ka.use_lds == 1 ? full : lite;
+  // 1 full arena + Adam state of single-person scenes, 3 full arena (both: single-pass instances, a thread per frame), 2 lite arena,
+  // 0 everything in the workspace
+  const bool per_frame = batch->max_len <= threads;
+  ka.use_lds = (full <= LDS_BUDGET && per_frame) ? 1 : ((full_arena <= LDS_BUDGET && per_frame) ? 3 : (lite <= LDS_BUDGET ? 2 : 0));
+  const size_t base = ka.use_lds == 1 ? full : (ka.use_lds == 3 ? full_arena : lite);
   const size_t want = base + (size_t)NJ * 6 * batch->max_persons * arena_len * sizeof(float);
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
   ka.fast_floats = (unsigned)(dyn / sizeof(float));
@@ -187,7 +191,9 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     rc = cam == 1 ? launch(grecon_stage_kernel<1, true, 1, CL>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, true, 2, CL>, dyn) : launch(grecon_stage_kernel<1, true, 0, CL>, dyn);
   else if (ka.use_lds == 1 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<1, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, true, 2>, dyn) : launch(grecon_stage_kernel<1, true, 0>, dyn);
-  else if (ka.use_lds == 1)
+  else if (ka.use_lds == 3 && single)
+    rc = cam == 1 ? launch(grecon_stage_kernel<3, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<3, true, 2>, dyn) : launch(grecon_stage_kernel<3, true, 0>, dyn);
+  else if (ka.use_lds == 1 || ka.use_lds == 3)      // several persons: the two full-arena modes are the same layout
     rc = cam == 1 ? launch(grecon_stage_kernel<1, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, false, 2>, dyn) : launch(grecon_stage_kernel<1, false, 0>, dyn);
   else if (ka.use_lds == 2 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<2, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, true, 2>, dyn) : launch(grecon_stage_kernel<2, true, 0>, dyn);

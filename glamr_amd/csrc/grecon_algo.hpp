@@ -138,8 +138,8 @@ template <int FAST, class T> __device__ __forceinline__ T* fastp(T* p) {
   }
   return glob(p);
 }
-// arrays of the second group are on chip only with the full arena (FAST == 1); with the lite arena (FAST == 2) they are global
-template <int FAST, class T> __device__ __forceinline__ T* fastp2(T* p) { return FAST == 1 ? fastp<1>(p) : glob(p); }
+// arrays of the second group are on chip only with a full arena (FAST == 1 or 3); with the lite arena (FAST == 2) they are global
+template <int FAST, class T> __device__ __forceinline__ T* fastp2(T* p) { return (FAST == 1 || FAST == 3) ? fastp<1>(p) : glob(p); }
 #else
 template <class T> inline T* uni(T* p) { return p; }
 inline int uni(int x) { return x; }
@@ -346,7 +346,8 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
 
 // Where every per-scene array lives: float offsets into the on-chip arena (lds) or into the scene's workspace slice.  One function
 // for the binder (run time), the size queries, and -- with a frame count known at compile time -- the constant addresses of the
-// constant-layout instances.  `fast`: an arena exists; `fast_mode` 1 = full, 2 = lite.
+// constant-layout instances.  `fast`: an arena exists; `fast_mode` 1 = full (+ parameters and Adam moments of single-person scenes),
+// 2 = lite, 3 = full with the Adam state in the workspace (a smaller arena: several workgroups of short sequences share a CU).
 struct ArrOff { unsigned off; bool lds; };
 struct PersonOff {
   ArrOff m_ws, v_ws, m, v, p, g_ws, theta, csn, xy, d6, tw, g_d6, g_tw, g_theta, g_xy, Lc, kpc_ws, vis_rank, kp_wsum, h_prior, oc6;
@@ -365,8 +366,8 @@ GLAMR_HD constexpr SceneOff scene_offsets(int max_persons, int max_len, bool fas
   unsigned w = 0, f = 0;
   // arrays other threads read (neighbouring frames, prefix sums) go to the arena when there is one; the second group (own-frame
   // hand-over arrays) only to the full arena; parameters and Adam moments only for single-person scenes with the full arena
-  const bool full = fast && fast_mode == 1;
-  o.adam_fast = full && max_persons == 1;
+  const bool full = fast && (fast_mode == 1 || fast_mode == 3);
+  o.adam_fast = fast && fast_mode == 1 && max_persons == 1;
   const bool af = o.adam_fast;
   auto take = [&](unsigned n) { ArrOff r{w, false}; w += n; return r; };
   auto lds = [&](unsigned n) { ArrOff r{f, true}; f += n; return r; };
@@ -670,7 +671,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   // Frame loops of the full-arena instances make ONE pass (the launcher only selects them when every frame has its own thread): with
   // a step the compiler can see is larger than any sequence the loop is an `if`, and no per-array 64-bit induction pointers stay
   // live across the whole body (two registers each, a few dozen arrays).
-  const int fstep = (FAST == 1 && RT::one_thread_per_frame) ? (1 << 20) : rt.nthreads();
+  const int fstep = ((FAST == 1 || FAST == 3) && RT::one_thread_per_frame) ? (1 << 20) : rt.nthreads();
   const int T = sc.T, P = SINGLE ? 1 : sc.P;
   const bool var_cam = CAM != 0 ? true : (bool)(st.var_mask & GLAMR_VAR_CAM);
   const bool fixed_cam = CAM == 2 ? true : (CAM == 1 ? false : (bool)(st.flags & GLAMR_FLAG_FIXED_CAM));

@@ -29,7 +29,7 @@ def main():
     L = _lib.lib()
     spec = cfg['opt_stage_specs'][os.environ.get('GLAMR_MB_STAGE', 'init_opt')]
     has_wd = os.environ.get('GLAMR_MB_STAGE', 'init_opt') != 'init_opt' and any('world_dheading' in s_['opt_variables'] for s_ in cfg['opt_stage_specs'].values())
-    for S in (1, 256) if 'GLAMR_MB_FRAMES' in os.environ else (1, 64, 256, 1024):
+    for S in [int(x) for x in os.environ['GLAMR_MB_SCENES'].split(',')] if 'GLAMR_MB_SCENES' in os.environ else ((1, 256) if 'GLAMR_MB_FRAMES' in os.environ else (1, 64, 256, 1024)):
         packed = packing.PackedScenes([data] * S, [jl] * S, dev)
         sd = packing.stage_desc(spec, cfg['grecon_model_specs'], False, niters=min(200, spec['opt_niters']))
         sb = packed.struct()
