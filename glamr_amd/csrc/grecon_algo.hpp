@@ -761,7 +761,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     for (int p = 0; p < P; ++p) {
       PersonState& s = sc.ps[p];
       s.njc = 0;
-      if (on(GLAMR_LOSS_KP_2D)) for (int j = 0; j < NJ; ++j) if (s.kp_wsum[j] > 0.f) s.jidx[s.njc++] = j;
+      // (a forward-only launch, niters == 0, evaluates all 26 joints from the full arrays once: it needs no table)
+      if (on(GLAMR_LOSS_KP_2D) && st.niters > 0) for (int j = 0; j < NJ; ++j) if (s.kp_wsum[j] > 0.f) s.jidx[s.njc++] = j;
       const size_t per_joint = (size_t)6 * sc.TM;
       s.njc_fast = 0;
       if (sc.fast_free) {

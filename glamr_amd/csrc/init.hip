@@ -118,8 +118,14 @@ __global__ __launch_bounds__(256) void prep_person_kernel(PrepArgs a) {
       atomicMin(&s_first, t);
       atomicMax(&s_last, t);
       atomicAdd(&s_nvis, 1);
-      for (int j = 0; j < 24; ++j) rotmat_to_rotvec_nearest(a.rotmats + ((o1 + t) * 24 + j) * 9, aa_raw + (size_t)t * 72 + j * 3);
     }
+  }
+  // rotation matrix -> rotation vector (double precision, ~1 500 instructions each: most of this kernel's time) over (frame, joint)
+  // items: 7 200 of them spread evenly over the 256 threads, neighbouring lanes on neighbouring 36-byte matrices -- a thread per FRAME
+  // left 44 threads with two frames of 24 conversions and the rest with one
+  for (int idx = threadIdx.x; idx < n_fr * 24; idx += blockDim.x) {
+    const int t = idx / 24, j = idx - t * 24;
+    if (exist[t] != 0.f) rotmat_to_rotvec_nearest(a.rotmats + ((o1 + t) * 24 + j) * 9, aa_raw + (size_t)t * 72 + j * 3);
   }
   __syncthreads();
   const int first = s_first, last = s_last;
