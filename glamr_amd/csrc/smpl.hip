@@ -19,6 +19,7 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace glamr {
 
@@ -32,9 +33,11 @@ constexpr int MAX_EXTRA = 9;
 constexpr int MAX_PICKED = 32;
 constexpr int OUT_STRIDE = 97;    // LDS transpose row stride (floats) for the vertex write-out
 constexpr int K_ONE = 217;        // feature index that carries the constant 1 (multiplies v_template)
+constexpr int KSH = 232;          // halves per LDS row of one fp16 plane of the direction matrix (224 + 8: 16-byte rows, conflict-free b128 reads)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 }  // namespace glamr
 
@@ -43,6 +46,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct glamr_tileset {
   int n_verts, n_tiles, Vpad;
   float* dirs_tiled;      // [n_tiles][3][32][KSTRIDE]
+  unsigned short* dirs_h; // [n_tiles][3][2 planes][32][KSH] the same matrix as two fp16 planes (hi, lo), or null
   float* w_tiled;         // [Vpad][24]
   float* jx_used;         // [n_extra_used][Vpad]
   int32_t* pick_row;      // [n_picked] row inside the tile
@@ -103,7 +107,9 @@ struct PrepArgs {
   const int32_t* parents;
   const int32_t* level;
   float* feat;              // (Bpad, KTOT) or null
+  unsigned short* feat_h;   // (Bpad, 2 planes, KTOT) the same rows as two fp16 planes, or null
   float* askin;             // (Bpad, 12, 24) or null
+  unsigned short* askin_h;  // (Bpad, 12, 2 planes, 32) the same transforms as two fp16 planes, K padded to 32 with zeros, or null
   float* chain_joints;      // (B, 24, 3)
 };
 
@@ -128,12 +134,17 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
     }
     if (a.feat) {
       float* f = a.feat + (size_t)b * KTOT;
+      _Float16* fh = a.feat_h ? reinterpret_cast<_Float16*>(a.feat_h) + (size_t)b * 2 * KTOT : nullptr;
+      auto put = [&](int k, float v) {
+        f[k] = v;
+        if (fh) { const _Float16 hi = (_Float16)v; fh[k] = hi; fh[KTOT + k] = (_Float16)(v - (float)hi); }
+      };
       if (j > 0) {
-        for (int e = 0; e < 9; ++e) f[10 + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+        for (int e = 0; e < 9; ++e) put(10 + (j - 1) * 9 + e, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
       } else {
-        for (int l = 0; l < 10; ++l) f[l] = (l < a.num_betas) ? a.betas[(size_t)b * a.num_betas + l] : 0.0f;
-        f[K_ONE] = 1.0f;
-        for (int k = K_ONE + 1; k < KTOT; ++k) f[k] = 0.0f;
+        for (int l = 0; l < 10; ++l) put(l, (l < a.num_betas) ? a.betas[(size_t)b * a.num_betas + l] : 0.0f);
+        put(K_ONE, 1.0f);
+        for (int k = K_ONE + 1; k < KTOT; ++k) put(k, 0.0f);
       }
     }
   }
@@ -165,9 +176,19 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
     if (a.askin) {
       // relative transform: A = [G_R | G_t - G_R J]
       float* A = a.askin + (size_t)b * 12 * NJ;
+      _Float16* Ah = a.askin_h ? reinterpret_cast<_Float16*>(a.askin_h) + (size_t)b * 12 * 2 * 32 : nullptr;
+      auto put = [&](int e, float v) {
+        A[e * NJ + j] = v;
+        if (Ah) {
+          const _Float16 hi = (_Float16)v;
+          Ah[(e * 2 + 0) * 32 + j] = hi;
+          Ah[(e * 2 + 1) * 32 + j] = (_Float16)(v - (float)hi);
+          if (j < 8) { Ah[(e * 2 + 0) * 32 + 24 + j] = (_Float16)0.f; Ah[(e * 2 + 1) * 32 + 24 + j] = (_Float16)0.f; }      // K padding
+        }
+      };
       for (int r0 = 0; r0 < 3; ++r0) {
-        for (int c = 0; c < 3; ++c) A[(r0 * 4 + c) * NJ + j] = G[r0 * 4 + c];
-        A[(r0 * 4 + 3) * NJ + j] = G[r0 * 4 + 3] - (G[r0 * 4 + 0] * Jr[0] + G[r0 * 4 + 1] * Jr[1] + G[r0 * 4 + 2] * Jr[2]);
+        for (int c = 0; c < 3; ++c) put(r0 * 4 + c, G[r0 * 4 + c]);
+        put(r0 * 4 + 3, G[r0 * 4 + 3] - (G[r0 * 4 + 0] * Jr[0] + G[r0 * 4 + 1] * Jr[1] + G[r0 * 4 + 2] * Jr[2]));
       }
     }
   }
@@ -185,6 +206,9 @@ struct LbsArgs {
   const int32_t* tile_pick_ids;
   const int32_t* pick_row;
   const float* feat;        // (Bpad, KTOT)
+  const unsigned short* dirs_h;   // fp16 planes of dirs_tiled (F16 instances)
+  const unsigned short* feat_h;   // fp16 planes of feat (F16 instances)
+  const unsigned short* askin_h;  // fp16 planes of askin (F16 instances)
   const float* askin;       // (Bpad, 12, 24)
   float* verts;             // (B, V, 3) or null
   float* picked;            // (B, n_picked, 3)
@@ -194,18 +218,25 @@ struct LbsArgs {
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int NE>
+// F16: the blend-shape product (K = 218, 70 % of the matrix work) on the fp16 matrix cores with both operands as two fp16 planes (hi + lo,
+// three v_mfma_f32_32x32x16_f16 per 16-deep k step: fp32-grade, 2^-22 of the operands) instead of 112 v_mfma_f32_32x32x2_f32 per
+// coordinate; planes are built once (directions at model creation, feature rows in smpl_prep_kernel).  Skinning stays fp32.
+template <int NE, bool F16 = false>
 __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sDirs = smem;                                   // [3][32][KSTRIDE]
-  float* sOut = smem + 3 * TILE_V * KSTRIDE;             // [4 waves][32 frames][OUT_STRIDE]  (only when verts != null)
+  float* sOut = smem + (F16 ? 3 * 2 * TILE_V * KSH / 2 : 3 * TILE_V * KSTRIDE);      // [4 waves][32 frames][OUT_STRIDE]  (only when verts != null)
   const int tile = blockIdx.x;
   const int v0 = tile * TILE_V;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
 
-  // stage this tile's direction matrix (contiguous 3*32*KSTRIDE floats) into LDS
-  {
+  // stage this tile's direction matrix (contiguous 3*32*KSTRIDE floats, or 3*2*32*KSH halves) into LDS
+  if (F16) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.dirs_h + (size_t)tile * 3 * 2 * TILE_V * KSH);
+    uint4* dst = reinterpret_cast<uint4*>(sDirs);
+    for (int i = tid; i < 3 * 2 * TILE_V * KSH / 8; i += 256) dst[i] = src[i];
+  } else {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.dirs_tiled + (size_t)tile * 3 * TILE_V * KSTRIDE);
     f32x4* dst = reinterpret_cast<f32x4*>(sDirs);
     for (int i = tid; i < 3 * TILE_V * KSTRIDE / 4; i += 256) dst[i] = src[i];
@@ -216,6 +247,21 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
     const float* w = a.w_tiled + (size_t)(v0 + col) * NJ + half * 12;
 #pragma unroll
     for (int m = 0; m < 12; ++m) wreg[m] = w[m];
+  }
+  // F16: the same weights as fp16 planes in the k order of the 16-deep steps (step m, lane half h: joints 16 m + 8 h .. + 7, zero from 24 on)
+  f16x8 wh_[2], wl_[2];
+  if (F16) {
+    const float* w = a.w_tiled + (size_t)(v0 + col) * NJ;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 16 * m + 8 * half + i;
+        const float x = k < NJ ? w[k] : 0.0f;
+        const _Float16 hi = (_Float16)x;
+        wh_[m][i] = hi;
+        wl_[m][i] = (_Float16)(x - (float)hi);
+      }
   }
   // extra-joint regressor weights for the 16 accumulator rows this lane owns
   float jx[NE > 0 ? NE : 1][16];
@@ -231,6 +277,32 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
     const int b = ft * TILE_F + col;            // Bpad is a multiple of 32: always a readable row
     const float* frow = a.feat + (size_t)b * KTOT + half * KH;
     f32x16 px = {0}, py = {0}, pz = {0};
+    if (F16) {
+      // lane half h supplies k = 112 h + 8 m .. + 7 to k step m, on both operands alike
+      const unsigned short* myH = reinterpret_cast<const unsigned short*>(sDirs) + (size_t)col * KSH + half * KH;
+      const unsigned short* fh = a.feat_h + (size_t)b * 2 * KTOT + half * KH;
+#pragma unroll 2
+      for (int m = 0; m < KH / 8; ++m) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(fh + 8 * m));
+        const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(fh + KTOT + 8 * m));
+        f16x8 ah[3], al[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          ah[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(myH + (size_t)(c * 2 + 0) * TILE_V * KSH + 8 * m));
+          al[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(myH + (size_t)(c * 2 + 1) * TILE_V * KSH + 8 * m));
+        }
+        // small products first; consecutive MFMAs go to different accumulators
+        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh, px, 0, 0, 0);
+        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh, py, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[2], bh, pz, 0, 0, 0);
+        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl, px, 0, 0, 0);
+        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl, py, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2], bl, pz, 0, 0, 0);
+        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh, px, 0, 0, 0);
+        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh, py, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2], bh, pz, 0, 0, 0);
+      }
+    } else
 #pragma unroll 2
     for (int m = 0; m < KH / 4; ++m) {
       const f32x4 fb = *reinterpret_cast<const f32x4*>(frow + 4 * m);
@@ -250,6 +322,26 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       f32x16 T[4];
+      if (F16) {
+        const unsigned short* ah = a.askin_h + (size_t)b * 12 * 2 * 32 + 8 * half;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T[c] = (f32x16){0};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          f16x8 bh[4], bl[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            bh[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ah + ((r * 4 + c) * 2 + 0) * 32 + 16 * m));
+            bl[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ah + ((r * 4 + c) * 2 + 1) * 32 + 16 * m));
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[m], bh[c], T[c], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], bl[c], T[c], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], bh[c], T[c], 0, 0, 0);
+        }
+      } else
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         T[c] = (f32x16){0};
@@ -563,6 +655,21 @@ extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const f
     }
     int rc;
     if ((rc = upload(&ts->dirs_tiled, dirs.data(), dirs.size()))) return rc;
+    {
+      // the same matrix as two fp16 planes: x = hi + lo to 2^-22 |x| (round to nearest, the remainder is exact in fp32)
+      std::vector<unsigned short> planes((size_t)ts->n_tiles * 3 * 2 * TILE_V * KSH, 0);
+      auto bits = [](float x) { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
+      for (int t = 0; t < ts->n_tiles; ++t)
+        for (int r = 0; r < 3; ++r)
+          for (int row = 0; row < TILE_V; ++row)
+            for (int k = 0; k < KTOT; ++k) {
+              const float x = dirs[(((size_t)t * 3 + r) * TILE_V + row) * KSTRIDE + k];
+              const float hi = (float)(_Float16)x;
+              planes[((((size_t)t * 3 + r) * 2 + 0) * TILE_V + row) * KSH + k] = bits(x);
+              planes[((((size_t)t * 3 + r) * 2 + 1) * TILE_V + row) * KSH + k] = bits(x - hi);
+            }
+      if ((rc = upload(&ts->dirs_h, planes.data(), planes.size()))) return rc;
+    }
     if ((rc = upload(&ts->w_tiled, w.data(), w.size()))) return rc;
     if ((rc = upload(&ts->jx_used, jx.data(), jx.size()))) return rc;
     if ((rc = upload(&ts->pick_row, pick_row.data(), pick_row.size()))) return rc;
@@ -642,7 +749,7 @@ extern "C" int glamr_smpl_create(glamr_smpl** out, int V, int num_betas, const f
 
 extern "C" int glamr_smpl_destroy(glamr_smpl* h) {
   if (!h) return GLAMR_OK;
-  void* ptrs[] = {h->j_template, h->j_shapedirs, h->parents, h->level, h->joint_map, h->extra_slot,
+  void* ptrs[] = {h->full.dirs_h, h->joints.dirs_h, h->j_template, h->j_shapedirs, h->parents, h->level, h->joint_map, h->extra_slot,
                   h->full.dirs_tiled, h->full.w_tiled, h->full.jx_used, h->full.pick_row, h->full.tile_pick_start, h->full.tile_pick_ids,
                   h->joints.dirs_tiled, h->joints.w_tiled, h->joints.jx_used, h->joints.pick_row, h->joints.tile_pick_start,
                   h->joints.tile_pick_ids};
@@ -652,14 +759,16 @@ extern "C" int glamr_smpl_destroy(glamr_smpl* h) {
 }
 
 namespace {
-struct SmplWs { float *feat, *askin, *chain, *picked, *partial, *pivot; size_t total; int Bpad; };
+struct SmplWs { float *feat, *feat_h, *askin, *askin_h, *chain, *picked, *partial, *pivot; size_t total; int Bpad; };
 SmplWs smpl_ws_layout(const glamr_smpl* h, int B, char* base) {
   SmplWs w{};
   w.Bpad = (B + TILE_F - 1) / TILE_F * TILE_F;
   size_t off = 0;
   auto take = [&](size_t nfloats) { float* p = reinterpret_cast<float*>(base + off); off = align_up(off + nfloats * sizeof(float), 256); return p; };
   w.feat = take((size_t)w.Bpad * KTOT);
+  w.feat_h = take((size_t)w.Bpad * KTOT);      // two fp16 planes of the same rows
   w.askin = take((size_t)w.Bpad * 12 * NJ);
+  w.askin_h = take((size_t)w.Bpad * 12 * 32);     // two fp16 planes, K padded to 32
   w.chain = take((size_t)w.Bpad * NJ * 3);
   w.picked = take((size_t)w.Bpad * std::max(1, h->n_picked) * 3);
   w.partial = take((size_t)h->full.n_tiles * w.Bpad * std::max(1, h->n_extra_used) * 3);
@@ -683,16 +792,24 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   // rows [B, Bpad) of feat/askin are read by the padded MFMA tiles: keep them finite
   if (w.Bpad > B) {
     GLAMR_HIP_CHECK(hipMemsetAsync(w.feat + (size_t)B * KTOT, 0, (size_t)(w.Bpad - B) * KTOT * sizeof(float), stream));
+    GLAMR_HIP_CHECK(hipMemsetAsync(w.feat_h + (size_t)B * KTOT, 0, (size_t)(w.Bpad - B) * KTOT * sizeof(float), stream));
     GLAMR_HIP_CHECK(hipMemsetAsync(w.askin + (size_t)B * 12 * NJ, 0, (size_t)(w.Bpad - B) * 12 * NJ * sizeof(float), stream));
+    GLAMR_HIP_CHECK(hipMemsetAsync(w.askin_h + (size_t)B * 12 * 32, 0, (size_t)(w.Bpad - B) * 12 * 32 * sizeof(float), stream));
   }
-  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, w.askin, w.chain};
+  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, reinterpret_cast<unsigned short*>(w.feat_h), w.askin, reinterpret_cast<unsigned short*>(w.askin_h), w.chain};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   const bool orig = (flags & GLAMR_SMPL_ORIG_JOINTS) != 0;
   const glamr_tileset& ts = (!verts && h->joints.n_tiles > 0) ? h->joints : h->full;
   const int n_ftiles = w.Bpad / TILE_F;
   LbsArgs la{B, h->V, ts.n_tiles, n_ftiles, h->n_extra_used, h->n_picked, ts.dirs_tiled, ts.w_tiled, ts.jx_used,
-             ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, w.askin, verts, w.picked, w.partial, w.Bpad};
-  const size_t lds = (size_t)(3 * TILE_V * KSTRIDE + (verts ? 4 * TILE_F * OUT_STRIDE : 0)) * sizeof(float);
+             ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, ts.dirs_h, reinterpret_cast<const unsigned short*>(w.feat_h), reinterpret_cast<const unsigned short*>(w.askin_h), w.askin, verts,
+             w.picked, w.partial, w.Bpad};
+  // blend shapes on the fp16 matrix cores (two-plane operands) when vertices are produced -- the calls where the matrix pipe is the
+  // bound; the joints-only calls of the optimiser path keep the fp32 products (GLAMR_SMPL_FP32_BLEND=1: everywhere)
+  static const bool fp32_blend = std::getenv("GLAMR_SMPL_FP32_BLEND") != nullptr;
+  const bool f16 = verts != nullptr && !fp32_blend && ts.dirs_h != nullptr;
+  const size_t dirs_bytes = f16 ? (size_t)3 * 2 * TILE_V * KSH * sizeof(unsigned short) : (size_t)3 * TILE_V * KSTRIDE * sizeof(float);
+  const size_t lds = dirs_bytes + (verts ? (size_t)4 * TILE_F * OUT_STRIDE * sizeof(float) : 0);
   // frame tiles are split over gridDim.y so that a launch has ~4 workgroups per CU even with few vertex tiles; every workgroup
   // re-stages its 87 KB direction tile, so a chunk keeps >= 8 frame tiles per wave
   int gy = std::max(1, std::min((1024 + ts.n_tiles - 1) / ts.n_tiles, n_ftiles / 32));
@@ -703,11 +820,11 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   };
   int rc = GLAMR_OK;
   if (verts || !orig) switch (h->n_extra_used) {
-    case 0: rc = launch(smpl_lbs_kernel<0>); break;
-    case 1: rc = launch(smpl_lbs_kernel<1>); break;
-    case 2: rc = launch(smpl_lbs_kernel<2>); break;
-    case 3: rc = launch(smpl_lbs_kernel<3>); break;
-    case 4: rc = launch(smpl_lbs_kernel<4>); break;
+    case 0: rc = f16 ? launch(smpl_lbs_kernel<0, true>) : launch(smpl_lbs_kernel<0>); break;
+    case 1: rc = f16 ? launch(smpl_lbs_kernel<1, true>) : launch(smpl_lbs_kernel<1>); break;
+    case 2: rc = f16 ? launch(smpl_lbs_kernel<2, true>) : launch(smpl_lbs_kernel<2>); break;
+    case 3: rc = f16 ? launch(smpl_lbs_kernel<3, true>) : launch(smpl_lbs_kernel<3>); break;
+    case 4: rc = f16 ? launch(smpl_lbs_kernel<4, true>) : launch(smpl_lbs_kernel<4>); break;
     default: return fail(GLAMR_E_UNSUPPORTED, "joint_map references %d extra-regressed joints (max 4 supported)", h->n_extra_used);
   }
   if (rc) return rc;
@@ -725,7 +842,7 @@ extern "C" int glamr_smpl_fk(glamr_smpl* h, int B, const float* pose, const floa
   GLAMR_REQUIRE(h && pose && joints, "null argument");
   GLAMR_REQUIRE(B > 0, "B must be positive");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  PrepArgs pa{B, h->num_betas, h->n_levels, 0, pose, nullptr, h->j_template, h->j_shapedirs, h->parents, h->level, nullptr, nullptr, joints};
+  PrepArgs pa{B, h->num_betas, h->n_levels, 0, pose, nullptr, h->j_template, h->j_shapedirs, h->parents, h->level, nullptr, nullptr, nullptr, nullptr, joints};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   if (root_trans) hipLaunchKernelGGL(smpl_fk_anchor_kernel, dim3(B), dim3(NJ), 0, stream, B, root_trans, root_scale, joints);
   GLAMR_HIP_CHECK(hipGetLastError());
