@@ -221,8 +221,12 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // F16: the blend-shape product (K = 218, 70 % of the matrix work) on the fp16 matrix cores with both operands as two fp16 planes (hi + lo,
 // three v_mfma_f32_32x32x16_f16 per 16-deep k step: fp32-grade, 2^-22 of the operands) instead of 112 v_mfma_f32_32x32x2_f32 per
 // coordinate; planes are built once (directions at model creation, feature rows in smpl_prep_kernel).  Skinning stays fp32.
+// The F16 instances run EIGHT waves per workgroup (two per SIMD: the direction tile fills the CU's LDS, so a second wave on the SIMD is
+// the only thing that hides a wave's operand fetches); their vertex transpose buffers hold half a frame tile and are used twice.
 template <int NE, bool F16 = false>
-__global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
+__global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
+  constexpr int NW = F16 ? 8 : 4, NT = NW * 64;               // waves, threads
+  constexpr int OF = F16 ? TILE_F / 2 : TILE_F;                // frames per transpose pass
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sDirs = smem;                                   // [3][32][KSTRIDE]
   float* sOut = smem + (F16 ? 3 * 2 * TILE_V * KSH / 2 : 3 * TILE_V * KSTRIDE);      // [4 waves][32 frames][OUT_STRIDE]  (only when verts != null)
@@ -235,11 +239,11 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
   if (F16) {
     const uint4* src = reinterpret_cast<const uint4*>(a.dirs_h + (size_t)tile * 3 * 2 * TILE_V * KSH);
     uint4* dst = reinterpret_cast<uint4*>(sDirs);
-    for (int i = tid; i < 3 * 2 * TILE_V * KSH / 8; i += 256) dst[i] = src[i];
+    for (int i = tid; i < 3 * 2 * TILE_V * KSH / 8; i += NT) dst[i] = src[i];
   } else {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.dirs_tiled + (size_t)tile * 3 * TILE_V * KSTRIDE);
     f32x4* dst = reinterpret_cast<f32x4*>(sDirs);
-    for (int i = tid; i < 3 * TILE_V * KSTRIDE / 4; i += 256) dst[i] = src[i];
+    for (int i = tid; i < 3 * TILE_V * KSTRIDE / 4; i += NT) dst[i] = src[i];
   }
   // skinning weights of my A-operand row (vertex v0 + col), my k-half: 12 values
   float wreg[12];
@@ -264,16 +268,22 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
       }
   }
   // extra-joint regressor weights for the 16 accumulator rows this lane owns
+  // (registers in the 4-wave instances; the 8-wave F16 instances live on 256 registers and read them from LDS at the point of use)
+  __shared__ float sJx[(NE > 0 ? NE : 1) * TILE_V];
   float jx[NE > 0 ? NE : 1][16];
+  if (F16) {
+    for (int i = tid; i < NE * TILE_V; i += NT) sJx[i] = a.jx_used[(size_t)(i / TILE_V) * (a.n_tiles * TILE_V) + v0 + (i % TILE_V)];
+  } else {
 #pragma unroll
-  for (int e = 0; e < NE; ++e)
+    for (int e = 0; e < NE; ++e)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) jx[e][r] = a.jx_used[(size_t)e * (a.n_tiles * TILE_V) + v0 + acc_row(r, half)];
+      for (int r = 0; r < 16; ++r) jx[e][r] = a.jx_used[(size_t)e * (a.n_tiles * TILE_V) + v0 + acc_row(r, half)];
+  }
   __syncthreads();
 
   const float* myDirs = sDirs + (size_t)col * KSTRIDE + half * KH;
 
-  for (int ft = blockIdx.y * 4 + wave; ft < a.n_ftiles; ft += 4 * gridDim.y) {
+  for (int ft = blockIdx.y * NW + wave; ft < a.n_ftiles; ft += NW * gridDim.y) {
     const int b = ft * TILE_F + col;            // Bpad is a multiple of 32: always a readable row
     const float* frow = a.feat + (size_t)b * KTOT + half * KH;
     f32x16 px = {0}, py = {0}, pz = {0};
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
         for (int r = 0; r < 3; ++r) {
           float s = 0.f;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) s = fmaf(jx[e][q], out[r][q], s);
+          for (int q = 0; q < 16; ++q) s = fmaf(F16 ? sJx[e * TILE_V + acc_row(q, half)] : jx[e][q], out[r][q], s);
           s += __shfl_xor(s, 32);
           if (half == 0) a.partial[(((size_t)tile * a.Bpad + b) * NE + e) * 3 + r] = s;
         }
@@ -389,24 +399,30 @@ __global__ __launch_bounds__(256) void smpl_lbs_kernel(LbsArgs a) {
     }
     // vertex write-out through an LDS transpose: [frame][vertex row][xyz] so each frame's 96 floats are contiguous
     if (a.verts) {
-      float* so = sOut + (size_t)wave * TILE_F * OUT_STRIDE;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = acc_row(q, half);
-        so[col * OUT_STRIDE + row * 3 + 0] = out[0][q];
-        so[col * OUT_STRIDE + row * 3 + 1] = out[1][q];
-        so[col * OUT_STRIDE + row * 3 + 2] = out[2][q];
-      }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      float* so = sOut + (size_t)wave * OF * OUT_STRIDE;
       const int nvalid = min(TILE_V, a.V - v0) * 3;
-      for (int idx = lane; idx < TILE_F * 96; idx += 64) {
-        const int f = idx / 96, c = idx - f * 96;
-        const int bb = ft * TILE_F + f;
-        if (bb < a.B && c < nvalid) a.verts[((size_t)bb * a.V + v0) * 3 + c] = so[f * OUT_STRIDE + c];
+#pragma unroll
+      for (int pass = 0; pass < TILE_F / OF; ++pass) {
+        if (col / OF == pass) {
+          const int fc = col - pass * OF;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = acc_row(q, half);
+            so[fc * OUT_STRIDE + row * 3 + 0] = out[0][q];
+            so[fc * OUT_STRIDE + row * 3 + 1] = out[1][q];
+            so[fc * OUT_STRIDE + row * 3 + 2] = out[2][q];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int idx = lane; idx < OF * 96; idx += 64) {
+          const int f = idx / 96, c = idx - f * 96;
+          const int bb = ft * TILE_F + pass * OF + f;
+          if (bb < a.B && c < nvalid) a.verts[((size_t)bb * a.V + v0) * 3 + c] = so[f * OUT_STRIDE + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
 }
@@ -809,13 +825,14 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   static const bool fp32_blend = std::getenv("GLAMR_SMPL_FP32_BLEND") != nullptr;
   const bool f16 = verts != nullptr && !fp32_blend && ts.dirs_h != nullptr;
   const size_t dirs_bytes = f16 ? (size_t)3 * 2 * TILE_V * KSH * sizeof(unsigned short) : (size_t)3 * TILE_V * KSTRIDE * sizeof(float);
-  const size_t lds = dirs_bytes + (verts ? (size_t)4 * TILE_F * OUT_STRIDE * sizeof(float) : 0);
+  const int nw = f16 ? 8 : 4;
+  const size_t lds = dirs_bytes + (verts ? (size_t)nw * (f16 ? TILE_F / 2 : TILE_F) * OUT_STRIDE * sizeof(float) : 0);
   // frame tiles are split over gridDim.y so that a launch has ~4 workgroups per CU even with few vertex tiles; every workgroup
   // re-stages its 87 KB direction tile, so a chunk keeps >= 8 frame tiles per wave
   int gy = std::max(1, std::min((1024 + ts.n_tiles - 1) / ts.n_tiles, n_ftiles / 32));
   auto launch = [&](auto kern) -> int {
     GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(ts.n_tiles, gy), dim3(256), lds, stream, la);
+    hipLaunchKernelGGL(kern, dim3(ts.n_tiles, gy), dim3(nw * 64), lds, stream, la);
     return GLAMR_OK;
   };
   int rc = GLAMR_OK;
