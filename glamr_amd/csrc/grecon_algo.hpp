@@ -39,7 +39,10 @@ namespace grecon {
 
 constexpr int NJ = 26;
 #ifndef GLAMR_KP_DEPTH
-#define GLAMR_KP_DEPTH 3      // keypoint rows requested ahead of the one being processed (grecon_algo.hpp phase E)
+#define GLAMR_KP_DEPTH 3      // keypoint rows requested ahead of the one being processed (grecon_algo.hpp phase E; GLAMR_KP_GROUP=0 builds only)
+#endif
+#ifndef GLAMR_KP_GROUP
+#define GLAMR_KP_GROUP 3      // workspace keypoint rows per group (requested a whole group ahead, processed without branches); 0 = the one-row ring
 #endif
 constexpr float FPS = 30.0f;
 
@@ -1138,8 +1141,66 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
                 }
               }
             };
+#if GLAMR_KP_GROUP > 0
+            // Workspace rows in GROUPS, the next group requested before the current one is processed, and no branch inside a group: around
+            // a loop back edge (or any merge) the compiler cannot count the loads in flight and waits for ALL of them -- with the one-row
+            // ring above every workspace row cost a full memory round trip (0.3 us); a whole group of arithmetic now covers it.
+            constexpr int KG = GLAMR_KP_GROUP;
+            (void)run;
+            if (w_kp != 0.f) {
+              // Every multiply-add of a row is written out (fused where fma_ says so, nowhere else): the compiler contracts a * b + c at its
+              // own discretion PER COPY of this code, and the copies (on-chip rows, the two group buffers) must agree to the bit -- which
+              // rows fit the arena must not change the result (test_shared_cu_arena_gives_the_same_values).
+              auto joint_nb = [&](const float (&cur)[6], bool in_range) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+                const float hx = rm::fma_(H[2], cur[2], rm::fma_(H[1], cur[1], H[0] * cur[0])) + q[0];
+                const float hy = rm::fma_(H[5], cur[2], rm::fma_(H[4], cur[1], H[3] * cur[0])) + q[1];
+                const float hz = (rm::fma_(H[8], cur[2], rm::fma_(H[7], cur[1], H[6] * cur[0])) + q[2]) + 1e-8f;
+                const float ihz = rm::rcp_(hz);
+                const float u = hx * ihz, v = hy * ihz;
+                const float du = u - cur[3], dv = v - cur[4];
+                const float ru = rm::rcp_(rm::fma_(du, du, 1e4f)), rv = rm::rcp_(rm::fma_(dv, dv, 1e4f));      // gmof_d(x, 1e4) = 2e8 x / (1e4 + x^2)^2
+                const float gu = ((((2e8f * du) * ru) * ru) * cur[5]) * w_kp, gv = ((((2e8f * dv) * rv) * rv) * cur[5]) * w_kp;
+                const bool live = in_range && cur[5] != 0.f;          // a select, not a branch: rows without weight add exact zeros
+                const float g2 = -rm::fma_(gu, u, gv * v);
+                const float gh[3] = {live ? gu * ihz : 0.f, live ? gv * ihz : 0.f, live ? g2 * ihz : 0.f};
+                for (int i = 0; i < 3; ++i) {
+                  for (int k = 0; k < 3; ++k) gH[i * 3 + k] = rm::fma_(gh[i], cur[k], gH[i * 3 + k]);
+                  gq[i] = gq[i] + gh[i];
+                }
+              };
+              for (int jj = 0; jj < nf; ++jj) {
+                float c6[6];
+                fetch_chip(jj, c6);
+                joint_nb(c6, true);
+              }
+              float ga[KG][6], gb[KG][6];
+              auto fetch_group = [&](int base, float (&b)[KG][6]) {
+#pragma unroll
+                for (int d = 0; d < KG; ++d) fetch_ws(base + d < njc ? base + d : njc - 1, b[d]);
+              };
+              auto do_group = [&](int base, float (&b)[KG][6]) {
+#pragma unroll
+                for (int d = 0; d < KG; ++d) joint_nb(b[d], base + d < njc);
+              };
+              int base = nf;
+              if (base < njc) fetch_group(base, ga);
+              while (base < njc) {
+                if (base + KG < njc) fetch_group(base + KG, gb);
+                do_group(base, ga);
+                base += KG;
+                if (base >= njc) break;
+                if (base + KG < njc) fetch_group(base + KG, ga);
+                do_group(base, gb);
+                base += KG;
+              }
+            }
+#else
             run(0, nf, fetch_chip);
             run(nf, njc, fetch_ws);
+#endif
           }
           if (w_kp != 0.f && kp_frame) push_back();
         }
