@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdlib>
 #include <cstdio>
+#include <type_traits>
 #include "common.hpp"
 
 namespace glamr {
@@ -252,7 +253,10 @@ struct RowsArgs {
   float* Y; int ldy;
 };
 
-template <bool TWO>
+// KS1 > 0: the k steps of the first GEMM phase are known at compile time (16 for the 256-wide transformer layers): every phase is then
+// straight-line code -- around a loop back edge the compiler cannot count the weight fragments in flight and waits for all of them at
+// the loop head, which defeats the three-steps-ahead prefetch.
+template <bool TWO, int KS1 = 0>
 __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NJ = 1;                                             // 8 waves: one 32-column tile each (x 2 row tiles)
@@ -276,7 +280,9 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
   }
   __syncthreads();
   // one GEMM phase: acc[i][j] += A(rows 32 i.., K) * W(cols of this wave's tiles j, k range) with A planes in LDS
-  auto phase = [&](const unsigned char* sA, int AS, int ksteps_here, const unsigned short* Ws, size_t plane, int ksteps_w, int kstep0, int nb0, f32x16 (&acc)[2][NJ]) {
+  // KSC > 0: compile-time number of k steps (fully unrolled, no branches); KSC == 0: `ksteps_here` at run time
+  auto phase = [&](auto ksc_tag, const unsigned char* sA, int AS, int ksteps_here, const unsigned short* Ws, size_t plane, int ksteps_w, int kstep0, int nb0, f32x16 (&acc)[2][NJ]) {
+    constexpr int KSC = decltype(ksc_tag)::value;
     const uint4* wf[2][NJ];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -284,41 +290,65 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
       for (int j = 0; j < NJ; ++j) wf[p][j] = reinterpret_cast<const uint4*>(Ws + p * plane) + ((size_t)(nb0 + j) * ksteps_w + kstep0) * 64 + lane;
     // weight fragments THREE k steps ahead (a wave has one other wave on its SIMD to hide an L2 round trip behind: 3 x 6 MFMAs do)
     uint4 vb[4][2][NJ];
+    auto step = [&](int kstep, int u) {
+      f16x8 xa[2][2], xb[2][NJ];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+      for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
+        for (int i = 0; i < 2; ++i) xa[p][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + p * 64 * AS + (i * 32 + c) * AS + kstep * 32 + kg * 16));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) if (d < ksteps_here) vb[d][p][j] = wf[p][j][(size_t)d * 64];
-    for (int ks = 0; ks < ksteps_here; ks += 4) {
+        for (int j = 0; j < NJ; ++j) xb[p][j] = __builtin_bit_cast(f16x8, vb[u][p][j]);
+      }
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kstep = ks + u;
-        if (kstep >= ksteps_here) break;
-        if (kstep + 3 < ksteps_here) {
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[PA[term]][i], xb[PB[term]][j], acc[i][j], 0, 0, 0);
+    };
+    if constexpr (KSC > 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) if (d < KSC) vb[d][p][j] = wf[p][j][(size_t)d * 64];
+#pragma unroll
+      for (int kstep = 0; kstep < KSC; ++kstep) {
+        if (kstep + 3 < KSC) {
 #pragma unroll
           for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) vb[(u + 3) & 3][p][j] = wf[p][j][(size_t)(kstep + 3) * 64];
+            for (int j = 0; j < NJ; ++j) vb[(kstep + 3) & 3][p][j] = wf[p][j][(size_t)(kstep + 3) * 64];
         }
-        f16x8 xa[2][2], xb[2][NJ];
+        step(kstep, kstep & 3);
+      }
+    } else {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) xa[p][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + p * 64 * AS + (i * 32 + c) * AS + kstep * 32 + kg * 16));
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) xb[p][j] = __builtin_bit_cast(f16x8, vb[u][p][j]);
+          for (int j = 0; j < NJ; ++j) if (d < ksteps_here) vb[d][p][j] = wf[p][j][(size_t)d * 64];
+      for (int ks = 0; ks < ksteps_here; ks += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kstep = ks + u;
+          if (kstep >= ksteps_here) break;
+          if (kstep + 3 < ksteps_here) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) vb[(u + 3) & 3][p][j] = wf[p][j][(size_t)(kstep + 3) * 64];
+          }
+          step(kstep, u);
         }
-        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
-#pragma unroll
-        for (int term = 0; term < 3; ++term)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[PA[term]][i], xb[PB[term]][j], acc[i][j], 0, 0, 0);
       }
     }
   };
+  using ks1_t = std::integral_constant<int, KS1>;
+  using ks16_t = std::integral_constant<int, 16>;
   f32x16 acc2[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc1[i][j] = (f32x16){0};
-      phase(sX, XS, K1 / 16, a.W1s, a.w1_plane, K1 / 16, 0, hh * 8 + wave * NJ, acc1);
+      phase(ks1_t{}, sX, XS, K1 / 16, a.W1s, a.w1_plane, K1 / 16, 0, hh * 8 + wave * NJ, acc1);
       if (hh) __syncthreads();                                    // everybody is done reading the previous hidden half
       // hidden half -> planes: lane owns column n, rows (q & 3) + 8 (q >> 2) + 4 kg of each tile
 #pragma unroll
@@ -353,10 +383,10 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
           }
       }
       __syncthreads();
-      phase(sH, HS, 16, a.W2s, a.w2_plane, a.K2 / 16, hh * 16, wave * NJ, acc2);
+      phase(ks16_t{}, sH, HS, 16, a.W2s, a.w2_plane, a.K2 / 16, hh * 16, wave * NJ, acc2);
     }
   } else {
-    phase(sX, XS, K1 / 16, a.W2s, a.w2_plane, a.K2 / 16, 0, wave * NJ, acc2);
+    phase(ks1_t{}, sX, XS, K1 / 16, a.W2s, a.w2_plane, a.K2 / 16, 0, wave * NJ, acc2);
   }
   __syncthreads();                                                // sH is free: output rows go there
 #pragma unroll
@@ -991,13 +1021,16 @@ inline int launch_rows(hipStream_t st, const float* X, int ldx, int M, int K1, c
   const size_t lds = rows_fused_lds(K1, W1s != nullptr);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    if (e1 != hipSuccess || e2 != hipSuccess) return fail(GLAMR_E_HIP, "hipFuncSetAttribute(rows_fused_kernel) failed");
+    const void* kerns[] = {reinterpret_cast<const void*>(rows_fused_kernel<true>), reinterpret_cast<const void*>(rows_fused_kernel<false>),
+                           reinterpret_cast<const void*>(rows_fused_kernel<true, 16>), reinterpret_cast<const void*>(rows_fused_kernel<false, 16>)};
+    for (const void* k : kerns)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) return fail(GLAMR_E_HIP, "hipFuncSetAttribute(rows_fused_kernel) failed");
     attr_done = true;
   }
-  if (W1s) hipLaunchKernelGGL(rows_fused_kernel<true>, dim3((M + 63) / 64), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(rows_fused_kernel<false>, dim3((M + 63) / 64), dim3(512), lds, st, a);
+  // K1 = 256 (every transformer block): the instances whose phases are straight-line code
+  const bool k256 = K1 == 256;
+  if (W1s) { if (k256) hipLaunchKernelGGL((rows_fused_kernel<true, 16>), dim3((M + 63) / 64), dim3(512), lds, st, a); else hipLaunchKernelGGL(rows_fused_kernel<true>, dim3((M + 63) / 64), dim3(512), lds, st, a); }
+  else { if (k256) hipLaunchKernelGGL((rows_fused_kernel<false, 16>), dim3((M + 63) / 64), dim3(512), lds, st, a); else hipLaunchKernelGGL(rows_fused_kernel<false>, dim3((M + 63) / 64), dim3(512), lds, st, a); }
   return GLAMR_OK;
 }
 
