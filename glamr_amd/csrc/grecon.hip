@@ -9,6 +9,7 @@
 #include "grecon_algo.hpp"
 #include "block_rt.hpp"
 #include <map>
+#include <set>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -180,7 +181,13 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // SINGLE needs every scene of the batch to hold exactly one person: max_persons == 1 guarantees it
   const bool single = batch->max_persons == 1;
   auto launch = [&](auto kern, size_t lds) -> int {
-    if (lds) GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    if (lds) {      // once per instance and process (a driver call per launch is host time on every step)
+      static std::mutex amu;
+      static std::set<const void*> raised;
+      std::lock_guard<std::mutex> lock(amu);
+      if (raised.insert(reinterpret_cast<const void*>(kern)).second)
+        GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    }
     hipLaunchKernelGGL(kern, dim3(batch->n_scenes), dim3(threads), lds, stream, ka);
     return GLAMR_OK;
   };

@@ -20,6 +20,8 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 namespace glamr {
 
@@ -814,8 +816,9 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   }
   const bool orig = (flags & GLAMR_SMPL_ORIG_JOINTS) != 0;
   const glamr_tileset& ts = (!verts && h->joints.n_tiles > 0) ? h->joints : h->full;
-  // (the fp16 planes of the feature rows / joint transforms are only written for the launches that read them)
-  const bool planes = verts != nullptr && std::getenv("GLAMR_SMPL_FP32_BLEND") == nullptr && ts.dirs_h != nullptr;
+  // blend shapes and skinning transforms on the fp16 matrix cores (two-plane operands: fp32-grade products); GLAMR_SMPL_FP32_BLEND=1
+  // selects the fp32-MFMA instances (and then the planes of the feature rows / joint transforms are not written)
+  const bool planes = std::getenv("GLAMR_SMPL_FP32_BLEND") == nullptr && ts.dirs_h != nullptr;
   PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat,
               planes ? reinterpret_cast<unsigned short*>(w.feat_h) : nullptr, w.askin, planes ? reinterpret_cast<unsigned short*>(w.askin_h) : nullptr, w.chain};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
@@ -823,8 +826,6 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   LbsArgs la{B, h->V, ts.n_tiles, n_ftiles, h->n_extra_used, h->n_picked, ts.dirs_tiled, ts.w_tiled, ts.jx_used,
              ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, ts.dirs_h, reinterpret_cast<const unsigned short*>(w.feat_h), reinterpret_cast<const unsigned short*>(w.askin_h), w.askin, verts,
              w.picked, w.partial, w.Bpad};
-  // blend shapes on the fp16 matrix cores (two-plane operands) when vertices are produced -- the calls where the matrix pipe is the
-  // bound; the joints-only calls of the optimiser path keep the fp32 products (GLAMR_SMPL_FP32_BLEND=1: everywhere)
   const bool f16 = planes;
   const size_t dirs_bytes = f16 ? (size_t)3 * 2 * TILE_V * KSH * sizeof(unsigned short) : (size_t)3 * TILE_V * KSTRIDE * sizeof(float);
   const int nw = f16 ? 8 : 4;
@@ -833,7 +834,13 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   // re-stages its 87 KB direction tile, so a chunk keeps >= 8 frame tiles per wave
   int gy = std::max(1, std::min((1024 + ts.n_tiles - 1) / ts.n_tiles, n_ftiles / 32));
   auto launch = [&](auto kern) -> int {
-    GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {      // once per instance and process: the largest arena an instance can ask for (direction tile + eight half-tile transposes)
+      static std::mutex amu;
+      static std::set<const void*> raised;
+      std::lock_guard<std::mutex> lock(amu);
+      if (raised.insert(reinterpret_cast<const void*>(kern)).second)
+        GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    }
     hipLaunchKernelGGL(kern, dim3(ts.n_tiles, gy), dim3(nw * 64), lds, stream, la);
     return GLAMR_OK;
   };
