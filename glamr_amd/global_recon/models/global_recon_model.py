@@ -530,8 +530,10 @@ class GlobalReconOptimizer:
         # inputs / outputs / workspace of the priors live at fixed addresses (two sets per stream): the library replays the call as a HIP graph
         nw = num_windows(int(rin.lens.max()))
         rs = self.mt_model.handle.resident_set(n_slots, T, nw) if hasattr(self.mt_model, 'handle') else None
-        pa_t = dict(visible_orig=f32(n_slots, T), smpl_pose=f32(n_slots, T, 69), smpl_beta=f32(n_slots, T, 10), trans_cam=f32(n_slots, T, 3),
-                    nets_pose=rs['nets_pose'] if rs else f32(n_slots, T, 69), nets_vis=rs['nets_vis'] if rs else f32(n_slots, T))
+        pa_t = packing.carve_zeros([('visible_orig', torch.float32, (n_slots, T)), ('smpl_pose', torch.float32, (n_slots, T, 69)),
+                                    ('smpl_beta', torch.float32, (n_slots, T, 10)), ('trans_cam', torch.float32, (n_slots, T, 3))], dev)
+        pa_t['nets_pose'] = rs['nets_pose'] if rs else f32(n_slots, T, 69)
+        pa_t['nets_vis'] = rs['nets_vis'] if rs else f32(n_slots, T)
         # the cached joints are produced in place by the skinning kernel: keep a placeholder until then
         packed.t['j_local'] = f32(1)
         raw = _lib.RawBatch()

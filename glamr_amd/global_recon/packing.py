@@ -77,6 +77,21 @@ def stage_desc(stage_specs, model_specs, has_world_dheading=False, niters=None):
     return sd
 
 
+def carve_zeros(spec, device):
+    """{name: zero tensor} for [(name, dtype, shape)] of 4-byte dtypes, all views of ONE zero-filled device allocation (64-float aligned)."""
+    import math
+    offs, total = [], 0
+    for _, _, shape in spec:
+        offs.append(total)
+        total += (math.prod(shape) + 63) // 64 * 64
+    slab = torch.zeros(total, dtype=torch.float32, device=device)
+    out = {}
+    for (name, dtype, shape), o in zip(spec, offs):
+        v = slab[o:o + math.prod(shape)]
+        out[name] = (v if dtype == torch.float32 else v.view(dtype)).view(shape)
+    return out
+
+
 class PackedScenes:
     """Flat tensors of a batch of scenes on `device` + the ctypes struct that points at them."""
 
@@ -89,16 +104,19 @@ class PackedScenes:
         S, P, T = n_scenes, max_persons, max_len
         self.device, self.S, self.P, self.T = device, S, P, T
         self.layout = param_layout_py(P, T)
-        f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
-        i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=device)
-        self.t = dict(n_persons=i32(S), seq_len=i32(S), fr_start=i32(S * P), fr_end=i32(S * P), vis=f32(S * P, T), j_local=None,
-                      kp_2d=f32(S * P, T, NJ, 2), kp_score=f32(S * P, T, NJ), cam_K=f32(S * P, T, 9), traj_local_pred=f32(S * P, T, 11),
-                      orient_cam=f32(S * P, T, 3), base_orient=f32(S * P, T, 3), base_trans=f32(S * P, T, 3), person2cam=f32(S * P, T, 12),
-                      cam_pose=f32(S, T, 12), params=f32(S, self.layout['scene_stride']), losses=f32(S, _lib.NUM_LOSSES),
-                      orient_world=f32(S * P, T, 3), trans_world=f32(S * P, T, 3), kp_2d_pred=f32(S * P, T, NJ, 2),
-                      orient_cam_in_world=f32(S * P, T, 3))
+        # ONE zero allocation carved into the arrays (22 allocations + 22 fill launches otherwise: host time on every batch, and on hosts
+        # with slow driver calls the launches of a step are paced by it)
+        spec = [('n_persons', torch.int32, (S,)), ('seq_len', torch.int32, (S,)), ('fr_start', torch.int32, (S * P,)), ('fr_end', torch.int32, (S * P,)),
+                ('vis', torch.float32, (S * P, T)), ('kp_2d', torch.float32, (S * P, T, NJ, 2)), ('kp_score', torch.float32, (S * P, T, NJ)),
+                ('cam_K', torch.float32, (S * P, T, 9)), ('traj_local_pred', torch.float32, (S * P, T, 11)), ('orient_cam', torch.float32, (S * P, T, 3)),
+                ('base_orient', torch.float32, (S * P, T, 3)), ('base_trans', torch.float32, (S * P, T, 3)), ('person2cam', torch.float32, (S * P, T, 12)),
+                ('cam_pose', torch.float32, (S, T, 12)), ('params', torch.float32, (S, self.layout['scene_stride'])), ('losses', torch.float32, (S, _lib.NUM_LOSSES)),
+                ('orient_world', torch.float32, (S * P, T, 3)), ('trans_world', torch.float32, (S * P, T, 3)), ('kp_2d_pred', torch.float32, (S * P, T, NJ, 2)),
+                ('orient_cam_in_world', torch.float32, (S * P, T, 3))]
         if P > 1 if with_rel is None else with_rel:
-            self.t['rel_transform_cam'] = f32(S, P, P, T, 12)
+            spec.append(('rel_transform_cam', torch.float32, (S, P, P, T, 12)))
+        self.t = carve_zeros(spec, device)
+        self.t['j_local'] = None
         self.person_ids = None
         self.has_world_dheading = False
         return self
