@@ -154,3 +154,23 @@ def test_host_scatter_matches_numpy_indexing():
     bad['bboxes_dict']['exist'] = e1
     with pytest.raises(RuntimeError):
         g._scatter_inputs([{'est': {0: bad}}], [[0]], 1, h)
+
+
+def test_carved_batch_arrays_are_independent_zero_views():
+    """PackedScenes.empty carves its arrays from one zero allocation: right shapes / dtypes, 256-byte steps, no overlap (writing one array
+    leaves every other array zero), and the C struct the library receives points at them."""
+    from glamr_amd.global_recon import packing
+    p = packing.PackedScenes.empty(3, 2, 40, torch.device('cpu'))
+    t = {k: v for k, v in p.t.items() if v is not None}
+    assert t['fr_start'].dtype == torch.int32 and t['kp_2d'].shape == (6, 40, 26, 2) and t['rel_transform_cam'].shape == (3, 2, 2, 40, 12)
+    base = min(v.data_ptr() for v in t.values())
+    for name, v in t.items():      # (256-byte steps from the allocation's start; device allocations themselves are 256-byte aligned)
+        assert v.is_contiguous() and (v.data_ptr() - base) % 256 == 0 and float(v.abs().sum()) == 0.0, name
+    for name, v in t.items():
+        v.fill_(1)
+        for other, w in t.items():
+            if other != name:
+                assert float(w.abs().sum()) == 0.0, (name, other)
+        v.zero_()
+    sb = p.struct()
+    assert sb.params == t['params'].data_ptr() and sb.cam_pose == t['cam_pose'].data_ptr()
