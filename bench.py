@@ -12,6 +12,10 @@ independent, so ranks share nothing on the data path; the only collectives are t
 time.  `--mode weak` (default): every rank works on its own B sequences; `--mode strong --total 64`: BASELINE configs[2], a fixed set
 of 64 sequences split over the ranks.
 
+After the warm-up the whole step is captured as ONE HIP graph per stream, checked against a plain step bit for bit (same seed for the
+sampled latents) and replayed in the timed region: the same kernels on the same buffers with one launch on the host instead of ~25, so a
+host with slow driver calls does not pace the GPU (`config.step_graph`; `--no-graph-step`, or any failure of capture / check: plain launches).
+
 Kernel durations come from the kernel's own clock (stamps in the workspace header = what rocprofv3 reports for the dispatch), and the
 roofline launch is measured with the GPU to itself (see run()).
 
@@ -243,6 +247,9 @@ def run(argv=None):
     ap.add_argument('--mode', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--total', type=int, default=64, help='--mode strong: sequences in the whole job (BASELINE configs[2]: 64)')
     ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over')
+    ap.add_argument('--no-graph-step', action='store_true', help='do NOT capture a whole step per stream as one HIP graph after the warm-up (default: capture, check the replay '
+                    'against a plain step bit for bit, replay it in the timed region -- a host whose driver calls are slow then no longer paces the ~25 launches of '
+                    'a step; any failure of capture or check falls back to plain launches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-lines', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo with --stub-model for the CPU test of the skeleton)')
@@ -304,9 +311,48 @@ def run(argv=None):
         if len(keep) > 2 * len(streams):
             keep.pop(0)
 
-    for i in range(args.warmup):
+    graph_step = on_gpu and not args.no_graph_step
+    for i in range(max(args.warmup, len(streams) if graph_step else 0)):
         step(i)
     sync()
+    step_graphs = None
+    if graph_step:
+        # every stream has run the step once (allocations, attribute calls, the priors' own graph): capture it, one graph per stream
+        try:
+            step_graphs = []
+            for st in streams:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    _, pk = model.optimize_resident(rin)
+                step_graphs.append((g, pk))
+            sync()
+            # self-check: the replay must reproduce a plain step bit for bit (same seed for the sampled latents)
+            torch.manual_seed(20260926)
+            with torch.cuda.stream(streams[0]):
+                _, ref = model.optimize_resident(rin)
+            sync()
+            want = ref.t['kp_2d_pred'].clone()
+            torch.manual_seed(20260926)
+            with torch.cuda.stream(streams[0]):
+                step_graphs[0][0].replay()
+            sync()
+            got = step_graphs[0][1].t['kp_2d_pred']
+            if not (bool(torch.isfinite(got).all()) and torch.equal(got, want)):
+                raise RuntimeError('the replayed step does not reproduce the plain one (max |diff| %.3g)' % float((got - want).abs().max()))
+            eager_step = step
+
+            def step(i=0):
+                g, pk = step_graphs[i % len(step_graphs)]
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    g.replay()
+                stage_events.append(pk.stage_ws)
+        except Exception as e:      # noqa: BLE001 -- anything: the plain launches are always available
+            sys.stderr.write('bench: step graph not used (%s); plain launches\n' % e)
+            step_graphs = None
+            try:
+                sync()
+            except Exception:      # noqa: BLE001
+                pass
     del stage_events[:]
     if world > 1:
         dist.barrier()
@@ -385,7 +431,7 @@ def run(argv=None):
                                    ('BASELINE configs[2]: %d independent %d-frame 1-person sequences (cfg %s, %d iterations) split over %d GPU(s): %d per GPU '
                                     '= %d of %d CUs busy in the optimiser stage' % (args.total, NUM_FRAMES, CFG_ID, iters, world, B, min(B, n_cus), n_cus)),
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
-                       'streams_per_gpu': len(streams)},
+                       'streams_per_gpu': len(streams), 'step_graph': bool(step_graphs)},
             'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'hbm', 'real_bound': 'latency / issue (one workgroup per scene, state on chip)',
                          'us_per_scene_iteration': us_scene_iter, 'dependent_boundary_floor_us': DEPENDENT_BOUNDARY_US,
                          'times_above_floor': us_scene_iter / DEPENDENT_BOUNDARY_US,

@@ -883,7 +883,12 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   GLAMR_REQUIRE(!do_infill || n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   Ws w = ws_layout(B, max_len, static_cast<char*>(workspace));
-  GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  // A caller that is CAPTURING this stream (its whole step as one graph) gets the plain launch sequence recorded into its graph; the
+  // host->device copy of the lengths is left out of it (its source is a temporary of this call): the caller replays a call that already
+  // ran once on these buffers, so the lengths are in place.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool outer_capture = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+  if (!outer_capture) GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   auto enqueue = [&]() -> int {
     return enqueue_infer(h, st, w, B, max_len, n_win, n_win_max, do_infill, do_traj, body_pose, visible, motion_eps, traj_eps, out_pose, out_local_traj, out_trans,
                          out_orient);
@@ -892,7 +897,7 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   // steady state) seen twice is captured into a HIP graph and replayed from then on: one launch on the host instead of 450, which is
   // what keeps the step time when the host is slow or shared.  Anything unexpected falls back to the plain launches.
   static const bool no_graph = std::getenv("GLAMR_NETS_NO_GRAPH") != nullptr;
-  if (!no_graph) {
+  if (!no_graph && !outer_capture) {
     glamr_nets::GraphKey key;
     std::memset(&key, 0, sizeof(key));
     key.v[0] = B; key.v[1] = max_len; key.v[2] = n_win; key.v[3] = flags; key.v[4] = n_win_max;

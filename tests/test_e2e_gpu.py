@@ -415,3 +415,14 @@ def test_continue_opt_restarts_from_a_previous_result(make_model, asset_root):
     # it did move away from where it started, and the input dictionary was left alone
     assert np.abs(again['person_data'][0]['traj_local_rot'] - first['person_data'][0]['traj_local_rot']).max() > 1e-4
     assert 'world_dheading' in again['person_data'][0]
+
+
+def test_bench_step_graph_reproduces_the_plain_step():
+    """bench.py captures a whole step as one HIP graph per stream and replays it in the timed region; its self-check compares a replay with a
+    plain step bit for bit (same seed) and falls back to plain launches otherwise.  The short run here must have used the graph."""
+    import bench
+    out = bench.run(['--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--no-kernel-lines'])
+    assert out['config']['step_graph'] is True
+    assert out['value'] > 0 and out['steps'] == 2
+    plain = bench.run(['--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--no-kernel-lines', '--no-graph-step'])
+    assert plain['config']['step_graph'] is False
