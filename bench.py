@@ -322,7 +322,8 @@ def run(argv=None):
             step_graphs = []
             for st in streams:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st):
+                # (thread-local capture mode: a watchdog thread of the process group may query events while this thread captures)
+                with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
                     _, pk = model.optimize_resident(rin)
                 step_graphs.append((g, pk))
             sync()
