@@ -385,6 +385,51 @@ def gen_full(which=('gap', 'nogap')):
         print('full reference optimize() [%s]: %.1f s on %d threads' % (name, dt, torch.get_num_threads()))
 
 
+FULL_CASES = [('glamr_static_multi', 300, 4), ('glamr_3dpw', 300, 1), ('glamr_dynamic_multi', 300, 2), ('glamr_static', 300, 1),
+              ('glamr_h36m', 300, 2)]
+
+
+def full_name(cfg_id, T, P, gap=True):
+    return 'full_%s_T%d_P%d%s' % (cfg_id, T, P, '' if gap else '_nogap')
+
+
+def gen_full_cfg(cases=FULL_CASES, gaps=(True, False)):
+    """FULL schedules (every stage to its last iteration) of the configurations gen_grecon pins for a handful of iterations only
+    (VERDICT r2 item 1): BASELINE.json configs[3] (glamr_static_multi, 300 frames x 4 persons, 200 + 500 iterations, shared fixed
+    camera, relative-transform term), glamr_3dpw (camera from the person's pose, two stages), glamr_dynamic_multi (per-frame camera, two
+    persons), and the remaining two shipped files.  Seed 3 = the inputs of the K-step fixtures.  With the synthetic detection gaps
+    (person p undetected in [100 + 37 p, 160 + 37 p)) and without.  The state after the FIRST stage is stored as well (`s1_` keys), so a
+    difference can be attributed to a stage."""
+    import time
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    for cfg_id, T, P in cases:
+        for gap in gaps:
+            model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+            in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md, gap=None if gap else (0, 0))
+            snap = {}
+            keep = model.optimize_main
+            keys = PERSON_KEYS_OPT + ['smpl_pose', 'visible', 'vis_frames']
+
+            def optimize_main(data, *a, keep=keep, snap=snap, keys=keys, **k):
+                r = keep(data, *a, **k)
+                if not snap:
+                    snap.update({'s1_' + kk: v.copy() for kk, v in _flatten_state(data, keys, TOP_KEYS).items()})
+                return r
+            model.optimize_main = optimize_main
+            t0 = time.time()
+            data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 3))
+            dt = time.time() - t0
+            out = _flatten_state(data, keys, TOP_KEYS)
+            if len(cfg.opt_stage_specs) > 1:
+                out.update(snap)
+            out['ref_seconds'] = np.array(dt)
+            out['ref_threads'] = np.array(torch.get_num_threads())
+            np.savez_compressed(os.path.join(GOLD, full_name(cfg_id, T, P, gap) + '.npz'), **out)
+            print('full reference optimize() %s T=%d P=%d gap=%s: %.1f s on %d threads' % (cfg_id, T, P, gap, dt, torch.get_num_threads()), flush=True)
+
+
 FAMILY = [('threads3', dict(threads=3)), ('threads8', dict(threads=8))] + \
          [('eps%s_seed%d' % (name, sd), dict(eps=eps, seed=sd)) for name, eps in (('1e-7', 1e-7), ('1e-6', 1e-6)) for sd in (0, 1, 2)]
 
@@ -480,7 +525,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'eval': gen_eval}[name]()
         print('done', name)
 
 
