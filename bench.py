@@ -49,7 +49,17 @@ DEPENDENT_BOUNDARY_US = 1.45
 SMPL_FLOP_PER_FRAME = 15.8e6                  # blend shapes + skinning + regression, with vertices
 SMPL_BYTES_PER_FRAME_VERTS = 6890 * 3 * 4 + 26 * 3 * 4 + 82 * 4      # vertex + joint write-out, pose / shape read
 NETS_FLOP_PER_SEQUENCE = 3.2e9                # infiller 272 MFLOP per window x 10 windows + trajectory predictor 0.93 GFLOP at 300 frames
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_stage_kernel.json')      # written by tools/collect_pmc.py from rocprofv3 --pmc passes
+FP16X3_PEAK_TFLOPS = 2500.0 / 3.0             # fp32-grade products on the fp16 matrix cores cost three MFMAs per k step (hi*hi + hi*lo + lo*hi): dense fp16 peak / 3
+
+
+def pmc_file():
+    """The newest profiles/rNN_pmc_stage_kernel.json (written by tools/collect_pmc.py from rocprofv3 --pmc passes on the shipped instance)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_stage_kernel.json')))
+    return files[-1] if files else None
+
+
+
 CFG_ID, NUM_FRAMES = 'glamr_dynamic', 300
 
 
@@ -149,9 +159,12 @@ def kernel_lines(asset_root, model, dev):
             tf = SMPL_FLOP_PER_FRAME * B / dt / 1e12 if verts else None
             lines.append({'frames': B, 'vertices': verts, 'ms': round(dt * 1e3, 4),
                           'tflops_algorithmic': None if tf is None else round(tf, 2), 'frac_of_f32_mfma_peak': None if tf is None else round(tf / F32_MFMA_PEAK_TFLOPS, 3),
+                          'frac_of_fp16x3_peak': None if tf is None else round(tf / FP16X3_PEAK_TFLOPS, 4),
                           'write_gbs': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9, 1) if verts else None,
                           'frac_of_hbm_peak': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9 / HBM_PEAK_GBS, 3) if verts else None})
-    out['smpl_lbs'] = {'flop_per_frame': SMPL_FLOP_PER_FRAME, 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'runs': lines}
+    best = max((l['tflops_algorithmic'] or 0.0) for l in lines)
+    out['smpl_lbs'] = {'flop_per_frame': SMPL_FLOP_PER_FRAME, 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'fp16x3_peak_tflops': round(FP16X3_PEAK_TFLOPS, 1),
+                       'frac_of_fp16x3_peak': round(best / FP16X3_PEAK_TFLOPS, 4), 'runs': lines}
     # the two priors on 1024 sequences of 300 frames (GEMM-dominated: the fp16-split MFMA kernels)
     md = synth.make_smpl_model()
     Bn, T = 1024, NUM_FRAMES
@@ -162,6 +175,8 @@ def kernel_lines(asset_root, model, dev):
     dt = _timed(lambda: model.mt_model.infer_padded(pose, vis, [T] * Bn, meps, teps), reps=2)
     out['priors'] = {'sequences': Bn, 'frames': T, 'ms': round(dt * 1e3, 2), 'sequences_per_sec': round(Bn / dt, 1),
                      'tflops_fp32_equivalent': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12, 1), 'flop_per_sequence': NETS_FLOP_PER_SEQUENCE,
+                     'frac_of_f32_mfma_peak': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 3),
+                     'frac_of_fp16x3_peak': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12 / FP16X3_PEAK_TFLOPS, 4),
                      'note': 'infiller (10 autoregressive windows) + trajectory predictor; fp32-grade results on the fp16 matrix cores by 2-way operand splitting (3 MFMAs per k step)'}
     # BASELINE configs[0]: one 120-frame clip through the infiller, then full skinning with vertices -- batched over 1024 clips
     T0 = 120
@@ -196,6 +211,34 @@ def kernel_lines(asset_root, model, dev):
         'us_per_scene_iteration': [round(x * 1e3 / n, 1) for x, n in zip(stage_ms, iters)],
         'shared_camera_reduction': 'in-kernel block reduction of the 9 shared camera gradients (one workgroup per scene); see `collective_alternative`'}
     return out
+
+
+def one_sequence_latency(model, in_dict, reps=5):
+    """BASELINE configs[1] is literally ONE 300-frame sequence: the latency of the reference's own call pattern, nothing to batch.  Median of
+    `reps` runs of optimize(in_dict) (host dictionary in -> host dictionary out) and of optimize_resident on the staged inputs (HBM -> HBM)."""
+    import statistics
+    import torch
+    model.optimize(in_dict)                                        # warm-up: allocations, attribute calls, the priors' graph for this geometry
+    model.optimize(in_dict)
+    host, hbm = [], []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        model.optimize(in_dict)
+        torch.cuda.synchronize()
+        host.append((time.time() - t0) * 1e3)
+    rin = model.stage_inputs([in_dict])
+    for i in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        _, pk = model.optimize_resident(rin)
+        torch.cuda.synchronize()
+        if i:
+            hbm.append((time.time() - t0) * 1e3)
+    stage = [model.launch_ms(ws) for ws in pk.stage_ws]
+    return {'host_dict_to_host_dict': round(statistics.median(host), 3), 'hbm_to_hbm': round(statistics.median(hbm), 3), 'stage_kernel': [round(x, 3) for x in stage],
+            'sequences_per_sec_one_in_flight': round(1e3 / statistics.median(host), 1), 'reps': reps,
+            'note': 'one 300-frame 1-person sequence alone on the GPU (the reference calls optimize() per sequence); `value` is the batched rate'}
 
 
 def small_collective_latency(dev, world):
@@ -327,26 +370,28 @@ def run(argv=None):
                     _, pk = model.optimize_resident(rin)
                 step_graphs.append((g, pk))
             sync()
-            # self-check: the replay must reproduce a plain step bit for bit (same seed for the sampled latents)
-            torch.manual_seed(20260926)
-            with torch.cuda.stream(streams[0]):
-                _, ref = model.optimize_resident(rin)
-            sync()
-            want = ref.t['kp_2d_pred'].clone()
-            torch.manual_seed(20260926)
-            with torch.cuda.stream(streams[0]):
-                step_graphs[0][0].replay()
-            sync()
-            got = step_graphs[0][1].t['kp_2d_pred']
-            if not (bool(torch.isfinite(got).all()) and torch.equal(got, want)):
-                raise RuntimeError('the replayed step does not reproduce the plain one (max |diff| %.3g)' % float((got - want).abs().max()))
+            # self-check: EVERY stream's replay must reproduce a plain step bit for bit (same seed for the sampled latents)
+            for si, st in enumerate(streams):
+                torch.manual_seed(20260926)
+                with torch.cuda.stream(st):
+                    _, ref = model.optimize_resident(rin)
+                sync()
+                want = ref.t['kp_2d_pred'].clone()
+                torch.manual_seed(20260926)
+                with torch.cuda.stream(st):
+                    step_graphs[si][0].replay()
+                sync()
+                got = step_graphs[si][1].t['kp_2d_pred']
+                if not (bool(torch.isfinite(got).all()) and torch.equal(got, want)):
+                    raise RuntimeError('the replayed step of stream %d does not reproduce the plain one (max |diff| %.3g)' % (si, float((got - want).abs().max())))
             eager_step = step
 
             def step(i=0):
                 g, pk = step_graphs[i % len(step_graphs)]
                 with torch.cuda.stream(streams[i % len(streams)]):
                     g.replay()
-                stage_events.append(pk.stage_ws)
+                # (no per-launch stamps here: a replay rewrites the ONE workspace its graph was captured with, so the stamps of all but
+                # the last replay are gone by the time the clock stops -- the roofline launches are measured right after, see below)
         except Exception as e:      # noqa: BLE001 -- anything: the plain launches are always available
             sys.stderr.write('bench: step graph not used (%s); plain launches\n' % e)
             step_graphs = None
@@ -382,11 +427,11 @@ def run(argv=None):
     # one entry per optimiser-stage launch in the timed region: the kernel's own clock (earliest workgroup start to latest workgroup
     # end, what rocprofv3 reports for the dispatch) -- HIP events around the launch would also count the time it waits behind the
     # other stream
-    kms_timed = [model.launch_ms(ws) for wss in stage_events for ws in wss]
+    kms_timed = [model.launch_ms(ws) for wss in stage_events for ws in wss] if not step_graphs else None
     # With more than one stream the stage launches of consecutive batches share the CUs, so a launch's span says nothing about the
     # kernel: the roofline figure comes from launches that have the GPU to themselves -- the timed ones when --streams 1, otherwise
     # two extra single-stream steps right after the timed region.
-    if len(streams) == 1:
+    if len(streams) == 1 and kms_timed:
         kms = kms_timed
     else:
         kms = []
@@ -407,6 +452,7 @@ def run(argv=None):
         n_out = sum(len(r) for r in model.optimize_stream([in_dicts] * nb))
         host_stream = n_out / (time.time() - t0)
     coll_us = small_collective_latency(dev, world) if world > 1 else None
+    latency = one_sequence_latency(model, in_dicts[0]) if (rank == 0 and not args.stub_model and hasattr(model, 'optimize')) else None
 
     out = None
     if rank == 0:
@@ -417,35 +463,50 @@ def run(argv=None):
         us_scene_iter = k_avg * 1e3 / iters / rounds
         algo_bytes = B * iters * ALGO_BYTES_PER_PERSON_ITER
         achieved = algo_bytes / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
-        traffic, traffic_src = None, 'profiles/r02_pmc_stage_kernel.json not found'
-        if os.path.exists(PMC_FILE):
-            pmc = json.load(open(PMC_FILE))
-            traffic = pmc['bytes_per_scene_iteration'] * B * iters
-            traffic_src = pmc['source']
+        traffic, traffic_src, issue_util, over_compulsory, bytes_si = None, 'no profiles/rNN_pmc_stage_kernel.json', None, None, None
+        pf = pmc_file()
+        if pf:
+            pmc = json.load(open(pf))
+            bytes_si = pmc['bytes_per_scene_iteration']
+            traffic = bytes_si * B * iters
+            traffic_src = os.path.relpath(pf, ROOT) + ': ' + pmc['source']
+            # compulsory = the live state of a scene read or written ONCE per launch, per iteration
+            over_compulsory = bytes_si / (ALGO_BYTES_PER_PERSON_ITER / float(iters))
+            sq = pmc.get('counters', {}).get('sq', {})
+            if 'SQ_ACTIVE_INST_ANY' in sq and 'SQ_WAVE_CYCLES' in sq:
+                # five waves of a 300-frame scene on the four SIMDs of its CU: issue slots available = 4/5 of the summed wave cycles
+                issue_util = sq['SQ_ACTIVE_INST_ANY']['mean'] / (0.8 * sq['SQ_WAVE_CYCLES']['mean'])
         out = {
             'metric': 'sequences/sec (300-frame, 1-person) end-to-end global_recon', 'value': n_total * args.steps / elapsed,
             'unit': 'sequences/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.mode, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'host_enqueue_ms_per_step': enqueue / args.steps * 1e3,
             'config': {'workload': ('BASELINE configs[1]: %d-frame 1-person dynamic-camera sequences, cfg %s (%d Adam iterations), batch of %d independent '
-                                    'sequences per GPU, HybrIK arrays resident in HBM' % (NUM_FRAMES, CFG_ID, iters, B)) if args.mode == 'weak' else
+                                    'sequences per GPU, HybrIK arrays resident in HBM%s' % (NUM_FRAMES, CFG_ID, iters, B, '; the step is replayed as one captured HIP graph per stream (bit-checked against plain launches)' if step_graphs else '')) if args.mode == 'weak' else
                                    ('BASELINE configs[2]: %d independent %d-frame 1-person sequences (cfg %s, %d iterations) split over %d GPU(s): %d per GPU '
                                     '= %d of %d CUs busy in the optimiser stage' % (args.total, NUM_FRAMES, CFG_ID, iters, world, B, min(B, n_cus), n_cus)),
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
                        'streams_per_gpu': len(streams), 'step_graph': bool(step_graphs)},
-            'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'hbm', 'real_bound': 'latency / issue (one workgroup per scene, state on chip)',
+            'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'latency/issue',
+                         'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration: neither HBM nor the matrix pipes limit it; the '
+                                       "contract's hbm line (achieved / peak / frac) is kept below and is NOTIONAL",
+                         'contract_bound': 'hbm',
                          'us_per_scene_iteration': us_scene_iter, 'dependent_boundary_floor_us': DEPENDENT_BOUNDARY_US,
                          'times_above_floor': us_scene_iter / DEPENDENT_BOUNDARY_US,
+                         'issue_slot_utilisation': issue_util, 'traffic_over_compulsory': over_compulsory, 'traffic_bytes_per_scene_iteration': bytes_si,
+                         'compulsory_bytes_per_scene_iteration': ALGO_BYTES_PER_PERSON_ITER / float(iters),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'frac_is_notional': True,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'traffic_gbs': None if traffic is None or k_avg <= 0 else traffic / (k_avg * 1e-3) / 1e9,
                          'avg_launch_ms': k_avg, 'scenes_per_launch': B, 'iterations_per_launch': iters, 'rounds_per_launch': rounds,
-                         'launch_ms_each': [round(x, 2) for x in kms], 'launch_ms_in_timed_region': [round(x, 2) for x in kms_timed],
-                         'measured': ('the launches of the timed region (one stream)' if len(streams) == 1 else
-                                      '2 single-stream steps right after the timed region: in the timed region the launches of the %d streams '
-                                      'share the CUs' % len(streams)),
+                         'launch_ms_each': [round(x, 2) for x in kms],
+                         'launch_ms_in_timed_region': None if kms_timed is None else [round(x, 2) for x in kms_timed],
+                         'measured': ('the launches of the timed region (one stream)' if kms is kms_timed else
+                                      '2 single-stream plain steps right after the timed region: in the timed region the launches of the %d stream(s) '
+                                      'share the CUs%s' % (len(streams), ' and are graph replays (one workspace per graph: no per-replay stamps)' if step_graphs else '')),
                          'note': 'achieved / frac = %d B per person-iteration (SURVEY.md 8d K5 live state) x %d scenes x %d iterations / launch time: bytes the '
                                  'kernel keeps in LDS and does not move -- notional.  traffic = memory-side bytes (PMC).' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},
+            'latency_one_sequence_ms': latency,
             'host_inclusive_sequences_per_sec': host_stream if host_stream is not None else B / host_single,
             'host_inclusive_single_call_sequences_per_sec': B / host_single,
             'host_inclusive_stage_seconds': {k: round(v, 4) for k, v in tm.items()},

@@ -12,6 +12,7 @@
 #include <set>
 #include <mutex>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 namespace glamr {
@@ -79,6 +80,17 @@ extern "C" int glamr_grecon_param_layout(int max_persons, int max_len, glamr_par
 // workspace header: the launch's clock stamps
 constexpr size_t GLAMR_GRECON_WS_HEADER = 256;
 
+namespace {
+// stream of the last stage launch per workspace: glamr_grecon_last_launch_ns reads the stamps ON that stream (it waits for that stream's
+// work only, not for the device)
+std::mutex g_ws_mu;
+std::map<const void*, hipStream_t> g_ws_stream;
+int current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+}  // namespace
+
 extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len) {
   if (n_scenes <= 0 || max_persons < 1 || max_persons > 8 || max_len < 2) return 0;
   return GLAMR_GRECON_WS_HEADER + (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, layout_frames(max_persons, max_len)), 64) * sizeof(float);
@@ -143,9 +155,13 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // Occupancy: a workgroup's waves hold 256 registers each, so a CU (4 SIMDs x 512 registers) takes 8 / waves workgroups -- if their arenas fit its
   // 160 KB together.  When the batch has more scenes than the chip has CUs, the arena is capped at that share (the keypoint table
   // overflows into the workspace): 1024 scenes of 256 frames 40.1 -> 27.5 ms per 500 iterations.  A 300-frame scene has 5 waves: one per CU.
-  static const int n_cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  const int devid_launch = current_device();
+  const int n_cus = [devid_launch] {      // per device: a process may drive more than one GPU
+    static std::mutex cmu;
+    static std::map<int, int> cus;
+    std::lock_guard<std::mutex> lock(cmu);
+    int& n = cus[devid_launch];
+    if (n <= 0 && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, devid_launch) != hipSuccess || n <= 0)) n = 256;
     return n;
   }();
   const int wgs_per_cu = 4 * GLAMR_GRECON_WAVES_PER_EU / (threads / 64);
@@ -181,11 +197,11 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // SINGLE needs every scene of the batch to hold exactly one person: max_persons == 1 guarantees it
   const bool single = batch->max_persons == 1;
   auto launch = [&](auto kern, size_t lds) -> int {
-    if (lds) {      // once per instance and process (a driver call per launch is host time on every step)
+    if (lds) {      // once per (device, instance) and process (a driver call per launch is host time on every step)
       static std::mutex amu;
-      static std::set<const void*> raised;
+      static std::set<std::pair<int, const void*>> raised;
       std::lock_guard<std::mutex> lock(amu);
-      if (raised.insert(reinterpret_cast<const void*>(kern)).second)
+      if (raised.insert(std::make_pair(devid_launch, reinterpret_cast<const void*>(kern))).second)
         GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     }
     hipLaunchKernelGGL(kern, dim3(batch->n_scenes), dim3(threads), lds, stream, ka);
@@ -210,6 +226,11 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     rc = launch(grecon_stage_kernel<0, false, 0>, 0);
   if (rc) return rc;
   GLAMR_HIP_CHECK(hipGetLastError());
+  {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    if (g_ws_stream.size() > 4096) g_ws_stream.clear();      // callers that never ask for the stamps
+    g_ws_stream[workspace] = stream;
+  }
   return GLAMR_OK;
 }
 
@@ -243,9 +264,22 @@ extern "C" int glamr_debug_phase_ticks(unsigned long long* out16) {
 extern "C" int glamr_grecon_last_launch_ns(const void* workspace, double* ns) {
   GLAMR_REQUIRE(workspace && ns, "null argument");
   unsigned long long st[2];
-  // stage launches run on the caller's (non-blocking) streams, which the null stream's copy below does not wait for
-  GLAMR_HIP_CHECK(hipDeviceSynchronize());
-  GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));
+  // the stamps are read on the stream the launch ran on: this waits for the work of THAT stream, not for the device (a pipelined caller
+  // keeps its other streams running).  A workspace this library has not seen a launch on falls back to a device-wide wait.
+  hipStream_t stream = nullptr;
+  bool known = false;
+  {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    auto it = g_ws_stream.find(workspace);
+    if (it != g_ws_stream.end()) { stream = it->second; known = true; }
+  }
+  if (known && hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
+    // done
+  } else {
+    (void)hipGetLastError();                       // e.g. the stream has been destroyed since
+    GLAMR_HIP_CHECK(hipDeviceSynchronize());
+    GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));
+  }
   GLAMR_REQUIRE(st[0] != ~0ull, "no stage launch has completed on this workspace");
   *ns = st[1] > st[0] ? (double)(st[1] - st[0]) * 10.0 : 0.0;
   return GLAMR_OK;

@@ -11,7 +11,7 @@
 namespace {
 
 struct PersonDesc {      // one row of the int64 table the caller passes (glamr_hip.h)
-  int64_t exist, exist_is_f64, n_frames, n_det, rot, betas, trans, K, kp;
+  int64_t exist, exist_is_f64, n_frames, n_det, rot, betas, trans, K, kp, kp_stride;      // kp_stride: floats per detection row of kp_2d (2 x its keypoints, >= 48)
 };
 
 inline bool detected(const PersonDesc& d, int t) {
@@ -48,7 +48,8 @@ int scatter_one(const PersonDesc& d, int k, int T, const glamr_host_staging& h, 
     std::memcpy(h.betas + row * 10, betas + (size_t)det * 10, n * 10 * sizeof(float));
     std::memcpy(h.trans + row * 3, trans + (size_t)det * 3, n * 3 * sizeof(float));
     std::memcpy(h.K + row * 9, K + (size_t)det * 9, n * 9 * sizeof(float));
-    for (size_t i = 0; i < n; ++i) std::memcpy(h.kp + (row + i) * 48, kp + ((size_t)det + i) * 58, 48 * sizeof(float));      // 24 of 29 keypoints
+    const size_t ks = (size_t)d.kp_stride;
+    for (size_t i = 0; i < n; ++i) std::memcpy(h.kp + (row + i) * 48, kp + ((size_t)det + i) * ks, 48 * sizeof(float));      // the first 24 keypoints (29 from HybrIK)
     det += (int)n;
     t = e;
   }
@@ -69,6 +70,7 @@ extern "C" int glamr_host_scatter(int n_persons, const int64_t* table, int max_l
     if (!desc[k].exist) continue;                      // empty person slot (a scene with fewer persons than the batch maximum)
     GLAMR_REQUIRE(desc[k].n_frames >= 1 && desc[k].n_frames <= max_len, "person %d: %lld frames do not fit max_len=%d", k, (long long)desc[k].n_frames, max_len);
     GLAMR_REQUIRE(desc[k].rot && desc[k].betas && desc[k].trans && desc[k].K && desc[k].kp, "person %d: a source array is NULL", k);
+    GLAMR_REQUIRE(desc[k].kp_stride >= 48, "person %d: kp_2d rows hold %lld values, at least 24 keypoints x 2 are needed", k, (long long)desc[k].kp_stride);
   }
   const int nthr = std::max(1, std::min(threads, n_persons / 32 + 1));
   std::vector<int> status((size_t)std::max(n_persons, 1), 0);

@@ -142,10 +142,17 @@ struct glamr_nets {
     int v[5]; const void* p[9];
     bool operator<(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) < 0; }
   };
-  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
-  std::map<GraphKey, GraphEntry> graphs;
+  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; uint64_t last_use = 0; };
+  std::map<GraphKey, GraphEntry> graphs;          // at most GRAPH_CACHE_MAX entries, least recently used evicted (its executable destroyed)
+  uint64_t graph_clock = 0;
   std::mutex graph_mu;
+  // length tables of calls recorded into a CALLER's capture: carved from one pinned slab the handle owns (allocated at creation -- a
+  // capturing thread must not allocate -- and alive until glamr_nets_destroy), so the copy node of the caller's graph has a source that
+  // outlives the call
+  int32_t* capture_lens = nullptr;
+  size_t capture_lens_used = 0;
 };
+constexpr size_t GRAPH_CACHE_MAX = 24, CAPTURE_LENS_INTS = 256 * 1024;
 
 namespace {
 
@@ -536,6 +543,7 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
   }
   RC(upload_t(&h->rest_joints, fk_rest_joints, (size_t)72));
   RC(upload_t(&h->parents, parents, (size_t)24));
+  GLAMR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->capture_lens), CAPTURE_LENS_INTS * sizeof(int32_t), hipHostMallocDefault));
   tl_allocs = nullptr;
   *out = h;
   return GLAMR_OK;
@@ -547,6 +555,8 @@ extern "C" int glamr_nets_destroy(glamr_nets* h) {
     std::lock_guard<std::mutex> lock(h->graph_mu);
     for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     h->graphs.clear();
+    if (h->capture_lens) (void)hipHostFree(h->capture_lens);
+    h->capture_lens = nullptr;
   }
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
@@ -883,12 +893,22 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   GLAMR_REQUIRE(!do_infill || n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   Ws w = ws_layout(B, max_len, static_cast<char*>(workspace));
-  // A caller that is CAPTURING this stream (its whole step as one graph) gets the plain launch sequence recorded into its graph; the
-  // host->device copy of the lengths is left out of it (its source is a temporary of this call): the caller replays a call that already
-  // ran once on these buffers, so the lengths are in place.
+  // A caller that is CAPTURING this stream (its whole step as one graph) gets the plain launch sequence recorded into its graph,
+  // INCLUDING the upload of the lengths: they are copied to a pinned table the handle owns (alive until glamr_nets_destroy), and the
+  // copy node reads that table at every replay -- the caller's graph is self-contained whatever workspace it was captured with.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool outer_capture = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
-  if (!outer_capture) GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  const int32_t* lens_src = lens_host;
+  if (outer_capture) {
+    std::lock_guard<std::mutex> lock(h->graph_mu);
+    GLAMR_REQUIRE(h->capture_lens && h->capture_lens_used + (size_t)B <= CAPTURE_LENS_INTS,
+                  "the handle's table for calls recorded into caller graphs is full (%zu lengths); destroy and re-create the handle", CAPTURE_LENS_INTS);
+    int32_t* pinned = h->capture_lens + h->capture_lens_used;
+    h->capture_lens_used += (size_t)B;
+    std::memcpy(pinned, lens_host, (size_t)B * sizeof(int32_t));
+    lens_src = pinned;
+  }
+  GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_src, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   auto enqueue = [&]() -> int {
     return enqueue_infer(h, st, w, B, max_len, n_win, n_win_max, do_infill, do_traj, body_pose, visible, motion_eps, traj_eps, out_pose, out_local_traj, out_trans,
                          out_orient);
@@ -905,9 +925,21 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
     for (int i = 0; i < 9; ++i) key.p[i] = ptrs[i];
     std::lock_guard<std::mutex> lock(h->graph_mu);
     auto it = h->graphs.find(key);
-    if (it == h->graphs.end() && h->graphs.size() < 24) it = h->graphs.emplace(key, glamr_nets::GraphEntry()).first;
-    if (it != h->graphs.end()) {
+    if (it == h->graphs.end()) {
+      if (h->graphs.size() >= GRAPH_CACHE_MAX) {          // evict the least recently used geometry; its executable goes with it
+        auto old = h->graphs.begin();
+        for (auto jt = h->graphs.begin(); jt != h->graphs.end(); ++jt) if (jt->second.last_use < old->second.last_use) old = jt;
+        if (old->second.exec) {
+          (void)hipDeviceSynchronize();                    // a launch of it may still be in flight; evictions are rare (a 25th geometry)
+          (void)hipGraphExecDestroy(old->second.exec);
+        }
+        h->graphs.erase(old);
+      }
+      it = h->graphs.emplace(key, glamr_nets::GraphEntry()).first;
+    }
+    {
       glamr_nets::GraphEntry& e = it->second;
+      e.last_use = ++h->graph_clock;
       if (e.exec) {
         GLAMR_HIP_CHECK(hipGraphLaunch(e.exec, st));
         return GLAMR_OK;
@@ -924,12 +956,12 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
           if (std::getenv("GLAMR_DEBUG_GRAPH")) std::fprintf(stderr, "graph capture: rc=%d in-capture error=%s end=%s B=%d max_len=%d flags=%d\n", rc, hipGetErrorString(e_in), hipGetErrorString(ec), B, max_len, flags);
           hipGraphExec_t exec = nullptr;
           if (rc == GLAMR_OK && ec == hipSuccess && g && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess) {
-            hipGraphDestroy(g);
+            (void)hipGraphDestroy(g);
             e.exec = exec;
             GLAMR_HIP_CHECK(hipGraphLaunch(e.exec, st));
             return GLAMR_OK;
           }
-          if (g) hipGraphDestroy(g);
+          if (g) (void)hipGraphDestroy(g);
           (void)hipGetLastError();                 // capture failed: nothing was launched; run the plain sequence below and never retry this key
         }
       }

@@ -396,7 +396,7 @@ class GlobalReconOptimizer:
     def _scatter_inputs(self, in_dicts, ids, P, h):
         """Per-detection HybrIK arrays -> their frame rows in the staging arrays `h` (numpy views): glamr_host_scatter, a few host threads
         doing block copies without the GIL (numpy on one thread took 60-130 ms per 1024 sequences depending on the box, a Python thread
-        pool was slower still).  This loop only collects the nine numbers per person the library needs.  Returns (seq_len per slot,
+        pool was slower still).  This loop only collects the ten numbers per person the library needs.  Returns (seq_len per slot,
         length of the existing range per slot, {(sequence, person id): exist array})."""
         import ctypes
         n_slots = len(in_dicts) * P
@@ -404,7 +404,7 @@ class GlobalReconOptimizer:
         seq_len_slot = np.zeros(n_slots, np.int32)
         lens = np.full(n_slots, 11, np.int32)
         exists = {}
-        table = np.zeros((n_slots, 9), np.int64)
+        table = np.zeros((n_slots, 10), np.int64)
         keep = []                                                  # converted copies must outlive the call
         f32, f64 = np.dtype(np.float32), np.dtype(np.float64)
 
@@ -426,8 +426,9 @@ class GlobalReconOptimizer:
                     exa = np.ascontiguousarray(exa, dtype=np.float64)
                     keep.append(exa)
                 nv = len(src['smpl_beta'])
+                kpw = 2 * int(np.shape(src['kp_2d'])[1])               # floats per detection row: HybrIK writes 29 keypoints, the wire format asks for >= 24
                 table[si * P + pi] = (exa.__array_interface__['data'][0], exa.dtype == f64, exa.shape[0], nv, addr(src['smpl_pose_quat_wroot'], 216),
-                                      addr(src['smpl_beta'], 10), addr(src['root_trans'], 3), addr(src['cam_K'], 9), addr(src['kp_2d'], 58))
+                                      addr(src['smpl_beta'], 10), addr(src['root_trans'], 3), addr(src['cam_K'], 9), addr(src['kp_2d'], kpw), kpw)
         # (rows left at zero = the empty person slots of scenes with fewer persons than the batch maximum: seq_len 0, nothing copied)
         stg = _lib.HostStaging(*[ctypes.c_void_p(h[k].ctypes.data) for k in ('exist', 'rot', 'betas', 'trans', 'K', 'kp')])
         _lib.check(_lib.lib().glamr_host_scatter(n_slots, ctypes.c_void_p(table.ctypes.data), T, ctypes.byref(stg), ctypes.c_void_p(seq_len_slot.ctypes.data),

@@ -58,22 +58,34 @@ class MotionPriorsHandle:
             torch.cuda.synchronize(self.device)
             _lib.lib().glamr_nets_destroy(h)
 
+    RESIDENT_GEOMETRIES = 3          # per stream
+
     def resident_set(self, B, T, n_win):
         """Persistent buffers for the batched pipeline (GlobalReconOptimizer.init_resident): inputs, outputs and workspace of one
         glamr_nets_infer call at FIXED addresses, one set per HIP stream and batch geometry.  The set is only ever reused by a later call on
         the SAME stream, after everything that consumed it was enqueued there, so stream order keeps it safe; fixed addresses are what
-        lets the library replay the call's ~450 launches as one captured HIP graph."""
+        lets the library replay the call's ~450 launches as one captured HIP graph.  At most RESIDENT_GEOMETRIES sets per stream are kept
+        (least recently used dropped: a dataset of videos of many lengths must not grow device memory without bound); a set tells the
+        library to capture (`persistent`) only from its SECOND use on -- a geometry seen once never pays capture + instantiation."""
         L = _lib.lib()
         sid = torch.cuda.current_stream(self.device).cuda_stream
         ring = self.__dict__.setdefault('_ring', {})
-        slot = ring.setdefault((sid, B, T, n_win), {'sets': [None]})
-        i = 0
-        if slot['sets'][i] is None:
+        per_stream = ring.setdefault(sid, {})          # insertion order = recency
+        key = (B, T, n_win)
+        cur = per_stream.pop(key, None)
+        if cur is None:
+            while len(per_stream) >= self.RESIDENT_GEOMETRIES:
+                # work that still reads the dropped set is already enqueued on this stream; the caching allocator hands the blocks to later
+                # allocations of the same stream only, which run after it
+                per_stream.pop(next(iter(per_stream)))
             f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
-            slot['sets'][i] = dict(nets_pose=f32(B, T, 69), nets_vis=f32(B, T), meps=f32(B, n_win, NZ), teps=f32(B, NZ), pose=f32(B, T, 69),
-                                   local_traj=f32(B, T, 11), trans=f32(B, T, 3), orient=f32(B, T, 3),
-                                   ws=torch.empty(L.glamr_nets_workspace_bytes(self.h, B, T), dtype=torch.uint8, device=self.device))
-        return slot['sets'][i]
+            cur = dict(nets_pose=f32(B, T, 69), nets_vis=f32(B, T), meps=f32(B, n_win, NZ), teps=f32(B, NZ), pose=f32(B, T, 69),
+                       local_traj=f32(B, T, 11), trans=f32(B, T, 3), orient=f32(B, T, 3),
+                       ws=torch.empty(L.glamr_nets_workspace_bytes(self.h, B, T), dtype=torch.uint8, device=self.device), uses=0)
+        cur['uses'] += 1
+        cur['persistent'] = cur['uses'] >= 2
+        per_stream[key] = cur
+        return cur
 
     def infer(self, body_pose, visible, lens, motion_eps=None, traj_eps=None, infill=True, traj=True, buffers=None):
         """body_pose (B,T,69) fp32 device, visible (B,T) 1/0, lens list[int].  Returns dict of device tensors.  `buffers`: a
@@ -84,7 +96,7 @@ class MotionPriorsHandle:
         body_pose = body_pose.float().contiguous()
         lens_np = np.ascontiguousarray(lens, dtype=np.int32)
         out = {}
-        flags = (NETS_INFILL if infill else 0) | (NETS_TRAJ if traj else 0) | (NETS_PERSISTENT if buffers is not None else 0)
+        flags = (NETS_INFILL if infill else 0) | (NETS_TRAJ if traj else 0) | (NETS_PERSISTENT if buffers is not None and buffers.get('persistent', True) else 0)
         n_win_max = 0
         new = (lambda name, *shape: buffers[name]) if buffers is not None else (lambda name, *shape: torch.empty(shape, device=dev))
         if infill:

@@ -100,7 +100,11 @@ size_t glamr_nets_workspace_bytes(const glamr_nets* h, int n_seq, int max_len);
 #define GLAMR_NETS_TRAJ 2     /* run the trajectory predictor on the (infilled) body pose (TrajPredVAE.inference) */
 #define GLAMR_NETS_PERSISTENT 4   /* the caller promises that every buffer of this call (inputs, outputs, workspace) keeps its address and is
                                      only reused on this stream: the ~450 launches are captured as a HIP graph at the first call and replayed
-                                     afterwards (without the flag: captured when the identical call is seen a second time) */
+                                     afterwards (without the flag: captured when the identical call is seen a second time).  The handle
+                                     keeps at most 24 such graphs; the least recently used one is destroyed when a 25th geometry arrives */
+/* Under a CALLER's stream capture (the whole step as one graph) the call records its plain launch sequence into that graph, the upload of
+ * `lens` included: the lengths are copied into a pinned table owned by the handle (alive until glamr_nets_destroy; room for 262 144
+ * lengths over the handle's lifetime, GLAMR_E_INVALID beyond), so the caller's graph carries its own lengths whatever workspace it uses. */
 int glamr_nets_infer(glamr_nets* h, int n_seq, int max_len, const int32_t* lens, const float* body_pose,
                      const float* visible, const float* motion_eps, int n_win_max, const float* traj_eps,
                      float* out_pose, float* out_local_traj, float* out_trans, float* out_orient,
@@ -253,7 +257,7 @@ int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_des
                            void* workspace, void* stream);
 /* Duration of the last glamr_grecon_run_stage that used `workspace`, from the kernel's own clock (earliest workgroup start to latest
  * workgroup end, 10 ns resolution): what a profiler reports for the dispatch, also when other streams share the GPU.  Blocks until
- * that launch has finished. */
+ * the work enqueued so far on THAT launch's stream has finished -- other streams keep running (no device-wide wait). */
 int glamr_grecon_last_launch_ns(const void* workspace, double* ns);
 
 /* One torch.optim.Adam step (betas 0.9 / 0.999, eps 1e-8, no weight decay; torch/optim/adam.py _single_tensor_adam, the path
@@ -291,10 +295,11 @@ typedef struct glamr_person_arrays {     /* per-person state that is not an inpu
 
 /* Host-side scatter of the HybrIK wire format (one array row per DETECTED frame, demo.py:317-354) into the frame-indexed staging arrays
  * whose device copies glamr_raw_batch points at -- what the reference does person by person with fancy indexing inside init_data
- * (global_recon_model.py:98-136).  All pointers are HOST pointers.  `table` has one row of nine int64 per person slot:
+ * (global_recon_model.py:98-136).  All pointers are HOST pointers.  `table` has one row of TEN int64 per person slot:
  *   exist (address of bboxes_dict['exist']), exist_is_f64 (1: float64 as the reference stores it, 0: float32), n_frames, n_det (rows of
  *   the per-detection arrays), then the addresses of smpl_pose_quat_wroot (n_det,216), smpl_beta (n_det,10), root_trans (n_det,3),
- *   cam_K (n_det,9), kp_2d (n_det,29,2) -- float32, C-contiguous.
+ *   cam_K (n_det,9), kp_2d (n_det,n_kp,2) -- float32, C-contiguous -- and kp_stride = 2 n_kp, the floats per row of kp_2d (HybrIK: 58;
+ *   at least 48: the first 24 keypoints are taken).
  * A row whose `exist` address is 0 is an empty person slot (seq_len 0, nothing copied).
  * Rows of undetected frames are left untouched (the device code never reads them); seq_len[k] = n_frames, exist_len[k] = last - first
  * + 1 detected frame.  Persons are split over `threads` host threads.  Errors: a person without detections, or whose exist array marks a

@@ -16,7 +16,7 @@ Multi-Person Linear Model", SIGGRAPH Asia 2015, eqs. 2-10, as implemented by the
 
 Parity status: *unpinned* -- there is no smplx golden vector anywhere under /root/reference.
 The restatement is anchored on the reference's own call sites and on closed-form identities checked in
-tests/test_oracle_smplx.py (rest pose returns the template; a pure root rotation rotates the mesh rigidly;
+tests/test_oracle_golden.py::test_smplx_closed_form_identities (rest pose returns the template; a pure root rotation rotates the mesh rigidly;
 the posed joints equal the forward-kinematics chain).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.

@@ -116,19 +116,20 @@ def test_host_scatter_matches_numpy_indexing():
     rng = np.random.RandomState(0)
     T = 40
 
-    def person(exist, dtype=np.float64, strided=False):
+    def person(exist, dtype=np.float64, strided=False, n_kp=29):
         nv = int((exist != 0).sum())
         mk = lambda *shape: rng.rand(*shape).astype(np.float32)
         rot = mk(nv, 54, 4)
         if strided:
             rot = np.asfortranarray(rot)
         return {'bboxes_dict': {'exist': exist.astype(dtype)}, 'smpl_pose_quat_wroot': rot, 'smpl_beta': mk(nv, 10), 'root_trans': mk(nv, 3),
-                'cam_K': mk(nv, 3, 3), 'kp_2d': mk(nv, 29, 2)}
+                'cam_K': mk(nv, 3, 3), 'kp_2d': mk(nv, n_kp, 2)}
     e0 = np.ones(T)
     e1 = np.ones(T); e1[5:9] = 0; e1[20:31] = 0
     e2 = np.zeros(33); e2[7:30] = 1
     e3 = np.ones(T); e3[0] = 0; e3[-1] = 0
-    in_dicts = [{'est': {0: person(e0), 1: person(e1)}}, {'est': {4: person(e2, np.float32, strided=True)}}, {'est': {0: person(e3), 7: person(e0)}}]
+    # (the wire format takes any kp_2d with >= 24 keypoints, glamr_amd/utils/wire.py: 24 and 31 here beside HybrIK's 29)
+    in_dicts = [{'est': {0: person(e0), 1: person(e1, n_kp=24)}}, {'est': {4: person(e2, np.float32, strided=True)}}, {'est': {0: person(e3, n_kp=31), 7: person(e0)}}]
     ids = [list(d['est'].keys()) for d in in_dicts]
     P, n = 2, 6
     h = {'exist': np.full((n, T), -7, np.float32), 'rot': np.full((n, T, 216), -7, np.float32), 'betas': np.full((n, T, 10), -7, np.float32),

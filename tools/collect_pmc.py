@@ -2,12 +2,13 @@
 group per pass, kernel trace only -- the combination gpurun allows), plus a calibration of FETCH_SIZE / WRITE_SIZE on a kernel whose
 bytes are known and whose accesses are 4 bytes per lane like the stage kernel's (glamr_adam_step: reads 4 arrays, writes 3).
 
-    python tools/collect_pmc.py            # writes gpurun_out/r02_pmc_*.csv and gpurun_out/r02_pmc_stage_kernel.json
-Copy the json / csv into profiles/ (bench.py reads profiles/r02_pmc_stage_kernel.json)."""
+    python tools/collect_pmc.py            # writes gpurun_out/<tag>_pmc_*.csv and gpurun_out/<tag>_pmc_stage_kernel.json (tag: GLAMR_ROUND_TAG, default r03)
+Copy the json / csv into profiles/ (bench.py reads the newest profiles/rNN_pmc_stage_kernel.json)."""
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 KERNEL = 'grecon_stage_kernel<1, true, 1, 304>'
+TAG = os.environ.get('GLAMR_ROUND_TAG', 'r03')          # file prefix: profiles are named per round
 B, ITERS = 1024, 500
 
 
@@ -48,7 +49,7 @@ def main():
         for c, vals in k.items():
             res.setdefault(tag, {})[c] = {'launches': len(vals), 'mean': sum(vals) / max(1, len(vals)), 'min': min(vals), 'max': max(vals)}
             raw.append((tag, c, len(vals), sum(vals) / max(1, len(vals)), min(vals), max(vals)))
-    with open(os.path.join(OUT, 'r02_pmc_stage_kernel_counters.csv'), 'w') as f:
+    with open(os.path.join(OUT, TAG + '_pmc_stage_kernel_counters.csv'), 'w') as f:
         f.write('pass,counter,launches,mean_per_launch,min,max\n')
         for r in raw:
             f.write('%s,%s,%d,%.6g,%.6g,%.6g\n' % r)
@@ -69,7 +70,7 @@ def main():
         out['bytes_per_scene_iteration'] = (fk + wk) * 1024 / (B * ITERS)
     except KeyError:
         pass
-    json.dump(out, open(os.path.join(OUT, 'r02_pmc_stage_kernel.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(OUT, TAG + '_pmc_stage_kernel.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
 
@@ -98,12 +99,12 @@ def priors():
             short = name.split('(')[0].replace('void ', '').replace('glamr::nn::', '').replace('(anonymous namespace)::', '')
             a = agg.setdefault(short, {})
             a.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-    with open(os.path.join(OUT, 'r02_pmc_priors.csv'), 'w') as f:
+    with open(os.path.join(OUT, TAG + '_pmc_priors.csv'), 'w') as f:
         f.write('kernel,counter,dispatches,mean,sum\n')
         for k in sorted(agg):
             for cname, vals in sorted(agg[k].items()):
                 f.write('"%s",%s,%d,%.6g,%.6g\n' % (k, cname, len(vals), sum(vals) / len(vals), sum(vals)))
-    print(open(os.path.join(OUT, 'r02_pmc_priors.csv')).read())
+    print(open(os.path.join(OUT, TAG + '_pmc_priors.csv')).read())
 
 
 if __name__ == '__main__':
