@@ -243,11 +243,9 @@ def one_sequence_latency(model, in_dict, reps=5):
 
 def small_collective_latency(dev, world):
     """What the person-sharded variant of configs[3] would pay per iteration: an all-reduce of 9 floats + an all-gather of 4 x 300 x 12
-    floats over RCCL, measured on this job's ranks (only meaningful with --gpus > 1)."""
+    floats over RCCL, measured on this job's ranks (with one rank: the launch + completion cost of the two collectives, no link traffic)."""
     import torch
     import torch.distributed as dist
-    if world < 2:
-        return None
     g9 = torch.zeros(9, device=dev)
     own = torch.zeros(300 * 12, device=dev)
     allp = [torch.zeros(300 * 12, device=dev) for _ in range(world)]
@@ -297,6 +295,8 @@ def run(argv=None):
     ap.add_argument('--no-kernel-lines', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo with --stub-model for the CPU test of the skeleton)')
     ap.add_argument('--stub-model', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--force-dist', action='store_true', help='create the process group also at --gpus 1 (a world of one rank): runs the init / barrier / reduction / '
+                    'collective-latency code of the multi-GPU path on a single GPU (tests/test_e2e_gpu.py)')
     args = ap.parse_args(argv)
 
     import torch
@@ -311,8 +311,13 @@ def run(argv=None):
         torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank) if on_gpu else torch.device('cpu')
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -323,7 +328,7 @@ def run(argv=None):
     # synthetic model files are written ONCE: rank 0 creates them, everybody else waits at the barrier and then only reads
     if rank == 0:
         ensure_assets()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     asset_root = ensure_assets()
     model = _StubModel() if args.stub_model else build_model(asset_root, dev)
@@ -400,7 +405,7 @@ def run(argv=None):
             except Exception:      # noqa: BLE001
                 pass
     del stage_events[:]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     t0 = time.time()
@@ -408,7 +413,7 @@ def run(argv=None):
         step(i)
     enqueue = time.time() - t0                                       # host time to ENQUEUE the timed steps (launch-bound if close to `elapsed`)
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
@@ -420,7 +425,7 @@ def run(argv=None):
                                                                                                           'seeds_first_last': [int(seeds[0]), int(seeds[-1])]}}
         if rank == 0:
             print(json.dumps(out))
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return out if rank == 0 else None
 
@@ -451,7 +456,7 @@ def run(argv=None):
         t0 = time.time()
         n_out = sum(len(r) for r in model.optimize_stream([in_dicts] * nb))
         host_stream = n_out / (time.time() - t0)
-    coll_us = small_collective_latency(dev, world) if world > 1 else None
+    coll_us = small_collective_latency(dev, world) if use_dist else None
     latency = one_sequence_latency(model, in_dicts[0]) if (rank == 0 and not args.stub_model and hasattr(model, 'optimize')) else None
 
     out = None
@@ -520,7 +525,7 @@ def run(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(asset_root)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return out
 

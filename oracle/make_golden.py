@@ -385,8 +385,13 @@ def gen_full(which=('gap', 'nogap')):
         print('full reference optimize() [%s]: %.1f s on %d threads' % (name, dt, torch.get_num_threads()))
 
 
-FULL_CASES = [('glamr_static_multi', 300, 4), ('glamr_3dpw', 300, 1), ('glamr_dynamic_multi', 300, 2), ('glamr_static', 300, 1),
-              ('glamr_h36m', 300, 2)]
+# (cfg, frames, persons, seed).  Seeds: the first one (from 3) whose ESTIMATED initial solution keeps every joint in front of the camera
+# (|projection| < 3000 px after init_data).  The synthetic checkpoints are random-initialised, so the predicted trajectories wander and in
+# most seeds somebody walks through the camera plane of the estimate (projections of 1e6 px, gradients that are rounding noise): seed 3
+# with 4 persons is such a scene -- the reference's own 700-iteration result there is not reproducible to better than metres.
+FULL_CASES = [('glamr_3dpw', 300, 1, 4), ('glamr_dynamic_multi', 300, 2, 3), ('glamr_static_multi', 300, 4, 38), ('glamr_static', 300, 1, 4),
+              ('glamr_h36m', 300, 2, 4)]
+FULL_SEED = {(c, T, P): s for c, T, P, s in FULL_CASES}
 
 
 def full_name(cfg_id, T, P, gap=True):
@@ -404,10 +409,10 @@ def gen_full_cfg(cases=FULL_CASES, gaps=(True, False)):
     from oracle import ref_harness as rh
     from glamr_amd.utils import synth
     md = synth.make_smpl_model()
-    for cfg_id, T, P in cases:
+    for cfg_id, T, P, seed in cases:
         for gap in gaps:
             model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
-            in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md, gap=None if gap else (0, 0))
+            in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=md, gap=None if gap else (0, 0))
             snap = {}
             keep = model.optimize_main
             keys = PERSON_KEYS_OPT + ['smpl_pose', 'visible', 'vis_frames']
@@ -419,9 +424,10 @@ def gen_full_cfg(cases=FULL_CASES, gaps=(True, False)):
                 return r
             model.optimize_main = optimize_main
             t0 = time.time()
-            data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 3))
+            data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, seed))
             dt = time.time() - t0
             out = _flatten_state(data, keys, TOP_KEYS)
+            out['seed'] = np.array(seed)
             if len(cfg.opt_stage_specs) > 1:
                 out.update(snap)
             out['ref_seconds'] = np.array(dt)

@@ -180,3 +180,58 @@ KSTEP_TOL = {   # achieved (MI355X / CPU runtime):           kp px            ro
     ('glamr_h36m', 100, 2): (0.55, 2e-5, 9e-4),               # 0.074 / 0.177    2.4e-6 / 5.0e-6   2.8e-4 / 2.6e-4
     ('glamr_static_multi', 300, 4): (0.05, 6e-5, 1.1e-3),     # 0.012 / 0.015    1.2e-5 / 1.9e-5   3.5e-4 / 3.3e-4
 }
+
+
+def full_schedule_errors(out_persons, cam_pose, g, P, prefix=''):
+    """Differences between a finished optimisation and a full-schedule reference fixture (oracle/make_golden.py gen_full_cfg), over the
+    frames each person is seen in: (projected keypoints px, root-in-camera m, world root m, world orientation as a rotation, camera)."""
+    def root_cam(cam, trans):
+        return np.einsum('tij,tj->ti', cam[:, :3, :3], trans) + cam[:, :3, 3]
+    cam_ref = g[prefix + 'cam_pose']
+    worst = dict(kp=0.0, root_cam=0.0, root_world=0.0, orient=0.0, frames_over_1px=0)
+    for pi in range(P):
+        pd = out_persons[pi]
+        vis = g['%sp%d_vis_frames' % (prefix, pi)]
+        kp, ref = np.asarray(pd['kp_2d_pred'], np.float64)[vis], np.asarray(g['%sp%d_kp_2d_pred' % (prefix, pi)], np.float64)[vis]
+        ok = np.abs(ref).max(axis=-1) < 2.5e3                      # see kp_err: points near the camera plane say nothing
+        d = np.where(ok, np.abs(kp - ref).max(axis=-1), 0.0).max(axis=-1)      # per visible frame
+        worst['kp'] = max(worst['kp'], float(d.max()))
+        worst['frames_over_1px'] = max(worst['frames_over_1px'], int((d > 1).sum()))
+        tr, tr_ref = np.asarray(pd['root_trans_world']), g['%sp%d_root_trans_world' % (prefix, pi)]
+        worst['root_world'] = max(worst['root_world'], float(np.abs(tr - tr_ref)[vis].max()))
+        worst['root_cam'] = max(worst['root_cam'], float(np.abs(root_cam(np.asarray(cam_pose), tr) - root_cam(cam_ref, tr_ref))[vis].max()))
+        worst['orient'] = max(worst['orient'], _rot_err(np.asarray(pd['smpl_orient_world'])[vis], g['%sp%d_smpl_orient_world' % (prefix, pi)][vis]))
+    return worst
+
+
+# Full schedules vs the unmodified reference (tests/golden/full_<cfg>_T300_P<P>[_nogap].npz), starting from the reference's own initial
+# state (the oracle's / the numpy init_data): bounds = (keypoints px, root in camera m) ~3 x achieved, MI355X / CPU runtime in the comment
+FULL_TOL = {}
+
+
+def check_full_schedule(runner, asset_root, golden, cfg_id, T, P, gap):
+    """All stages to their last iteration on the runner (CPU runtime or device kernel) from the oracle's init_data state."""
+    run, dev = runner
+    g = golden(mg.full_name(cfg_id, T, P, gap))
+    cfg = get_config(cfg_id)
+    specs = cfg['grecon_model_specs']
+    seed = mg.FULL_SEED[(cfg_id, T, P)]
+    assert int(g['seed']) == seed
+    in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model(), gap=None if gap else (0, 0))
+    ora = build.load_optimizer(asset_root, cfg)
+    data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, seed))
+    jl = j_local_from_oracle(ora.smpl, data)
+    has_wd = False
+    report = []
+    for si, (stage, spec) in enumerate(cfg['opt_stage_specs'].items()):
+        packed = packing.PackedScenes([data], [jl], dev)
+        run(packed, packing.stage_desc(spec, specs, has_wd), False)
+        packed.unpack_into([data], spec, specs)
+        has_wd = has_wd or 'world_dheading' in spec['opt_variables']
+        last = si == len(cfg['opt_stage_specs']) - 1
+        if last or 's1_cam_pose' in g:
+            persons = {pi: {k: v.numpy() if hasattr(v, 'numpy') else v for k, v in data['person_data'][pi].items() if k in ('kp_2d_pred', 'root_trans_world', 'smpl_orient_world')}
+                       for pi in range(P)}
+            cam = data['cam_pose'].numpy() if hasattr(data['cam_pose'], 'numpy') else data['cam_pose']
+            report.append((stage, full_schedule_errors(persons, cam, g, P, '' if last else 's1_')))
+    return report

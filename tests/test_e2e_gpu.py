@@ -426,3 +426,24 @@ def test_bench_step_graph_reproduces_the_plain_step():
     assert out['value'] > 0 and out['steps'] == 2
     plain = bench.run(['--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--no-kernel-lines', '--no-graph-step'])
     assert plain['config']['step_graph'] is False
+
+
+def test_bench_runs_under_an_rccl_process_group_of_one_rank(monkeypatch):
+    """The multi-GPU launch of bench.py (`torch.distributed.run --nproc-per-node N`) on the one GPU this box has: a world of ONE rank over
+    the `nccl` backend (= RCCL) goes through everything the 8-GPU run will -- process-group init with the device id, the asset barrier,
+    the capture of the step graph while the group's watchdog thread is alive, the barriers around the timed region, the max / sum
+    reductions on device tensors and the small-collective latency probe -- so that run is not the first execution of that code."""
+    import socket
+    import bench
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    for k, v in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', str(port)), ('RANK', '0'), ('LOCAL_RANK', '0'), ('WORLD_SIZE', '1')):
+        monkeypatch.setenv(k, v)
+    out = bench.run(['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--no-kernel-lines', '--force-dist'])
+    assert out['n_gpus'] == 1 and out['value'] > 0 and out['config']['step_graph'] is True
+    coll = out['collective_alternative']
+    assert coll['ranks'] == 1 and 0 < coll['us_per_iteration_allreduce9_plus_allgather_4x300x12'] < 5e3
+    import torch.distributed as dist
+    assert not dist.is_initialized()          # the group is torn down again
