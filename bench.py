@@ -262,6 +262,53 @@ def small_collective_latency(dev, world):
     return (time.time() - t0) / n * 1e6
 
 
+def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8):
+    """BASELINE configs[3] both ways on this job's ranks (SURVEY 8e "measure both and report"): `iters` iterations of every stage of cfg
+    glamr_static_multi on `scenes` 4-person 300-frame scenes, (a) the default schedule -- one workgroup per scene, the shared camera's gradient
+    reduced on chip, every rank its own scenes -- and (b) the person-sharded schedule (glamr_amd/parallel.py PersonShardedSchedule): the persons
+    of each scene split over the ranks, per iteration 2 launches + an all-gather of the world poses + an all-reduce of the camera gradient over
+    RCCL + the Adam launch.  Needs a process group (--gpus > 1, or --force-dist for a world of one rank)."""
+    import torch
+    from glamr_amd import parallel
+    from glamr_amd.utils import synth
+    m4 = build_model(asset_root, dev, 'glamr_static_multi')
+    md = synth.make_smpl_model()
+    in_dicts = [synth.make_in_dict(seed=2000 + i, num_frames=NUM_FRAMES, num_persons=4, smpl_model=md) for i in range(scenes)]
+    rin = m4.stage_inputs(in_dicts)
+    n_stage_iters = sum(min(iters, s['opt_niters']) for s in m4.opt_stage_specs.values())
+
+    def fused():
+        _, packed = m4.init_resident(rin, init_forward=False)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        m4.run_schedule(packed, max_iters=iters)
+        torch.cuda.synchronize()
+        return time.time() - t0, packed
+
+    def sharded():
+        _, packed = m4.init_resident(rin, init_forward=False)
+        sched = parallel.PersonShardedSchedule()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        sched.run(packed, m4.opt_stage_specs, m4.specs, max_iters=iters)
+        torch.cuda.synchronize()
+        return time.time() - t0, packed, sched
+    fused()
+    t_f, pk_f = fused()
+    sharded()
+    t_s, pk_s, sched = sharded()
+    diff = float((pk_f.t['kp_2d_pred'] - pk_s.t['kp_2d_pred']).abs().median())
+    return {'workload': 'cfg glamr_static_multi, %d scenes of 4 persons x %d frames, %d iterations per stage (%d in all)' % (scenes, NUM_FRAMES, iters, n_stage_iters),
+            'ranks': world, 'persons_per_rank': len(sched.owned(4)),
+            'in_kernel_reduction_us_per_iteration': t_f / n_stage_iters * 1e6,
+            'person_sharded_us_per_iteration': t_s / n_stage_iters * 1e6,
+            'person_sharded_collective_host_us_per_iteration': sched.collective_seconds / n_stage_iters * 1e6,
+            'launches_per_iteration': sched.launches / float(n_stage_iters),
+            'median_projection_difference_px': diff,
+            'note': 'per iteration the sharded form pays 2 stage launches (forward-only + gradient), an all-gather of 4 x 300 x 6 floats, an all-reduce of the '
+                    'shared camera gradient and the Adam launch; the default keeps the scene in one workgroup for all iterations of a stage'}
+
+
 class _StubModel:
     """CPU stand-in used by tests/test_parallel_gloo.py to run this file's distributed skeleton (init, asset barrier, seed partition,
     timing protocol, max-reduction, rank-0 JSON) over gloo without a GPU.  Never used by a real measurement."""
@@ -458,6 +505,7 @@ def run(argv=None):
         host_stream = n_out / (time.time() - t0)
     coll_us = small_collective_latency(dev, world) if use_dist else None
     latency = one_sequence_latency(model, in_dicts[0]) if (rank == 0 and not args.stub_model and hasattr(model, 'optimize')) else None
+    sharded4 = person_sharded_line(asset_root, dev, rank, world) if (use_dist and not args.stub_model and not args.no_kernel_lines) else None
 
     out = None
     if rank == 0:
@@ -516,6 +564,8 @@ def run(argv=None):
             'host_inclusive_single_call_sequences_per_sec': B / host_single,
             'host_inclusive_stage_seconds': {k: round(v, 4) for k, v in tm.items()},
         }
+        if sharded4 is not None:
+            out['configs3_person_sharded'] = sharded4
         if coll_us is not None:
             out['collective_alternative'] = {'us_per_iteration_allreduce9_plus_allgather_4x300x12': coll_us, 'ranks': world,
                                              'note': 'what a person-sharded 4-person scene would add to EVERY iteration (loss_func.py:255-268, '

@@ -60,6 +60,7 @@ struct PersonConst {
   const float* base_trans;            // [T][3]
   const float* person2cam;            // [T][12]
   const float* dheading_mask;         // [T] (row e, e >= 1) or null = all zero
+  int frozen;                         // person owned by another rank: world pose given in base_orient / base_trans (glamr_scene_batch.frozen)
 };
 
 struct PersonState {
@@ -164,7 +165,7 @@ GLAMR_HD bool frame_in(int t, int T) {
 }
 
 struct PersonView {      // what the iteration loop needs of PersonConst + PersonState, uniform
-  int fr_start, fr_end, njc, njc_fast;
+  int fr_start, fr_end, njc, njc_fast, frozen;      // (a frozen person's existing range is EMPTY here: every frame takes the given pose)
   const float *vis, *j_local, *kp_2d, *kp_score, *cam_K, *prior, *base_orient, *base_trans, *person2cam, *dheading_mask, *h_prior, *oc6, *kp_wsum;
   const int* vis_rank;
   float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc;
@@ -426,7 +427,8 @@ GLAMR_HD PersonView person_view(RT& rt, const Scene& sc, int p) {
   const PersonConst& c = sc.pc[p];
   const PersonState& s = sc.ps[p];
   PersonView w;
-  w.fr_start = uni(c.fr_start); w.fr_end = uni(c.fr_end); w.njc = uni(s.njc); w.njc_fast = uni(s.njc_fast);
+  w.frozen = TMC > 0 ? 0 : uni(c.frozen);
+  w.fr_start = w.frozen ? 0 : uni(c.fr_start); w.fr_end = w.frozen ? 0 : uni(c.fr_end); w.njc = uni(s.njc); w.njc_fast = uni(s.njc_fast);
   w.j_local = glob(c.j_local); w.kp_2d = glob(c.kp_2d); w.kp_score = glob(c.kp_score);      // last evaluation only
   w.orient_world = glob(s.orient_world); w.trans_world = glob(s.trans_world); w.kp_2d_pred = glob(s.kp_2d_pred); w.orient_cam_in_world = glob(s.orient_cam_in_world);
   if constexpr (TMC > 0) {
@@ -533,6 +535,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     c.base_trans = b.base_trans + slot * TM * 3;
     c.person2cam = b.person2cam + slot * TM * 12;
     c.dheading_mask = b.dheading_mask ? b.dheading_mask + slot * TM : nullptr;
+    c.frozen = (b.frozen && b.max_persons > 1) ? (b.frozen[slot] != 0) : 0;
     s.orient_world = b.orient_world + slot * TM * 3;
     s.trans_world = b.trans_world + slot * TM * 3;
     s.kp_2d_pred = b.kp_2d_pred + slot * TM * NJ * 2;
@@ -725,7 +728,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int k = 0; k < 12; ++k) s.in_person2cam[t * 12 + k] = c.person2cam[(size_t)t * 12 + k];
     }
   }
-  if (var_cam) {
+  if (var_cam && !(st.flags & GLAMR_FLAG_KEEP_CAM_PARAMS)) {
     const int rows = fixed_cam ? 1 : T;
     for (int t = rt.tid(); t < rows; t += rt.nthreads()) {
       const float* M = sc.cam_pose + (size_t)t * 12;
@@ -897,7 +900,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           for (int k = 0; k < 3; ++k) { c1[k] = Rb[k * 3 + 0]; c2[k] = Rb[k * 3 + 1]; tb[k] = c.base_trans[t * 3 + k]; }
         }
         float sn = 0.f, cs = 1.f;
-        if (has_wd) { phi += s.p[lo.world_dheading + t]; rm::sincos_(phi, sn, cs); }
+        const bool frozen = !SINGLE && c.frozen;            // the given pose already carries its owner's world heading offset
+        if (has_wd && !frozen) { phi += s.p[lo.world_dheading + t]; rm::sincos_(phi, sn, cs); }
         else if (t >= c.fr_start && t < c.fr_end) { cs = s.csn[t * 2 + 0]; sn = s.csn[t * 2 + 1]; }
         float w1[3], w2[3];
         rotz2(cs, sn, c1, w1);
@@ -909,7 +913,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           s.d6[t * 6 + 3 + k] = w2[k];
           s.tw[t * 3 + k] = tb[k];
         }
-        if (last) {
+        if (last && !frozen) {
           float Rw[9], ow[3];
           cols_to_R(s.d6 + t * 6, Rw);
           rm::rotmat_to_aa(Rw, ow);
@@ -971,10 +975,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const float w_ctr = active(GLAMR_LOSS_CAM_TRAJ_ROT) ? st.loss_weight[GLAMR_LOSS_CAM_TRAJ_ROT] / n_ctr : 0.f;
     const float n_trs = (float)(P * (T - 1));
     const float w_trs = active(GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS) ? st.loss_weight[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] / n_trs : 0.f;
-    const float w_crs = active(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS) ? st.loss_weight[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] / (float)(T - 1) : 0.f;
-    const float w_cos = active(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS) ? st.loss_weight[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] / (float)(T - 1) : 0.f;
+    const bool cam_terms = !(st.flags & GLAMR_FLAG_NO_CAMERA_TERMS);      // false: the camera-only residuals are another rank's
+    const float w_crs = (cam_terms && active(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) ? st.loss_weight[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] / (float)(T - 1) : 0.f;
+    const float w_cos = (cam_terms && active(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS)) ? st.loss_weight[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] / (float)(T - 1) : 0.f;
     const float n_up = ffo(GLAMR_LOSS_CAM_UP_REG) ? 1.0f : (float)T;
-    const float w_up = active(GLAMR_LOSS_CAM_UP_REG) ? st.loss_weight[GLAMR_LOSS_CAM_UP_REG] / n_up : 0.f;
+    const float w_up = (cam_terms && active(GLAMR_LOSS_CAM_UP_REG)) ? st.loss_weight[GLAMR_LOSS_CAM_UP_REG] / n_up : 0.f;
     const float n_rel = (float)(P * (P - 1) * T);
     const float w_rel = (active(GLAMR_LOSS_REL_TRANSFORM) && P > 1) ? st.loss_weight[GLAMR_LOSS_REL_TRANSFORM] / n_rel : 0.f;
     const float min_conf = st.kp_min_conf;
@@ -994,6 +999,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int p = 0; p < P; ++p) {
         const PersonView c = pv(p);
         const PersonView& s = c;
+        if (!SINGLE && c.frozen) {
+          for (int k = 0; k < 6; ++k) s.g_d6[t * 6 + k] = 0.f;
+          for (int k = 0; k < 3; ++k) s.g_tw[t * 3 + k] = 0.f;
+          continue;
+        }
         const float* tw = s.tw + t * 3;
         float K[9], tgt[6];
         for (int k = 0; k < 9; ++k) K[k] = c.cam_K[(size_t)t * 9 + k];
@@ -1274,7 +1284,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int t = rt.tid(); frame_in(t, T); t += fstep)
         for (int p = 0; p < P; ++p) {
           const PersonView s = pv(p);
-          if (s.vis[t] == 0.f) continue;
+          if (s.vis[t] == 0.f || s.frozen) continue;
           float Rk[9], gRk[9], g_tw[3] = {0, 0, 0}, g6[6];
           for (int k = 0; k < 9; ++k) gRk[k] = 0.f;
           cols_to_R(s.d6 + t * 6, Rk);
@@ -1322,7 +1332,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float* ga = sh.g_avg + (size_t)t * 12;
         for (int r = 0; r < 3; ++r) { ga[r * 4 + 0] = g6[r]; ga[r * 4 + 1] = g6[3 + r]; ga[r * 4 + 2] = 0.f; ga[r * 4 + 3] = gMi[r * 4 + 3]; }
         float g_tres[3] = {gMi[3], gMi[7], gMi[11]};
-        if (active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
+        if (cam_terms && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
           const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
           for (int k = 0; k < 3; ++k) g_tres[k] += 2.0f * FPS * FPS * sh.cp[lo.cam_inv_trans_res - rs + t * 3 + k] * wreg;
         }
@@ -1356,7 +1366,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         }
       }
       // the fold writes g_d6 / g_tw of frame t from thread t only: the owner continues without a barrier
-    } else if (update && !var_cam && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
+    } else if (update && !var_cam && cam_terms && active(GLAMR_LOSS_CAM_INV_TRANS_RES_REG)) {
       // camera neither optimised nor derived from the persons: the residual only feels its own regulariser
       const float wreg = st.loss_weight[GLAMR_LOSS_CAM_INV_TRANS_RES_REG] / (float)T;
       for (int t = rt.tid(); frame_in(t, T); t += fstep)

@@ -15,6 +15,7 @@ LOSS_IDS = {'kp_2d': 0, 'kp_2d_dist': 1, 'rel_transform': 2, 'cam_traj_rot': 3, 
 VAR_BITS = {'cam': 1, 'local_xy': 2, 'local_heading': 4, 'world_dheading': 8, 'local_dxy': 16, 'local_rot': 32, 'local_z': 64,
             'local_dheading': 128}
 FLAG_FIXED_CAM, FLAG_CAM_FROM_PERSON, FLAG_HAS_WORLD_DHEADING = 1, 2, 4
+FLAG_KEEP_CAM_PARAMS, FLAG_NO_CAMERA_TERMS = 8, 16          # launch-by-launch stages (glamr_amd/parallel.py PersonShardedSchedule)
 
 
 def param_layout_py(max_persons, max_len):

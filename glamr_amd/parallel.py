@@ -56,3 +56,172 @@ def gather_results(local_results, dst=0):
     if dist.get_rank() != dst:
         return None
     return [x for part in out for x in part]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Person-sharded scenes: the collective variant of BASELINE configs[3]
+# ------------------------------------------------------------------------------------------------------------------------------------
+
+def _device_run_stage(packed, sd, want_grads):
+    """glamr_grecon_run_stage on the packed batch (current stream); returns the gradient record (n_scenes, scene_stride) or None."""
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    sb = packed.struct()
+    grads = torch.zeros_like(packed.t['params']) if want_grads else None
+    ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=packed.device)
+    _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), _lib.ptr(grads), _lib.ptr(ws), _lib.current_stream()))
+    packed.last_ws = ws
+    return grads
+
+
+def _device_adam_step(p, m, v, g, lr, step):
+    from . import _lib
+    _lib.check(_lib.lib().glamr_adam_step(p.numel(), _lib.ptr(p), _lib.ptr(m), _lib.ptr(v), _lib.ptr(g), float(lr), int(step), _lib.current_stream()))
+
+
+class PersonShardedSchedule:
+    """The staged optimisation of multi-person scenes with the PERSONS of a scene sharded over the ranks of a process group -- the variant
+    north_star names for BASELINE configs[3] ("RCCL over xGMI only for the shared-camera reduction"), built next to the default one (a
+    4-person scene fits one workgroup, whose block reduction sums the shared camera's gradient on chip: GlobalReconOptimizer.run_schedule)
+    so that both can be measured (SURVEY.md 8e "measure both and report").
+
+    What couples the persons of a scene, per Adam iteration (global_recon/models/global_recon_model.py:475-477,597-601, loss_func.py:248-271):
+      * the shared camera: every person's reprojection / camera-orientation residuals pull on the same `cam_rot_6d(_fix)`, `cam_trans(_fix)`
+        -> ALL-REDUCE (sum) of the camera block of the gradient (9 floats with `flag_fixed_cam`, 9 per frame otherwise);
+      * `rel_transform`: each ordered pair (i, j) compares inv(T_i) T_j with its camera-frame value, T = person_transform_world
+        -> ALL-GATHER of every person's world pose (smpl_orient_world, root_trans_world: 6 floats per frame) before the gradients are formed.
+    Normalisers (visible frames, existing frames, persons) are global; every rank knows all persons' visibility masks and existence ranges.
+
+    One iteration on every rank, host-orchestrated over the existing ABI (no new kernel: glamr_grecon_run_stage with `frozen` person slots):
+      1. forward-only launch (niters 0): world poses of the rank's OWN persons at the current parameters;
+      2. all-gather -> the other ranks' persons are FROZEN slots of this rank's scene (pose given, no residuals of their own, no gradient);
+      3. gradient launch (niters 1, lr 0, grads_out): gradients of the own persons' variables and this rank's PART of the camera gradient
+         (the camera-only regularisers are counted on rank 0 only: GLAMR_FLAG_NO_CAMERA_TERMS elsewhere);
+      4. all-reduce of the camera block;  5. glamr_adam_step (the optimiser's own update function, torch.optim.Adam to the bit) on the
+         replicated camera parameters and the own persons' blocks, moments kept by this object across the launches of a stage.
+    The INITIALISATION is replicated (every rank packs the whole scene; init_data is ~1 % of the schedule): what is sharded is the
+    700-iteration loop.  Stages whose camera is DERIVED from the persons (flag_opt_cam_from_person_pose without 'cam') are refused: there
+    the camera average carries gradients from every person's residuals to every other person, which this exchange does not cover.
+
+    `run_stage(packed, stage_desc, want_grads)` / `adam_step(p, m, v, g, lr, step)`: the device entry points by default; the CPU tests
+    inject the host runtime of tests/hostsim and run two ranks over gloo."""
+
+    def __init__(self, rank=None, world=None, group=None, run_stage=None, adam_step=None):
+        initialised = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank(group) if initialised else 0)
+        self.world = world if world is not None else (dist.get_world_size(group) if initialised else 1)
+        self.group = group
+        self.run_stage = run_stage or _device_run_stage
+        self.adam_step = adam_step or _device_adam_step
+        # collectives are issued whenever a process group exists -- also in a world of ONE rank (bench.py --force-dist, the single-GPU test of
+        # the RCCL path): nothing is exchanged then, but the calls and their stream ordering are the ones of the N-rank run
+        self.use_dist = initialised
+        self.collective_seconds = 0.0
+        self.launches = 0
+
+    def owned(self, n_persons):
+        lo, hi = shard_range(n_persons, self.rank, self.world)
+        return list(range(lo, hi))
+
+    def _all_gather_poses(self, packed, own, block):
+        """Own persons' (orient_world, trans_world) of every scene -> everybody; the others' land in the base arrays of their frozen slots."""
+        import time
+        S, P, T = packed.S, packed.P, packed.T
+        ow, tw = packed.t['orient_world'].view(S, P, T, 3), packed.t['trans_world'].view(S, P, T, 3)
+        mine = torch.zeros((block, S, T, 6), dtype=torch.float32, device=ow.device)
+        for k, pi in enumerate(own):
+            mine[k, :, :, :3], mine[k, :, :, 3:] = ow[:, pi], tw[:, pi]
+        if not self.use_dist:
+            return
+        t0 = time.time()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        self.collective_seconds += time.time() - t0
+        bo, bt = packed.t['base_orient'].view(S, P, T, 3), packed.t['base_trans'].view(S, P, T, 3)
+        for r, part in enumerate(parts):
+            if r == self.rank:
+                continue
+            lo, hi = shard_range(P, r, self.world)
+            for k, pi in enumerate(range(lo, hi)):
+                bo[:, pi], bt[:, pi] = part[k, :, :, :3], part[k, :, :, 3:]
+
+    def _all_reduce(self, t):
+        import time
+        if self.use_dist:
+            t0 = time.time()
+            dist.all_reduce(t, group=self.group)
+            self.collective_seconds += time.time() - t0
+
+    def run(self, packed, opt_stage_specs, model_specs, max_iters=None, has_wd=False):
+        """Runs the whole schedule on `packed` (the FULL scene batch, identical on every rank when the call starts).  On return every rank
+        holds the full result: parameters, world poses and projections of all persons, the camera."""
+        from .global_recon import packing
+        S, P, T, l = packed.S, packed.P, packed.T, packed.layout
+        if P < self.world:
+            raise ValueError('%d persons cannot be sharded over %d ranks' % (P, self.world))
+        own = self.owned(P)
+        block = -(-P // self.world)
+        frozen = torch.ones((S, P), dtype=torch.int32)
+        frozen[:, own] = 0
+        packed.t['frozen'] = frozen.reshape(-1).to(packed.device)
+        params = packed.t['params']
+        person_cols = [slice(l['person0'] + pi * l['person_stride'], l['person0'] + (pi + 1) * l['person_stride']) for pi in range(P)]
+        for stage, spec in opt_stage_specs.items():
+            if model_specs.get('flag_opt_cam_from_person_pose', False) and 'cam' not in spec['opt_variables']:
+                raise NotImplementedError('stage %r derives the camera from the persons: not covered by the person-sharded exchange' % stage)
+            n = spec['opt_niters'] if max_iters is None else min(max_iters, spec['opt_niters'])
+            m, v = torch.zeros_like(params), torch.zeros_like(params)
+            for it in range(n):
+                keep = packing.FLAG_KEEP_CAM_PARAMS if it > 0 else 0
+                fwd = packing.stage_desc(spec, model_specs, has_wd, niters=0)
+                fwd.flags |= keep
+                self.run_stage(packed, fwd, False)                                   # 1. own poses at the current parameters (+ camera parameters at it 0)
+                self._all_gather_poses(packed, own, block)                           # 2.
+                gd = packing.stage_desc(spec, model_specs, has_wd, niters=1)
+                gd.lr = 0.0                                                          # the update is made below, after the reduction
+                gd.flags |= packing.FLAG_KEEP_CAM_PARAMS | (packing.FLAG_NO_CAMERA_TERMS if self.rank != 0 else 0)
+                grads = self.run_stage(packed, gd, True)                             # 3.
+                self.launches += 2
+                cam = grads[:, :l['person0']].contiguous()
+                self._all_reduce(cam)                                                # 4.
+                grads[:, :l['person0']] = cam
+                for pi in range(P):
+                    if pi not in own:
+                        grads[:, person_cols[pi]] = 0.0
+                self.adam_step(params.view(-1), m.view(-1), v.view(-1), grads.view(-1), spec['opt_lr'], it + 1)      # 5.
+            has_wd = has_wd or 'world_dheading' in spec['opt_variables']
+            if spec.get('reinitialize_cam', False):
+                packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
+        # every rank ends with the whole scene: own persons' variables and outputs to everybody
+        self._share_results(packed, own, block, person_cols)
+        packed.t['frozen'] = None
+        packed.has_world_dheading = has_wd
+        return packed
+
+    def _share_results(self, packed, own, block, person_cols):
+        if not self.use_dist:
+            return
+        S, P, T = packed.S, packed.P, packed.T
+        names = (('orient_world', 3), ('trans_world', 3), ('orient_cam_in_world', 3), ('kp_2d_pred', 52))
+        width = sum(w for _, w in names)
+        stride = person_cols[0].stop - person_cols[0].start
+        mine = torch.zeros((block, S, T * width + stride), dtype=torch.float32, device=packed.device)
+        for k, pi in enumerate(own):
+            o = 0
+            for name, w in names:
+                mine[k, :, o:o + T * w] = packed.t[name].view(S, P, T * w)[:, pi]
+                o += T * w
+            mine[k, :, o:] = packed.t['params'][:, person_cols[pi]]
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        for r, part in enumerate(parts):
+            if r == self.rank:
+                continue
+            lo, hi = shard_range(P, r, self.world)
+            for k, pi in enumerate(range(lo, hi)):
+                o = 0
+                for name, w in names:
+                    packed.t[name].view(S, P, T * w)[:, pi] = part[k, :, o:o + T * w]
+                    o += T * w
+                packed.t['params'][:, person_cols[pi]] = part[k, :, o:]

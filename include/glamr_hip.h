@@ -179,6 +179,11 @@ int glamr_traj_local_to_global(int n_seq, int T, const float* local_traj, float*
 #define GLAMR_FLAG_FIXED_CAM (1u << 0)             /* flag_fixed_cam */
 #define GLAMR_FLAG_CAM_FROM_PERSON (1u << 1)       /* flag_opt_cam_from_person_pose */
 #define GLAMR_FLAG_HAS_WORLD_DHEADING (1u << 2)    /* a previous stage created pose_dict['world_dheading'] (:624-627) */
+/* flags of a stage that is driven launch by launch from outside (the person-sharded variant, glamr_amd/parallel.py) */
+#define GLAMR_FLAG_KEEP_CAM_PARAMS (1u << 3)       /* the camera parameters in `params` are current: do NOT re-derive them from cam_pose when the
+                                                      launch starts (get_parameter :596-606 runs once per stage, not once per launch) */
+#define GLAMR_FLAG_NO_CAMERA_TERMS (1u << 4)       /* leave the camera-only residuals (cam_inv_rot_smoothness, cam_origin_smoothness, cam_up_reg,
+                                                      cam_inv_trans_residual_reg) out of the gradient: another rank owns them */
 
 /* loss ids (loss_func_dict, loss_func.py:314-340) -- order of glamr_stage_desc.loss_weight[] */
 enum {
@@ -234,6 +239,11 @@ typedef struct glamr_scene_batch {
   float* trans_world;                    /* (slots, max_len, 3) */
   float* kp_2d_pred;                     /* (slots, max_len, n_joints, 2) */
   float* orient_cam_in_world;            /* (slots, max_len, 3) */
+  /* person-sharded scenes (several persons only): a person slot with frozen[slot] != 0 belongs to ANOTHER rank.  Its world pose on every
+   * frame is GIVEN in base_orient / base_trans (what that rank published: smpl_orient_world, root_trans_world); it takes part in the
+   * relative-transform pairs, the camera average and every normaliser (vis, fr_start, fr_end must be its own), has no residuals of its
+   * own, receives no gradient and its outputs are not written.  NULL = nobody is frozen. */
+  const int32_t* frozen;                 /* (slots) or NULL */
 } glamr_scene_batch;
 
 /* Offsets (in floats) of each variable block inside one scene's parameter vector; see glamr_grecon_param_layout().
