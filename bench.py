@@ -278,6 +278,7 @@ def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8):
     n_stage_iters = sum(min(iters, s['opt_niters']) for s in m4.opt_stage_specs.values())
 
     def fused():
+        torch.manual_seed(4)                                           # the same latent draws for both variants
         _, packed = m4.init_resident(rin, init_forward=False)
         torch.cuda.synchronize()
         t0 = time.time()
@@ -286,6 +287,7 @@ def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8):
         return time.time() - t0, packed
 
     def sharded():
+        torch.manual_seed(4)
         _, packed = m4.init_resident(rin, init_forward=False)
         sched = parallel.PersonShardedSchedule()
         torch.cuda.synchronize()

@@ -64,6 +64,8 @@ _SIGNATURES = {
     'glamr_smpl_forward': (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p]),
     'glamr_smpl_fk': (c_int, [c_void_p, c_int] + [c_void_p] * 5),
     'glamr_smpl_backward_root': (c_int, [c_void_p, c_int] + [c_void_p] * 10 + [c_int, c_void_p]),
+    'glamr_smpl_backward_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
+    'glamr_smpl_backward': (c_int, [c_void_p, c_int] + [c_void_p] * 12 + [c_int, c_void_p, c_void_p]),
     'glamr_nets_create': (c_int, [POINTER(c_void_p), c_void_p, POINTER(TensorDesc), c_int, c_void_p, POINTER(TensorDesc), c_int, c_void_p, c_void_p]),
     'glamr_nets_destroy': (c_int, [c_void_p]),
     'glamr_nets_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),

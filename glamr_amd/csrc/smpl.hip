@@ -95,6 +95,30 @@ __device__ __forceinline__ void rodrigues_smplx(const float r[3], float R[9]) {
   R[8] = 1.0f + c1 * (-(x * x + y * y));
 }
 
+
+// backward of rodrigues_smplx: g_r = (dR/dr)^T gR
+__device__ __forceinline__ void rodrigues_smplx_bwd(const float r[3], const float gR[9], float* g_r) {
+  const float ax = r[0] + 1e-8f, ay = r[1] + 1e-8f, az = r[2] + 1e-8f;
+  const float angle = sqrtf(ax * ax + ay * ay + az * az), inv = 1.0f / angle;
+  const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
+  const float s = sinf(angle), c = cosf(angle), c1 = 1.0f - c;
+  // R = I + s K + c1 K2
+  const float K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
+  float g_s = 0.f, g_c1 = 0.f;
+  for (int e = 0; e < 9; ++e) { g_s += gR[e] * K[e]; g_c1 += gR[e] * K2[e]; }
+  // d/dx, d/dy, d/dz of (s K + c1 K2)
+  const float gx = s * (gR[7] - gR[5]) + c1 * (y * (gR[1] + gR[3]) + z * (gR[2] + gR[6]) - 2.f * x * (gR[4] + gR[8]));
+  const float gy = s * (gR[2] - gR[6]) + c1 * (x * (gR[1] + gR[3]) + z * (gR[5] + gR[7]) - 2.f * y * (gR[0] + gR[8]));
+  const float gz = s * (gR[3] - gR[1]) + c1 * (x * (gR[2] + gR[6]) + y * (gR[5] + gR[7]) - 2.f * z * (gR[0] + gR[4]));
+  const float g_angle = g_s * c + g_c1 * s;          // d s/d angle = cos, d c1/d angle = sin
+  // x = r0 / angle etc.; angle = || r + eps ||
+  const float g_angle_tot = g_angle - (gx * r[0] + gy * r[1] + gz * r[2]) * inv * inv;
+  g_r[0] = gx * inv + g_angle_tot * ax * inv;
+  g_r[1] = gy * inv + g_angle_tot * ay * inv;
+  g_r[2] = gz * inv + g_angle_tot * az * inv;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // prep: one thread per (frame, joint); FRAMES_PER_BLOCK frames per 256-thread block
 // ---------------------------------------------------------------------------------------------------------------------
@@ -559,26 +583,220 @@ __global__ __launch_bounds__(256) void smpl_backward_root_kernel(BwdArgs a) {
   float gR[9];
   for (int i = 0; i < 3; ++i)
     for (int k = 0; k < 3; ++k) gR[i * 3 + k] = M[i * 3 + 0] * R[0 * 3 + k] + M[i * 3 + 1] * R[1 * 3 + k] + M[i * 3 + 2] * R[2 * 3 + k];
-  // backward of rodrigues_smplx
-  const float ax = r[0] + 1e-8f, ay = r[1] + 1e-8f, az = r[2] + 1e-8f;
-  const float angle = sqrtf(ax * ax + ay * ay + az * az), inv = 1.0f / angle;
-  const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
-  const float s = sinf(angle), c = cosf(angle), c1 = 1.0f - c;
-  // R = I + s K + c1 K2
-  const float K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
-  const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
-  float g_s = 0.f, g_c1 = 0.f;
-  for (int e = 0; e < 9; ++e) { g_s += gR[e] * K[e]; g_c1 += gR[e] * K2[e]; }
-  // d/dx, d/dy, d/dz of (s K + c1 K2)
-  float gx = s * (gR[7] - gR[5]) + c1 * (y * (gR[1] + gR[3]) + z * (gR[2] + gR[6]) - 2.f * x * (gR[4] + gR[8]));
-  float gy = s * (gR[2] - gR[6]) + c1 * (x * (gR[1] + gR[3]) + z * (gR[5] + gR[7]) - 2.f * y * (gR[0] + gR[8]));
-  float gz = s * (gR[3] - gR[1]) + c1 * (x * (gR[2] + gR[6]) + y * (gR[5] + gR[7]) - 2.f * z * (gR[0] + gR[4]));
-  const float g_angle = g_s * c + g_c1 * s;          // d s/d angle = cos, d c1/d angle = sin
-  // x = r0 / angle etc.; angle = || r + eps ||
-  const float g_angle_tot = g_angle - (gx * r[0] + gy * r[1] + gz * r[2]) * inv * inv;
-  a.g_orient[(size_t)b * 3 + 0] = gx * inv + g_angle_tot * ax * inv;
-  a.g_orient[(size_t)b * 3 + 1] = gy * inv + g_angle_tot * ay * inv;
-  a.g_orient[(size_t)b * 3 + 2] = gz * inv + g_angle_tot * az * inv;
+  rodrigues_smplx_bwd(r, gR, a.g_orient + (size_t)b * 3);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GENERAL backward: gradients w.r.t. the whole pose (global orientation + 23 body joints), the shape coefficients, root translation and
+// scale, from gradients of the joints and / or the vertices (torch autograd through lib/models/smpl.py:289-316 + smplx.lbs).  Needed when
+// the body pose itself is a function of optimisation variables (the latent-optimisation mode, global_recon_model.py:434-437).
+//   anchor   y = (x - x_pivot) s + t                       -> g_x = s g_y,  g_pivot = -s sum g_y,  g_t = sum g_y,  g_s = sum g_y . (y - t) / s
+//   vertex   x_v = T_v [v_posed_v; 1],  T_v = sum_k W_vk A_k -> g_vposed = T_R^T g,  g_T = g (x) [v_posed; 1],  g_A_k = sum_v W_vk g_T_v
+//   blend    v_posed = dirs . [betas | vec(R_k - I) | 1]    -> g_feat = dirs^T g_vposed
+//   chain    G_k = G_parent [R_k | J_k - J_parent],  A_k = [G_R | G_t - G_R J_k],  chain joint k = G_t          (reverse order)
+//   rest     J = J_template + J_shapedirs betas             -> g_betas += J_shapedirs^T g_J
+// Per (vertex tile, frame) partial sums are written out and reduced in a FIXED order (no atomics: results are reproducible).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int BW_PART = 218 + 12 * NJ;        // g_feat[0..217] | g_A[12][24]
+
+struct BwdGenArgs {
+  int B, Bpad, V, Vpad, n_tiles, n_extra_used, n_picked, n_out, orig_joints, num_betas;
+  const float* pose; const float* betas; const float* root_trans; const float* root_scale;
+  const float* verts; const float* joints;         // forward outputs (needed for g_scale only)
+  const float* g_verts; const float* g_joints;
+  const int32_t* joint_map; const int32_t* extra_slot; const int32_t* parents;
+  const float* j_template; const float* j_shapedirs;
+  const float* dirs_tiled; const float* w_tiled; const float* jx_used;
+  const int32_t* tile_pick_start; const int32_t* tile_pick_ids; const int32_t* pick_row;
+  const float* feat; const float* askin;           // recomputed by smpl_prep_kernel
+  float* gj54;                                     // (B, 24 + MAX_PICKED + MAX_EXTRA, 3): gradient of [chain | picked | extra-regressed] joints
+  float* partial;                                  // (n_tiles, Bpad, BW_PART)
+  float* g_pose; float* g_betas; float* g_trans; float* g_scale;
+};
+constexpr int GJ_STRIDE = NJ + MAX_PICKED + MAX_EXTRA;
+
+// one workgroup per frame: gradient of the mapped joints -> gradient of the 54-joint set, anchor terms
+__global__ __launch_bounds__(256) void smpl_bwd_anchor_kernel(BwdGenArgs a) {
+  __shared__ float red[4];
+  __shared__ float sg[GJ_STRIDE * 3];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bool anchored = a.root_trans != nullptr;
+  const float sc = (anchored && a.root_scale) ? a.root_scale[b] : 1.0f;
+  const int n_out = a.orig_joints ? NJ : a.n_out;
+  for (int i = tid; i < GJ_STRIDE * 3; i += 256) sg[i] = 0.f;
+  float gs[3] = {0.f, 0.f, 0.f}, gdot = 0.f;
+  float t[3] = {0.f, 0.f, 0.f};
+  if (anchored) for (int c = 0; c < 3; ++c) t[c] = a.root_trans[(size_t)b * 3 + c];
+  if (a.g_verts)
+    for (int v = tid; v < a.V; v += 256)
+      for (int c = 0; c < 3; ++c) {
+        const float g = a.g_verts[((size_t)b * a.V + v) * 3 + c];
+        gs[c] += g;
+        if (a.g_scale && a.verts) gdot += g * (a.verts[((size_t)b * a.V + v) * 3 + c] - t[c]);
+      }
+  if (a.g_joints && tid < n_out)
+    for (int c = 0; c < 3; ++c) {
+      const float g = a.g_joints[((size_t)b * n_out + tid) * 3 + c];
+      gs[c] += g;
+      if (a.g_scale && a.joints) gdot += g * (a.joints[((size_t)b * n_out + tid) * 3 + c] - t[c]);
+    }
+  for (int c = 0; c < 3; ++c) gs[c] = block_sum_256(gs[c], red);
+  gdot = block_sum_256(gdot, red);
+  __syncthreads();
+  // scatter through the joint map (a source joint may be mapped more than once: one thread walks the outputs)
+  if (tid == 0) {
+    for (int j = 0; j < n_out && a.g_joints; ++j) {
+      const int src = a.orig_joints ? j : a.joint_map[j];
+      const int slot = src < NJ ? src : (src < NJ + a.n_picked ? NJ + (src - NJ) : NJ + MAX_PICKED + a.extra_slot[src - NJ - a.n_picked]);
+      for (int c = 0; c < 3; ++c) sg[slot * 3 + c] += sc * a.g_joints[((size_t)b * n_out + j) * 3 + c];
+    }
+    if (anchored) {      // the pivot is output joint 0 before re-anchoring
+      const int src = a.orig_joints ? 0 : a.joint_map[0];
+      const int slot = src < NJ ? src : (src < NJ + a.n_picked ? NJ + (src - NJ) : NJ + MAX_PICKED + a.extra_slot[src - NJ - a.n_picked]);
+      for (int c = 0; c < 3; ++c) sg[slot * 3 + c] -= sc * gs[c];
+      if (a.g_trans) for (int c = 0; c < 3; ++c) a.g_trans[(size_t)b * 3 + c] = gs[c];
+      if (a.g_scale) a.g_scale[b] = gdot / sc;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < GJ_STRIDE * 3; i += 256) a.gj54[(size_t)b * GJ_STRIDE * 3 + i] = sg[i];
+}
+
+// one workgroup per (vertex tile, frame)
+__global__ __launch_bounds__(256) void smpl_bwd_tile_kernel(BwdGenArgs a) {
+  __shared__ float sfeat[KTOT];
+  __shared__ float sA[12 * NJ];
+  __shared__ float sgv[TILE_V][3], svp[TILE_V][3], sgvp[TILE_V][3], sgT[TILE_V][12];
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  for (int k = tid; k < KTOT; k += 256) sfeat[k] = a.feat[(size_t)b * KTOT + k];
+  for (int k = tid; k < 12 * NJ; k += 256) sA[k] = a.askin[(size_t)b * 12 * NJ + k];
+  const float sc = (a.root_trans && a.root_scale) ? a.root_scale[b] : 1.0f;
+  const float* gj = a.gj54 + (size_t)b * GJ_STRIDE * 3;
+  if (tid < TILE_V * 3) {
+    const int v = tid / 3, c = tid % 3, vg = tile * TILE_V + v;
+    float g = 0.f;
+    if (a.g_verts && vg < a.V) g = sc * a.g_verts[((size_t)b * a.V + vg) * 3 + c];
+    for (int x = 0; x < a.n_extra_used; ++x) g += a.jx_used[(size_t)x * a.Vpad + vg] * gj[(NJ + MAX_PICKED + x) * 3 + c];
+    for (int q = a.tile_pick_start[tile]; q < a.tile_pick_start[tile + 1]; ++q) {
+      const int id = a.tile_pick_ids[q];
+      if (a.pick_row[id] == v) g += gj[(NJ + id) * 3 + c];
+    }
+    sgv[v][c] = g;
+  }
+  __syncthreads();
+  const float* dirs = a.dirs_tiled + (size_t)tile * 3 * TILE_V * KSTRIDE;
+  if (tid < TILE_V * 3) {      // v_posed of the tile (recomputed: the forward does not keep it)
+    const int v = tid % TILE_V, c = tid / TILE_V;
+    const float* row = dirs + ((size_t)c * TILE_V + v) * KSTRIDE;
+    float acc = 0.f;
+    for (int k = 0; k <= K_ONE; ++k) acc = fmaf(row[k], sfeat[k], acc);
+    svp[v][c] = acc;
+  }
+  __syncthreads();
+  if (tid < TILE_V) {
+    const int v = tid, vg = tile * TILE_V + v;
+    float T[12];
+    for (int e = 0; e < 12; ++e) {
+      float acc = 0.f;
+      for (int j = 0; j < NJ; ++j) acc = fmaf(a.w_tiled[(size_t)vg * NJ + j], sA[e * NJ + j], acc);
+      T[e] = acc;
+    }
+    const float g[3] = {sgv[v][0], sgv[v][1], sgv[v][2]};
+    for (int c = 0; c < 3; ++c) sgvp[v][c] = T[0 * 4 + c] * g[0] + T[1 * 4 + c] * g[1] + T[2 * 4 + c] * g[2];
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) sgT[v][r * 4 + c] = g[r] * svp[v][c];
+      sgT[v][r * 4 + 3] = g[r];
+    }
+  }
+  __syncthreads();
+  float* out = a.partial + ((size_t)tile * a.Bpad + b) * BW_PART;
+  for (int idx = tid; idx < BW_PART; idx += 256) {
+    float acc = 0.f;
+    if (idx <= K_ONE) {
+      for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < TILE_V; ++v) acc = fmaf(dirs[((size_t)c * TILE_V + v) * KSTRIDE + idx], sgvp[v][c], acc);
+    } else {
+      const int e = (idx - 218) / NJ, j = (idx - 218) % NJ;
+      for (int v = 0; v < TILE_V; ++v) acc = fmaf(a.w_tiled[(size_t)(tile * TILE_V + v) * NJ + j], sgT[v][e], acc);
+    }
+    out[idx] = acc;
+  }
+}
+
+// one workgroup per frame: reduce the tile partials, then the kinematic chain in reverse
+__global__ __launch_bounds__(256) void smpl_bwd_chain_kernel(BwdGenArgs a) {
+  __shared__ float sp[BW_PART];
+  __shared__ float sR[NJ][9], sGR[NJ][9], sGt[NJ][3], sJ[NJ][3], gGR[NJ][9], gGt[NJ][3], gJ[NJ][3], gpose[NJ][3];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < BW_PART; idx += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < a.n_tiles; ++t) acc += a.partial[((size_t)t * a.Bpad + b) * BW_PART + idx];
+    sp[idx] = acc;
+  }
+  if (tid < NJ) {
+    const int j = tid;
+    const float r[3] = {a.pose[(size_t)b * 72 + j * 3], a.pose[(size_t)b * 72 + j * 3 + 1], a.pose[(size_t)b * 72 + j * 3 + 2]};
+    rodrigues_smplx(r, sR[j]);
+    for (int c = 0; c < 3; ++c) {
+      float v = a.j_template[j * 3 + c];
+      for (int l = 0; l < a.num_betas; ++l) v = fmaf(a.j_shapedirs[(j * 3 + c) * a.num_betas + l], a.betas[(size_t)b * a.num_betas + l], v);
+      sJ[j][c] = v;
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const float* gj = a.gj54 + (size_t)b * GJ_STRIDE * 3;
+  // forward chain (parents precede their children in the SMPL tree)
+  for (int k = 0; k < NJ; ++k) {
+    const int p = a.parents[k];
+    if (p < 0) { for (int e = 0; e < 9; ++e) sGR[k][e] = sR[k][e]; for (int c = 0; c < 3; ++c) sGt[k][c] = sJ[k][c]; continue; }
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) sGR[k][r * 3 + c] = sGR[p][r * 3 + 0] * sR[k][0 * 3 + c] + sGR[p][r * 3 + 1] * sR[k][1 * 3 + c] + sGR[p][r * 3 + 2] * sR[k][2 * 3 + c];
+      sGt[k][r] = sGR[p][r * 3 + 0] * (sJ[k][0] - sJ[p][0]) + sGR[p][r * 3 + 1] * (sJ[k][1] - sJ[p][1]) + sGR[p][r * 3 + 2] * (sJ[k][2] - sJ[p][2]) + sGt[p][r];
+    }
+  }
+  // A_k = [G_R | G_t - G_R J_k],  chain joint k = G_t
+  for (int k = 0; k < NJ; ++k) {
+    float gAt[3];
+    for (int r = 0; r < 3; ++r) gAt[r] = sp[218 + (r * 4 + 3) * NJ + k];
+    for (int r = 0; r < 3; ++r) {
+      gGt[k][r] = gj[k * 3 + r] + gAt[r];
+      for (int c = 0; c < 3; ++c) gGR[k][r * 3 + c] = sp[218 + (r * 4 + c) * NJ + k] - gAt[r] * sJ[k][c];
+    }
+    for (int c = 0; c < 3; ++c) gJ[k][c] = -(sGR[k][0 * 3 + c] * gAt[0] + sGR[k][1 * 3 + c] * gAt[1] + sGR[k][2 * 3 + c] * gAt[2]);
+  }
+  for (int k = NJ - 1; k >= 0; --k) {
+    const int p = a.parents[k];
+    float gR[9];
+    if (p < 0) {
+      for (int e = 0; e < 9; ++e) gR[e] = gGR[k][e];
+      for (int c = 0; c < 3; ++c) gJ[k][c] += gGt[k][c];
+    } else {
+      const float d[3] = {sJ[k][0] - sJ[p][0], sJ[k][1] - sJ[p][1], sJ[k][2] - sJ[p][2]};
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          gR[r * 3 + c] = sGR[p][0 * 3 + r] * gGR[k][0 * 3 + c] + sGR[p][1 * 3 + r] * gGR[k][1 * 3 + c] + sGR[p][2 * 3 + r] * gGR[k][2 * 3 + c];
+          gGR[p][r * 3 + c] += gGR[k][r * 3 + 0] * sR[k][c * 3 + 0] + gGR[k][r * 3 + 1] * sR[k][c * 3 + 1] + gGR[k][r * 3 + 2] * sR[k][c * 3 + 2] + gGt[k][r] * d[c];
+        }
+      for (int c = 0; c < 3; ++c) {
+        gGt[p][c] += gGt[k][c];
+        const float gd = sGR[p][0 * 3 + c] * gGt[k][0] + sGR[p][1 * 3 + c] * gGt[k][1] + sGR[p][2 * 3 + c] * gGt[k][2];
+        gJ[k][c] += gd;
+        gJ[p][c] -= gd;
+      }
+      for (int e = 0; e < 9; ++e) gR[e] += sp[10 + (k - 1) * 9 + e];      // pose blend shapes: feature = vec(R_k - I), k >= 1
+    }
+    const float r[3] = {a.pose[(size_t)b * 72 + k * 3], a.pose[(size_t)b * 72 + k * 3 + 1], a.pose[(size_t)b * 72 + k * 3 + 2]};
+    rodrigues_smplx_bwd(r, gR, gpose[k]);
+  }
+  if (a.g_pose) for (int k = 0; k < NJ; ++k) for (int c = 0; c < 3; ++c) a.g_pose[(size_t)b * 72 + k * 3 + c] = gpose[k][c];
+  if (a.g_betas)
+    for (int l = 0; l < a.num_betas; ++l) {
+      float acc = sp[l];
+      for (int k = 0; k < NJ; ++k) for (int c = 0; c < 3; ++c) acc = fmaf(a.j_shapedirs[(k * 3 + c) * a.num_betas + l], gJ[k][c], acc);
+      a.g_betas[(size_t)b * a.num_betas + l] = acc;
+    }
 }
 
 }  // namespace glamr
@@ -886,6 +1104,59 @@ extern "C" int glamr_smpl_backward_root(glamr_smpl* h, int B, const float* pose,
   BwdArgs ba{B, h->V, (flags & GLAMR_SMPL_ORIG_JOINTS) ? NJ : h->n_out, pose, root_trans, root_scale, verts, joints, g_verts, g_joints,
              g_orient, g_trans, g_scale};
   hipLaunchKernelGGL(smpl_backward_root_kernel, dim3(B), dim3(256), 0, stream, ba);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+namespace {
+struct SmplBwdWs { float *feat, *askin, *chain, *gj54, *partial; size_t total; int Bpad; };
+SmplBwdWs smpl_bwd_ws_layout(const glamr_smpl* h, int B, int with_verts, char* base) {
+  SmplBwdWs w{};
+  w.Bpad = (B + TILE_F - 1) / TILE_F * TILE_F;
+  size_t off = 0;
+  auto take = [&](size_t nfloats) { float* p = reinterpret_cast<float*>(base + off); off = align_up(off + nfloats * sizeof(float), 256); return p; };
+  const glamr_tileset& ts = (!with_verts && h->joints.n_tiles > 0) ? h->joints : h->full;
+  w.feat = take((size_t)w.Bpad * KTOT);
+  w.askin = take((size_t)w.Bpad * 12 * NJ);
+  w.chain = take((size_t)w.Bpad * NJ * 3);
+  w.gj54 = take((size_t)w.Bpad * GJ_STRIDE * 3);
+  w.partial = take((size_t)ts.n_tiles * w.Bpad * BW_PART);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t glamr_smpl_backward_workspace_bytes(const glamr_smpl* h, int B, int with_vertex_gradient) {
+  if (!h || B <= 0) return 0;
+  return smpl_bwd_ws_layout(h, B, with_vertex_gradient, nullptr).total;
+}
+
+extern "C" int glamr_smpl_backward(glamr_smpl* h, int B, const float* pose, const float* betas, const float* root_trans, const float* root_scale,
+                                   const float* verts, const float* joints, const float* g_verts, const float* g_joints, float* g_pose,
+                                   float* g_betas, float* g_trans, float* g_scale, int flags, void* workspace, void* stream_) {
+  GLAMR_REQUIRE(h && pose && betas && workspace && (g_verts || g_joints) && (g_pose || g_betas), "null argument");
+  GLAMR_REQUIRE(B > 0, "B must be positive");
+  GLAMR_REQUIRE(!g_scale || (root_trans && (!g_verts || verts) && (!g_joints || joints)),
+                "g_scale needs the re-anchored forward and its outputs (verts / joints)");
+  GLAMR_REQUIRE(!(g_trans || g_scale) || root_trans, "g_trans / g_scale only exist for the re-anchored forward (root_trans != NULL)");
+  GLAMR_REQUIRE(h->n_picked <= MAX_PICKED, "more than %d picked vertices", MAX_PICKED);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool orig = (flags & GLAMR_SMPL_ORIG_JOINTS) != 0;
+  const int with_verts = g_verts != nullptr;
+  SmplBwdWs w = smpl_bwd_ws_layout(h, B, with_verts, static_cast<char*>(workspace));
+  const glamr_tileset& ts = (!with_verts && h->joints.n_tiles > 0) ? h->joints : h->full;
+  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, nullptr, w.askin, nullptr, w.chain};
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
+  BwdGenArgs a{B, w.Bpad, h->V, ts.Vpad, ts.n_tiles, h->n_extra_used, h->n_picked, h->n_out, orig ? 1 : 0, h->num_betas,
+               pose, betas, root_trans, root_scale, verts, joints, g_verts, g_joints, h->joint_map, h->extra_slot, h->parents,
+               h->j_template, h->j_shapedirs, ts.dirs_tiled, ts.w_tiled, ts.jx_used, ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row,
+               w.feat, w.askin, w.gj54, w.partial, g_pose, g_betas, g_trans, g_scale};
+  hipLaunchKernelGGL(smpl_bwd_anchor_kernel, dim3(B), dim3(256), 0, stream, a);
+  // (orig_joints without a vertex gradient: only the chain carries gradient, the tile pass has nothing to add)
+  const bool tiles = with_verts || !orig;
+  if (tiles) hipLaunchKernelGGL(smpl_bwd_tile_kernel, dim3(ts.n_tiles, B), dim3(256), 0, stream, a);
+  else a.n_tiles = 0;
+  hipLaunchKernelGGL(smpl_bwd_chain_kernel, dim3(B), dim3(256), 0, stream, a);
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }

@@ -9,9 +9,11 @@ Same constructor and call signature:
 
 All arithmetic (Rodrigues, kinematic chain, blend shapes, skinning, joint regression, re-anchoring) runs in hand-written
 HIP kernels behind the C ABI (`glamr_smpl_*` in include/glamr_hip.h); this file only loads the model file, owns the device
-handle and gives the call autograd semantics.  Gradients flow to `global_orient`, `root_trans` and `root_scale` (what the
-global optimiser differentiates, global_recon_model.py:517-524,591-633); asking for gradients w.r.t. `body_pose` or `betas`
-raises.  There is no CPU implementation: tensors must live on a HIP device.
+handle and gives the call autograd semantics.  Gradients flow to every input: when only `global_orient`, `root_trans` and `root_scale`
+need them (what the shipped configurations differentiate, global_recon_model.py:517-524,591-633) the backward uses the rigid identity on
+the forward outputs (glamr_smpl_backward_root); when `body_pose` or `betas` require gradients (the latent-optimisation mode, :434-437) the
+general backward runs (glamr_smpl_backward: skinning, blend shapes, kinematic chain, joint regression, re-anchoring in reverse), with or
+without `root_trans`.  There is no CPU implementation: tensors must live on a HIP device.
 """
 import os
 import pickle
@@ -67,7 +69,7 @@ def _dense(x):
 class _SmplFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, module, pose, betas, root_trans, root_scale, want_verts, orig_joints):
+    def forward(ctx, module, pose, betas, root_trans, root_scale, want_verts, orig_joints, general=False):
         h = module._handle(pose.device)
         B = pose.shape[0]
         n_out = 24 if orig_joints else module.n_out
@@ -78,16 +80,18 @@ class _SmplFn(torch.autograd.Function):
         flags = 1 if orig_joints else 0
         _lib.check(L.glamr_smpl_forward(h, B, _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(root_trans), _lib.ptr(root_scale),
                                         _lib.ptr(verts), _lib.ptr(joints), flags, _lib.ptr(ws), _lib.current_stream()))
-        ctx.module, ctx.flags, ctx.want_verts = module, flags, want_verts
-        ctx.save_for_backward(pose, root_trans, root_scale, verts, joints)
+        ctx.module, ctx.flags, ctx.want_verts, ctx.general = module, flags, want_verts, general
+        ctx.save_for_backward(pose, root_trans, root_scale, verts, joints, betas)
         if want_verts:
             return verts, joints
         return joints.new_empty(0), joints
 
     @staticmethod
     def backward(ctx, g_verts, g_joints):
-        pose, root_trans, root_scale, verts, joints = ctx.saved_tensors
+        pose, root_trans, root_scale, verts, joints, betas = ctx.saved_tensors
         module = ctx.module
+        if ctx.general:
+            return _SmplFn._backward_general(ctx, g_verts, g_joints)
         if root_trans is None:
             raise NotImplementedError('SMPL backward is implemented for the re-anchored call (root_trans given), the form the '
                                       'global optimiser uses (global_recon_model.py:517-524)')
@@ -103,7 +107,27 @@ class _SmplFn(torch.autograd.Function):
                                               _lib.ptr(g_trans), _lib.ptr(g_scale), ctx.flags, _lib.current_stream()))
         g_pose = torch.zeros_like(pose)
         g_pose[:, :3] = g_orient
-        return None, g_pose, None, g_trans, g_scale, None, None
+        return None, g_pose, None, g_trans, g_scale, None, None, None
+
+    @staticmethod
+    def _backward_general(ctx, g_verts, g_joints):
+        pose, root_trans, root_scale, verts, joints, betas = ctx.saved_tensors
+        module, B, dev = ctx.module, pose.shape[0], pose.device
+        gv = g_verts.contiguous() if (ctx.want_verts and g_verts is not None) else None
+        gj = g_joints.contiguous() if g_joints is not None else None
+        if gv is None and gj is None:
+            return (None,) * 8
+        g_pose = torch.empty((B, 72), device=dev, dtype=torch.float32)
+        g_betas = torch.empty_like(betas)
+        g_trans = torch.empty((B, 3), device=dev, dtype=torch.float32) if root_trans is not None else None
+        g_scale = torch.empty((B,), device=dev, dtype=torch.float32) if root_scale is not None else None
+        L = _lib.lib()
+        h = module._handle(dev)
+        ws = torch.empty(L.glamr_smpl_backward_workspace_bytes(h, B, 1 if gv is not None else 0), device=dev, dtype=torch.uint8)
+        _lib.check(L.glamr_smpl_backward(h, B, _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(root_trans), _lib.ptr(root_scale), _lib.ptr(verts), _lib.ptr(joints),
+                                         _lib.ptr(gv), _lib.ptr(gj), _lib.ptr(g_pose), _lib.ptr(g_betas), _lib.ptr(g_trans), _lib.ptr(g_scale), ctx.flags,
+                                         _lib.ptr(ws), _lib.current_stream()))
+        return None, g_pose, g_betas, g_trans, g_scale, None, None, None
 
 
 class SMPL(nn.Module):
@@ -183,10 +207,15 @@ class SMPL(nn.Module):
     def forward(self, *args, betas=None, body_pose=None, global_orient=None, root_trans=None, root_scale=None, orig_joints=False,
                 return_full_pose=False, return_verts=True, get_skin=True, **kwargs):
         if args:
-            raise TypeError('pass SMPL inputs by keyword (global_orient=, body_pose=, betas=, ...) as the reference call sites do')
-        if (body_pose.requires_grad or betas.requires_grad) and torch.is_grad_enabled():
-            raise NotImplementedError('gradients w.r.t. body_pose / betas are not implemented (they are constants of the '
-                                      'global optimisation, global_recon_model.py:591-633)')
+            # smplx.SMPL.forward(betas, body_pose, global_orient, transl, ...): the positional order of the class the reference extends
+            names = ('betas', 'body_pose', 'global_orient')
+            if len(args) > len(names):
+                raise TypeError('SMPL.forward takes at most betas, body_pose, global_orient positionally (transl is not used by GLAMR)')
+            given = dict(zip(names, args))
+            betas = given.get('betas', betas)
+            body_pose = given.get('body_pose', body_pose)
+            global_orient = given.get('global_orient', global_orient)
+        general = bool((body_pose.requires_grad or betas.requires_grad or (root_trans is None and global_orient.requires_grad)) and torch.is_grad_enabled())
         pose = torch.cat([global_orient, body_pose], dim=1).float().contiguous()
         B = pose.shape[0]
         if betas.shape[0] != B:
@@ -194,7 +223,7 @@ class SMPL(nn.Module):
         betas = betas.float().contiguous()
         rt = root_trans.float().contiguous() if root_trans is not None else None
         rs = root_scale.float().contiguous() if root_scale is not None else None
-        verts, joints = _SmplFn.apply(self, pose, betas, rt, rs, bool(return_verts), bool(orig_joints))
+        verts, joints = _SmplFn.apply(self, pose, betas, rt, rs, bool(return_verts), bool(orig_joints), general)
         return ModelOutput(vertices=verts if return_verts else None, joints=joints, betas=betas, global_orient=global_orient,
                            body_pose=body_pose, full_pose=pose if return_full_pose else None)
 

@@ -72,6 +72,21 @@ int glamr_smpl_backward_root(glamr_smpl* h, int B, const float* pose, const floa
                              const float* verts, const float* joints, const float* g_verts, const float* g_joints,
                              float* g_orient, float* g_trans, float* g_scale, int flags, void* stream);
 
+/* GENERAL backward of glamr_smpl_forward: gradients w.r.t. the whole pose (global orientation + body pose), the shape coefficients, the
+ * root translation and scale, from gradients of the joints and / or the vertices -- what torch autograd gives through
+ * lib/models/smpl.py:289-316 and smplx.lbs (blend shapes, kinematic chain, skinning, joint regression, re-anchoring).  Needed when the
+ * body pose is itself a function of optimisation variables: the latent-optimisation mode (global_recon_model.py:434-437), where
+ * smpl_pose comes out of the motion infiller every iteration.  Works with and without root_trans (re-anchored / plain call).
+ * dev in : pose (B,72), betas (B,num_betas), root_trans (B,3) / root_scale (B) or NULL as in the forward call, g_verts (B,V,3) or NULL,
+ *          g_joints (B,n_out,3) or NULL (at least one); verts / joints = the forward outputs, only read when g_scale is requested.
+ * dev out: g_pose (B,72) or NULL, g_betas (B,num_betas) or NULL, g_trans (B,3) or NULL, g_scale (B) or NULL.
+ * Without g_verts the joints-only tiling (picked + virtual vertices) is walked, as in the forward.  Sums over vertex tiles are made in a
+ * fixed order (reproducible).  workspace: glamr_smpl_backward_workspace_bytes(h, B, g_verts != NULL). */
+size_t glamr_smpl_backward_workspace_bytes(const glamr_smpl* h, int B, int with_vertex_gradient);
+int glamr_smpl_backward(glamr_smpl* h, int B, const float* pose, const float* betas, const float* root_trans, const float* root_scale,
+                        const float* verts, const float* joints, const float* g_verts, const float* g_joints, float* g_pose,
+                        float* g_betas, float* g_trans, float* g_scale, int flags, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Motion priors -- replace MotionInfillerVAE.inference (motion_infiller/models/motion_infiller_vae.py:618-667),
  * TrajPredVAE.inference (traj_pred/models/traj_pred_vae.py:524-548) and MotionTrajJointModel.inference

@@ -402,7 +402,7 @@ def gen_full_cfg(cases=FULL_CASES, gaps=(True, False)):
     """FULL schedules (every stage to its last iteration) of the configurations gen_grecon pins for a handful of iterations only
     (VERDICT r2 item 1): BASELINE.json configs[3] (glamr_static_multi, 300 frames x 4 persons, 200 + 500 iterations, shared fixed
     camera, relative-transform term), glamr_3dpw (camera from the person's pose, two stages), glamr_dynamic_multi (per-frame camera, two
-    persons), and the remaining two shipped files.  Seed 3 = the inputs of the K-step fixtures.  With the synthetic detection gaps
+    persons), and the remaining two shipped files (seeds: FULL_CASES).  With the synthetic detection gaps
     (person p undetected in [100 + 37 p, 160 + 37 p)) and without.  The state after the FIRST stage is stored as well (`s1_` keys), so a
     difference can be attributed to a stage."""
     import time
@@ -476,6 +476,50 @@ def gen_full_family():
     np.savez_compressed(os.path.join(GOLD, 'full_glamr_dynamic_T300_family.npz'), **out)
 
 
+FAMILY_CFG = [('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-6_seed0', dict(eps=1e-6, seed=0)), ('eps1e-6_seed1', dict(eps=1e-6, seed=1))]
+
+
+def gen_full_family_cfg(cfg_id='glamr_dynamic_multi', T=300, P=2):
+    """The reference's own spread on a full-schedule case WITH detection gaps (as gen_full_family does for configs[1]): per-frame cameras of
+    frames the first person is not seen in start as zero matrices, and the result then hangs on the last bit of the first camera gradients.
+    Members: another intra-op thread count, initial cam_pose x (1 + eps U(-1, 1)) right before each stage's optimiser is created."""
+    import time
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    seed = FULL_SEED[(cfg_id, T, P)]
+    base = np.load(os.path.join(GOLD, full_name(cfg_id, T, P) + '.npz'))
+    out = {}
+    keep_threads = torch.get_num_threads()
+    for name, opt in FAMILY_CFG:
+        torch.set_num_threads(opt.get('threads', keep_threads))
+        model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+        in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=md)
+        keep = model.init_opt
+        done = []
+
+        def init_opt(data, opt_variables, opt_lr, keep=keep, opt=opt, done=done):
+            if opt.get('eps') and not done:          # once, before the first stage
+                rng = np.random.RandomState(opt['seed'])
+                cp = data['cam_pose']
+                cp.mul_(torch.from_numpy((1 + opt['eps'] * rng.uniform(-1, 1, tuple(cp.shape))).astype(np.float32)))
+                done.append(1)
+            return keep(data, opt_variables, opt_lr)
+        model.init_opt = init_opt
+        t0 = time.time()
+        data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, seed))
+        worst = 0.0
+        for pi in range(P):
+            kp = _np(data['person_data'][pi]['kp_2d_pred'])
+            out['%s_p%d_kp_2d_pred' % (name, pi)] = kp
+            d = np.abs(kp - base['p%d_kp_2d_pred' % pi])[base['p%d_vis_frames' % pi]].max(axis=(1, 2))
+            worst = max(worst, float(d.max()))
+        out[name + '_cam_pose'] = _np(data['cam_pose'])
+        print('family member %-16s %.0f s: max %.3f px from the committed golden' % (name, time.time() - t0, worst), flush=True)
+    torch.set_num_threads(keep_threads)
+    np.savez_compressed(os.path.join(GOLD, full_name(cfg_id, T, P) + '_family.npz'), **out)
+
+
 EVAL_CASES = [('glamr_dynamic', 300, 1, '3DPW'), ('glamr_static_multi', 120, 2, '')]
 
 
@@ -531,7 +575,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'eval': gen_eval}[name]()
         print('done', name)
 
 

@@ -206,7 +206,9 @@ def full_schedule_errors(out_persons, cam_pose, g, P, prefix=''):
 
 # Full schedules vs the unmodified reference (tests/golden/full_<cfg>_T300_P<P>[_nogap].npz), starting from the reference's own initial
 # state (the oracle's / the numpy init_data): bounds = (keypoints px, root in camera m) ~3 x achieved, MI355X / CPU runtime in the comment
-FULL_TOL = {}
+# CPU runtime (tests/test_grecon_hostsim.py), worst stage:        kp px   root m       achieved
+FULL_TOL_CPU = {('glamr_3dpw', True): (0.1, 1e-3),                            # 0.026   3.3e-4
+                ('glamr_dynamic_multi', False): (0.01, 5e-5)}                 # 0.0012  8.6e-6
 
 
 def check_full_schedule(runner, asset_root, golden, cfg_id, T, P, gap):

@@ -83,3 +83,17 @@ def test_arena_and_constant_layout_instances_equal_the_plain_one(asset_root):
     for k, ref in results[0].items():
         for other, what in ((results[1], 'arena'), (results[2], 'constant layout')):
             assert np.array_equal(ref, other[k]), (k, what, np.abs(ref - other[k]).max())
+
+
+@pytest.mark.parametrize('cfg_id,T,P,gap', [('glamr_3dpw', 300, 1, True), ('glamr_dynamic_multi', 300, 2, False)])
+def test_full_schedules_of_the_other_configs_follow_the_reference(asset_root, golden, cfg_id, T, P, gap):
+    """Every stage to its LAST iteration (200 + 500) from the oracle's initial state, on the CPU runtime of the kernel algorithm, against the
+    unmodified reference's result value by value (tests/golden/full_*.npz, oracle/make_golden.py gen_full_cfg): the two-stage schedules, the
+    camera derived from the person (glamr_3dpw) and the two-person per-frame-camera scene -- code paths the K-step fixtures only follow for
+    5-15 iterations (the round-1 Adam defect was invisible at K = 25 and showed at 500).  The MI355X twins of all ten cases are in
+    tests/test_e2e_gpu.py."""
+    report = gc.check_full_schedule(gc.hostsim_runner(), asset_root, golden, cfg_id, T, P, gap)
+    for stage, w in report:
+        print('%s %s: kp %.4f px, root in camera %.2e m, world root %.2e m, orientation %.2e' % (cfg_id, stage, w['kp'], w['root_cam'], w['root_world'], w['orient']))
+        tol_kp, tol_root = gc.FULL_TOL_CPU[(cfg_id, gap)]
+        assert w['kp'] < tol_kp and w['root_cam'] < tol_root and w['frames_over_1px'] == 0, (stage, w)

@@ -61,8 +61,14 @@ def test_port_speed_is_the_reference_speed(asset_root):
             model.optimize_main(data, spec['opt_variables'], spec['opt_lr'], n, spec['loss_cfg'], {'stage': 'init_opt'})
             return (time.time() - t0) / n
         block(port, pdata, 2), block(ref, rdata, 2)                      # warm-up
-        t_port = min(block(port, pdata) for _ in range(3))
-        t_ref = min(block(ref, rdata) for _ in range(3))
+        # blocks interleaved (a busy host slows both alike); a timing comparison says nothing when other jobs hold most of the cores
+        if os.getloadavg()[0] > 0.75 * (os.cpu_count() or 1):
+            pytest.skip('host busy (load %.1f on %d cores): no timing comparison' % (os.getloadavg()[0], os.cpu_count() or 1))
+        tp, tr = [], []
+        for _ in range(3):
+            tp.append(block(port, pdata))
+            tr.append(block(ref, rdata))
+        t_port, t_ref = min(tp), min(tr)
     finally:
         os.chdir(keep_cwd)
         torch.set_num_threads(keep_threads)

@@ -108,3 +108,56 @@ def test_smpl_backward_root(models):
     for r, g, name in zip(ref, got, ('orient', 'trans', 'scale')):
         scale_ = max(1.0, r.abs().max().item())
         assert (r - g).abs().max().item() / scale_ < 2e-4, name
+
+
+@pytest.mark.parametrize('variant', ['joints+verts anchored', 'joints only anchored', 'plain call', 'orig joints'])
+def test_smpl_backward_wrt_body_pose_and_betas(models, variant):
+    """The GENERAL backward (glamr_smpl_backward): gradients w.r.t. the whole pose, the shape coefficients, root translation and scale from
+    gradients of joints and vertices -- skinning, blend shapes, kinematic chain, joint regression and re-anchoring in reverse -- against
+    torch autograd through the CPU restatement (oracle/port/smpl.py over oracle/smplx_lbs.py).  Variants: the full mesh, the joints-only
+    tiling (picked + virtual vertices: what the latent-optimisation loop differentiates), the call without root_trans, the 24 chain joints."""
+    ora, mine, dev = models
+    B = 37
+    gen = torch.Generator().manual_seed(21)
+    body = torch.randn(B, 69, generator=gen) * 0.3
+    betas = torch.randn(B, 10, generator=gen)
+    orient = torch.randn(B, 3, generator=gen)
+    orient[0] = 0.0
+    body[1] = 0.0
+    trans = torch.randn(B, 3, generator=gen)
+    scale = torch.rand(B, generator=gen) + 0.5
+    anchored = 'anchored' in variant
+    with_verts = variant in ('joints+verts anchored', 'plain call')
+    orig = variant == 'orig joints'
+    wj = torch.randn(B, 24 if orig else 26, 3, generator=gen)
+    wv = torch.randn(B, 6890, 3, generator=gen) * 0.01
+
+    def run(model, d):
+        o, bp, be = (x.clone().to(d).requires_grad_(True) for x in (orient, body, betas))
+        t, s = trans.clone().to(d).requires_grad_(True), scale.clone().to(d).requires_grad_(True)
+        kw = dict(root_trans=t, root_scale=s) if anchored else {}
+        if orig:
+            kw = dict(root_trans=t, orig_joints=True)
+        if model is mine and not with_verts:
+            kw['return_verts'] = False
+        out = model(global_orient=o, body_pose=bp, betas=be, **kw)
+        loss = (out.joints * wj.to(d)).sum()
+        if with_verts:
+            loss = loss + (out.vertices * wv.to(d)).sum()
+        loss.backward()
+        grads = {'orient': o.grad, 'body_pose': bp.grad, 'betas': be.grad}
+        if anchored or orig:
+            grads['trans'] = t.grad
+        if anchored:
+            grads['scale'] = s.grad
+        return {k: v.cpu() for k, v in grads.items()}
+
+    ref = run(ora, torch.device('cpu'))
+    got = run(mine, dev)
+    for name, r in ref.items():
+        g = got[name]
+        assert g.shape == r.shape and torch.isfinite(g).all(), name
+        err = (r - g).abs().max().item() / max(1.0, r.abs().max().item())
+        print('%s: d/d%s relative error %.2e (largest %.2e)' % (variant, name, err, r.abs().max().item()))
+        assert err < 2e-4, (variant, name, err)
+    assert ref['body_pose'].abs().max() > 1e-3 and ref['betas'].abs().max() > 1e-3
