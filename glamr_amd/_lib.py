@@ -69,6 +69,9 @@ _SIGNATURES = {
     'glamr_nets_create': (c_int, [POINTER(c_void_p), c_void_p, POINTER(TensorDesc), c_int, c_void_p, POINTER(TensorDesc), c_int, c_void_p, c_void_p]),
     'glamr_nets_destroy': (c_int, [c_void_p]),
     'glamr_nets_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
+    'glamr_nets_tape_bytes': (c_size_t, [c_void_p, c_int, c_int]),
+    'glamr_nets_infill_taped': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3),
+    'glamr_nets_infill_backward': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 2 + [c_int] + [c_void_p] * 4),
     'glamr_nets_infer': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     'glamr_nets_infiller_window': (c_int, [c_void_p, c_int, c_int, POINTER(InfillerIO), c_void_p, c_void_p]),
     'glamr_nets_traj_clip': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(TrajIO), c_void_p, c_void_p]),

@@ -151,6 +151,7 @@ struct glamr_nets {
   // outlives the call
   int32_t* capture_lens = nullptr;
   size_t capture_lens_used = 0;
+  std::map<const Lin*, Lin> lin_T;      // transposed weights of the layers the infiller's backward multiplies with (nets_tape.inc), made on first use
 };
 constexpr size_t GRAPH_CACHE_MAX = 24, CAPTURE_LENS_INTS = 256 * 1024;
 
@@ -799,6 +800,8 @@ int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const
   return GLAMR_OK;
 }
 
+#include "nets_tape.hpp"
+
 void bilstm(glamr_nets* h, hipStream_t st, const float* G, float* const hh[2], const int* lens, float* H, int max_len, int B) {
   LstmArgs la{G, hh[0], hh[1], lens, H, max_len};
   // large batches: 16 sequences per workgroup on the matrix cores; small ones: one sequence per workgroup keeps every CU busy
@@ -1043,4 +1046,69 @@ extern "C" int glamr_traj_local_to_global(int B, int T, const float* local_traj,
 extern "C" size_t glamr_traj_local_to_global_workspace_bytes(int B, int T) {
   if (B <= 0 || T <= 0) return 0;
   return align_up((size_t)B * sizeof(int), 256) + (size_t)B * T * 14 * sizeof(float);
+}
+
+// ---- taped infiller: forward with every activation kept + backward w.r.t. the latent draws (latent-optimisation mode) -----------------
+extern "C" size_t glamr_nets_tape_bytes(const glamr_nets* h, int n_seq, int max_len) {
+  if (!h || n_seq <= 0 || max_len <= PAST) return 0;
+  return tape_layout(n_seq, max_len, nullptr).total;
+}
+
+namespace {
+int tape_windows(const int32_t* lens_host, int B, int max_len, int* n_win) {
+  int longest = 0;
+  for (int b = 0; b < B; ++b) {
+    GLAMR_REQUIRE(lens_host[b] > PAST && lens_host[b] <= max_len, "sequence %d has length %d (need %d < len <= max_len)", b, lens_host[b], PAST);
+    longest = std::max(longest, (int)lens_host[b]);
+  }
+  *n_win = (longest - PAST + CUR - 1) / CUR;
+  return GLAMR_OK;
+}
+}  // namespace
+
+extern "C" int glamr_nets_infill_taped(glamr_nets* h, int B, int max_len, const int32_t* lens_host, const float* body_pose, const float* visible,
+                                       const float* motion_eps, int n_win_max, float* out_pose, void* tape_, void* stream_) {
+  GLAMR_REQUIRE(h && lens_host && body_pose && visible && motion_eps && out_pose && tape_, "null argument");
+  GLAMR_REQUIRE(B > 0 && max_len > PAST, "need n_seq > 0 and max_len > %d", PAST);
+  int n_win = 0;
+  RC(tape_windows(lens_host, B, max_len, &n_win));
+  GLAMR_REQUIRE(n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  Tape t = tape_layout(B, max_len, static_cast<char*>(tape_));
+  GLAMR_HIP_CHECK(hipMemcpyAsync(t.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(pose_in_kernel, dim3(B, t.Tpad), dim3(XLD), 0, st, body_pose, max_len, t.Tpad, t.pose);
+  for (int i = 0; i < n_win; ++i) {
+    WinTape& w = t.win[i];
+    const int s = i * CUR;
+    hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(XLD), 0, st, t.pose, visible, t.lens, t.Tpad, max_len, s, w.x, w.mask);
+    RC(taped_window(h, st, w, B, motion_eps + (size_t)i * NZ, n_win_max * NZ));
+    hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(XLD), 0, st, w.y, 128, t.lens, t.Tpad, s, t.pose);
+  }
+  hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(XLD), 0, st, t.pose, max_len, t.Tpad, t.lens, out_pose);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_nets_infill_backward(glamr_nets* h, int B, int max_len, const int32_t* lens_host, const float* motion_eps, int n_win_max,
+                                          const float* g_out_pose, float* g_motion_eps, void* tape_, void* stream_) {
+  GLAMR_REQUIRE(h && lens_host && motion_eps && g_out_pose && g_motion_eps && tape_, "null argument");
+  GLAMR_REQUIRE(B > 0 && max_len > PAST, "need n_seq > 0 and max_len > %d", PAST);
+  int n_win = 0;
+  RC(tape_windows(lens_host, B, max_len, &n_win));
+  GLAMR_REQUIRE(n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  Tape t = tape_layout(B, max_len, static_cast<char*>(tape_));
+  GLAMR_HIP_CHECK(hipMemsetAsync(t.pose + t.values, 0, t.values * sizeof(float), st));            // every gradient starts at zero
+  GLAMR_HIP_CHECK(hipMemsetAsync(g_motion_eps, 0, (size_t)B * n_win_max * NZ * sizeof(float), st));
+  TapeCtx c{h, st, &t};
+  hipLaunchKernelGGL(pose_out_bwd_kernel, dim3(B, t.Tpad), dim3(XLD), 0, st, g_out_pose, max_len, t.Tpad, t.lens, GR(t, t.pose));
+  for (int i = n_win - 1; i >= 0; --i) {
+    const WinTape& w = t.win[i];
+    const int s = i * CUR;
+    hipLaunchKernelGGL(window_scatter_bwd_kernel, dim3(B, CUR), dim3(XLD), 0, st, GR(t, t.pose), t.lens, t.Tpad, s, GR(t, w.y), 128);
+    RC(taped_window_bwd(c, w, B, motion_eps + (size_t)i * NZ, n_win_max * NZ, g_motion_eps + (size_t)i * NZ, n_win_max * NZ));
+    hipLaunchKernelGGL(window_gather_bwd_kernel, dim3(B, WIN), dim3(XLD), 0, st, GR(t, w.x), t.lens, t.Tpad, s, GR(t, t.pose));
+  }
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
 }

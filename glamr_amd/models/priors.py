@@ -117,6 +117,30 @@ class MotionPriorsHandle:
         return out
 
 
+    # -- the infiller inside an optimisation loop (latent-optimisation mode) ----------------------------------------------------------------
+    def infill_taped(self, body_pose, visible, lens, motion_eps):
+        """The infiller half of infer() with every activation kept: returns (out_pose (B,T,69), tape).  `tape` goes to infill_backward."""
+        L = _lib.lib()
+        B, T = body_pose.shape[:2]
+        dev = body_pose.device
+        body_pose, visible, motion_eps = body_pose.float().contiguous(), visible.float().contiguous(), motion_eps.float().contiguous()
+        lens_np = np.ascontiguousarray(lens, dtype=np.int32)
+        out_pose = torch.empty((B, T, 69), device=dev)
+        buf = torch.empty(L.glamr_nets_tape_bytes(self.h, B, T), dtype=torch.uint8, device=dev)
+        _lib.check(L.glamr_nets_infill_taped(self.h, B, T, _lib.ptr(lens_np), _lib.ptr(body_pose), _lib.ptr(visible), _lib.ptr(motion_eps), motion_eps.shape[1],
+                                             _lib.ptr(out_pose), _lib.ptr(buf), _lib.current_stream()))
+        return out_pose, {'buf': buf, 'lens': lens_np, 'eps': motion_eps, 'B': B, 'T': T}
+
+    def infill_backward(self, tape, g_out_pose):
+        """dL/d motion_eps (B, n_win_max, 128) for dL/d out_pose (B,T,69) of the taped call."""
+        L = _lib.lib()
+        eps = tape['eps']
+        g_out_pose = g_out_pose.float().contiguous()
+        g_eps = torch.empty_like(eps)
+        _lib.check(L.glamr_nets_infill_backward(self.h, tape['B'], tape['T'], _lib.ptr(tape['lens']), _lib.ptr(eps), eps.shape[1], _lib.ptr(g_out_pose),
+                                                _lib.ptr(g_eps), _lib.ptr(tape['buf']), _lib.current_stream()))
+        return g_eps
+
     # -- training-mode / reconstruction passes (forward(data), inference(recon=True)) -----------------------------------------------------
     def infiller_window(self, mode, in_body_pose, frame_mask, eps=None, body_pose=None, want_context=True):
         """One 50-frame window per sequence through context encoder, (posterior encoder,) prior and decoder.  in_body_pose / body_pose

@@ -125,6 +125,20 @@ int glamr_nets_infer(glamr_nets* h, int n_seq, int max_len, const int32_t* lens,
                      float* out_pose, float* out_local_traj, float* out_trans, float* out_orient,
                      int flags, void* workspace, void* stream);
 
+/* The infiller INSIDE an optimisation loop (latent-optimisation mode, global_recon_model.py:43-44,155-158,434-437: `motion_latent` is a
+ * parameter and infer_motion_traj runs every iteration).  glamr_nets_infill_taped is the infiller half of glamr_nets_infer with every
+ * activation of every window kept in `tape` (glamr_nets_tape_bytes: ~4 MB per window and sequence, values + gradients);
+ * glamr_nets_infill_backward then gives dL/d motion_eps (n_seq, n_win_max, 128) for a gradient g_out_pose (n_seq, max_len, 69) of the
+ * generated body pose -- what torch autograd returns for `in_motion_latent` through MotionInfillerVAE.inference_multi_step (:618-632):
+ * decoder, reparameterisation, prior and context encoder of every window and the autoregression between windows (:604-607).  Weights are
+ * constants.  (The trajectory predictor needs no backward: get_pred_trajectory_base :396 detaches its output.)  lens / motion_eps must
+ * be the ones of the taped call. */
+size_t glamr_nets_tape_bytes(const glamr_nets* h, int n_seq, int max_len);
+int glamr_nets_infill_taped(glamr_nets* h, int n_seq, int max_len, const int32_t* lens, const float* body_pose, const float* visible,
+                            const float* motion_eps, int n_win_max, float* out_pose, void* tape, void* stream);
+int glamr_nets_infill_backward(glamr_nets* h, int n_seq, int max_len, const int32_t* lens, const float* motion_eps, int n_win_max,
+                               const float* g_out_pose, float* g_motion_eps, void* tape, void* stream);
+
 /* Training-mode / reconstruction passes of the two VAEs -- what `forward(data)` and `inference(recon=True)` run:
  *   MotionInfillerVAE.forward  motion_infiller/models/motion_infiller_vae.py:478-482 = ContextEncoder :92-123, DataEncoder (posterior)
  *                              :126-249, DataDecoder in mode 'train' / 'recon' / 'infer' :345-433; one-shot inference :659-666

@@ -146,6 +146,31 @@ def gen_nets():
 
 
 
+def latent_loss_weights(T, seed=0):
+    """Fixed weights of the scalar the latent-gradient fixtures differentiate: L = sum(W * infer_out_body_pose)."""
+    return np.random.default_rng(31337 + seed + T).normal(size=(T, 69)).astype(np.float32)
+
+
+def gen_nets_latent():
+    """d L / d in_motion_latent through MotionInfillerVAE.inference(multi_step=True) of the unmodified reference (torch autograd through all
+    windows and the autoregression between them): what the latent-optimisation mode differentiates (global_recon_model.py:434-437)."""
+    from oracle import ref_harness as rh
+    model, _ = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
+    inf = model.mt_model.mfiller
+    out = {}
+    for T in (120, 300):
+        b = {k: torch.tensor(v) for k, v in net_inputs(T).items()}
+        lat = b['in_motion_latent'].clone().requires_grad_(True)
+        d = inf.inference({'in_body_pose': b['in_body_pose'], 'frame_mask': b['frame_mask'], 'in_motion_latent': lat}, sample_num=1, multi_step=True)
+        pose = d['infer_out_body_pose'][0, 0]
+        loss = (pose * torch.tensor(latent_loss_weights(T))).sum()
+        loss.backward()
+        out['T%d_body_pose' % T] = _np(pose)
+        out['T%d_grad_latent' % T] = _np(lat.grad)
+        print('T=%d: |dL/dlatent| max %.3e per window %s' % (T, float(lat.grad.abs().max()), [round(float(x), 4) for x in lat.grad.abs().amax(dim=1)]))
+    np.savez_compressed(os.path.join(GOLD, 'nets_latent.npz'), **out)
+
+
 def train_inputs(seed=0):
     """Training-style batches (AMASS layout, amass_dataset.py:65-67): the infiller sees ONE 50-frame window (:478-482 runs on an
     initialised window), the trajectory predictor a 100-frame clip with root translation and orientation."""
@@ -575,7 +600,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'eval': gen_eval}[name]()
         print('done', name)
 
 

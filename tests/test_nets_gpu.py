@@ -280,3 +280,43 @@ def test_handle_close_releases_device_memory(asset_root, priors):
     free1 = torch.cuda.mem_get_info(dev)[0]
     assert free0 - free1 < 8 << 20, 'three create / close cycles kept %.1f MB' % ((free0 - free1) / 2**20)
     assert torch.isfinite(priors.infer(pose, vis, [120, 120], motion_eps=meps, traj_eps=teps)['pose']).all()
+
+
+@pytest.mark.parametrize('T', [120, 300])
+def test_infiller_gradient_wrt_the_latent_matches_reference_autograd(priors, golden, T):
+    """The infiller INSIDE an optimisation loop (latent-optimisation mode, global_recon_model.py:434-437): glamr_nets_infill_taped reproduces
+    the inference output, and glamr_nets_infill_backward the gradient torch autograd gives for `in_motion_latent` through every window's
+    decoder, reparameterisation, prior and context encoder and through the autoregression between windows -- against the unmodified
+    reference (tests/golden/nets_latent.npz; L = sum(W * infer_out_body_pose))."""
+    g = golden('nets_latent')
+    dev = torch.device('cuda:0')
+    b = {k: torch.tensor(v, device=dev) for k, v in mg.net_inputs(T).items()}
+    eps = b['in_motion_latent'][None]
+    pose, tape = priors.infill_taped(b['in_body_pose'], b['frame_mask'], [T], eps)
+    plain = priors.infer(b['in_body_pose'], b['frame_mask'], [T], motion_eps=eps, traj_eps=None, traj=False)['pose']
+    assert _err(pose.cpu(), plain.cpu()) < 2e-5                                   # same network, unfused launch sequence
+    assert _err(pose[0].cpu(), g['T%d_body_pose' % T]) < 1e-4
+    W = torch.tensor(mg.latent_loss_weights(T), device=dev)[None]
+    grad = priors.infill_backward(tape, W)[0].cpu().numpy()
+    ref = g['T%d_grad_latent' % T]
+    err = np.abs(grad - ref).max()
+    print('d/d motion_latent, T=%d (%d windows): max abs err %.2e (largest gradient %.3f)' % (T, ref.shape[0], err, np.abs(ref).max()))
+    assert grad.shape == ref.shape and err < 2e-4 * max(1.0, np.abs(ref).max())
+    # two different sequences in one batch: each gets the gradient it gets alone
+    b2 = {k: torch.tensor(v, device=dev) for k, v in mg.net_inputs(T - 37, seed=1).items()}
+    pose_in = torch.zeros(2, T, 69, device=dev)
+    vis = torch.zeros(2, T, device=dev)
+    pose_in[0], vis[0] = b['in_body_pose'][0], b['frame_mask'][0]
+    pose_in[1, :T - 37], vis[1, :T - 37] = b2['in_body_pose'][0], b2['frame_mask'][0]
+    eps2 = torch.zeros(2, eps.shape[1], 128, device=dev)
+    eps2[0] = eps[0]
+    eps2[1, :b2['in_motion_latent'].shape[0]] = b2['in_motion_latent']
+    _, tape2 = priors.infill_taped(pose_in, vis, [T, T - 37], eps2)
+    W2 = torch.zeros(2, T, 69, device=dev)
+    W2[0] = W[0]
+    W2[1, :T - 37] = W[0, :T - 37]
+    both = priors.infill_backward(tape2, W2).cpu().numpy()
+    assert np.abs(both[0] - grad).max() < 1e-5
+    _, tape_b = priors.infill_taped(b2['in_body_pose'], b2['frame_mask'], [T - 37], b2['in_motion_latent'][None])
+    alone = priors.infill_backward(tape_b, W[:, :T - 37].contiguous())[0].cpu().numpy()
+    assert np.abs(both[1, :alone.shape[0]] - alone).max() < 1e-5
