@@ -75,6 +75,7 @@ struct PersonState {
   float* orient_world; float* trans_world;  // [T][3] outputs, written by the last evaluation
   float* g_theta; float* g_xy;        // [T], [T][2]
   float* kp_2d_pred; float* orient_cam_in_world;   // outputs
+  float* g_j_local;                   // [T][NJ][3] output of the last evaluation: dL/d j_local, or null (glamr_scene_batch.g_j_local)
   float* kp_wsum;                     // [NJ] sum over visible frames of thresholded score^2
   float* Lc;                          // [12][T] cached trajectory row of frame t (dx dy z r6[6] h), written in phase A
   float* kpc;                         // [njc][6][T] compact keypoint data of the scored joints: j_local(3) target(2) weight(1)
@@ -168,7 +169,7 @@ struct PersonView {      // what the iteration loop needs of PersonConst + Perso
   int fr_start, fr_end, njc, njc_fast, frozen;      // (a frozen person's existing range is EMPTY here: every frame takes the given pose)
   const float *vis, *j_local, *kp_2d, *kp_score, *cam_K, *prior, *base_orient, *base_trans, *person2cam, *dheading_mask, *h_prior, *oc6, *kp_wsum;
   const int* vis_rank;
-  float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc;
+  float *p, *m, *v, *g, *theta, *csn, *xy, *d6, *tw, *g_d6, *g_tw, *orient_world, *trans_world, *g_theta, *g_xy, *kp_2d_pred, *orient_cam_in_world, *Lc, *g_j_local;
   const float *kpc, *kpc_ws;
 };
 struct SceneView {
@@ -431,6 +432,7 @@ GLAMR_HD PersonView person_view(RT& rt, const Scene& sc, int p) {
   w.fr_start = w.frozen ? 0 : uni(c.fr_start); w.fr_end = w.frozen ? 0 : uni(c.fr_end); w.njc = uni(s.njc); w.njc_fast = uni(s.njc_fast);
   w.j_local = glob(c.j_local); w.kp_2d = glob(c.kp_2d); w.kp_score = glob(c.kp_score);      // last evaluation only
   w.orient_world = glob(s.orient_world); w.trans_world = glob(s.trans_world); w.kp_2d_pred = glob(s.kp_2d_pred); w.orient_cam_in_world = glob(s.orient_cam_in_world);
+  w.g_j_local = glob(s.g_j_local);
   if constexpr (TMC > 0) {
     constexpr SceneOff o = scene_offsets(1, TMC, true, 1);
     constexpr PersonOff q = o.ps[0];
@@ -540,6 +542,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
     s.trans_world = b.trans_world + slot * TM * 3;
     s.kp_2d_pred = b.kp_2d_pred + slot * TM * NJ * 2;
     s.orient_cam_in_world = b.orient_cam_in_world + slot * TM * 3;
+    s.g_j_local = b.g_j_local ? b.g_j_local + slot * TM * NJ * 3 : nullptr;
   }
   sc.fast_free = fast ? fast + o.fast_end : nullptr;
   sc.fast_left = fast ? fast_floats - (size_t)o.fast_end : 0;
@@ -1088,6 +1091,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
               for (int k = 0; k < 3; ++k) gH[i * 3 + k] += gh[i] * jl[k];
               gq[i] += gh[i];
             }
+            if (last && jout >= 0 && s.g_j_local)                                        // h = H jl + q: dL/d jl = H^T gh
+              for (int k = 0; k < 3; ++k) s.g_j_local[((size_t)t * NJ + jout) * 3 + k] = H[0 * 3 + k] * gh[0] + H[1 * 3 + k] * gh[1] + H[2 * 3 + k] * gh[2];
           };
           // dL/dH, dL/dq -> camera [Rc | tc], world rotation Rs, world translation tw
           auto push_back = [&]() {
@@ -1106,6 +1111,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             }
           };
           if (last) {
+            if (s.g_j_local) for (int k = 0; k < NJ * 3; ++k) s.g_j_local[(size_t)t * NJ * 3 + k] = 0.f;
             // all 26 joints from the full arrays: the projections are an output (kp_2d_pred) and feed the monitor term
             for (int j = 0; j < NJ; ++j) {
               const float sc_raw = c.kp_score[(size_t)t * NJ + j];

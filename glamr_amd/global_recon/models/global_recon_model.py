@@ -150,12 +150,15 @@ class GlobalReconOptimizer:
                 or not g('flag_opt_traj', True) or not g('flag_infill_motion', True):
             raise NotImplementedError('only est_type=hybrik with motion infilling + trajectory prediction + trajectory optimisation '
                                       '(every shipped config) is supported')
-        for flag in ('flag_opt_motion_latent', 'flag_opt_traj_latent', 'flag_opt_vis_local_rot', 'flag_opt_person2cam_rot',
+        for flag in ('flag_opt_vis_local_rot', 'flag_opt_person2cam_rot',
                      'flag_opt_person2cam_trans', 'flag_make_invis_with_keypoint', 'flag_traj_from_cam', 'flag_use_pen_loss', 'absolute_heading'):
             if g(flag, False):
                 raise NotImplementedError('%s is not supported by the MI355X path' % flag)
         if g('heading_type', 'scalar') != 'scalar' or not g('flag_cam_inv_trans_res_all', True) or not g('flag_opt_cam', True):
             raise NotImplementedError('unsupported grecon_model_specs')
+        # latent-optimisation mode (:43-44,155-158,434-437,619-622): the priors run INSIDE the Adam loop and the latent draws are parameters
+        self.flag_opt_motion_latent = bool(g('flag_opt_motion_latent', False))
+        self.flag_opt_traj_latent = bool(g('flag_opt_traj_latent', False))
         self.flag_filter_pose = g('flag_filter_pose', True)
         self.flag_init_cam_all_frames = g('flag_init_cam_all_frames', False)
         self.cam_fix_frames = [tuple(x) for x in g('cam_fix_frames', [[0, None]])]
@@ -561,6 +564,7 @@ class GlobalReconOptimizer:
             meps = rin.meps if rin.meps is not None else torch.randn((n_slots, nw, NZ), device=dev)
             teps = rin.teps if rin.teps is not None else torch.randn((n_slots, NZ), device=dev)
         out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps, buffers=rs)
+        packed.latents = (meps, teps)                                  # the draws this batch was initialised with (parameters in latent-optimisation mode)
         _lib.check(L.glamr_init_scenes(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
                                        _lib.ptr(out['orient']), _lib.ptr(ws), st))
         # root-relative joints of every frame, cached for the whole optimisation
@@ -762,9 +766,97 @@ class GlobalReconOptimizer:
     def optimize_resident(self, rin, max_iters=None):
         """HBM in, HBM out: init_data + the full schedule on a ResidentInputs batch.  Returns (datas, packed) with every result
         (optimised variables, world trajectories, projections, camera) in packed.t on the device; collect() brings them to the host."""
+        if self.latent_mode:
+            datas, packed = self.init_resident(rin, init_forward=True)
+            self.run_latent_schedule(rin, packed, max_iters)
+            return datas, packed
         datas, packed = self.init_resident(rin, init_forward=not self._schedule_overwrites_init())
         self.run_schedule(packed, max_iters)
         return datas, packed
+
+    @property
+    def latent_mode(self):
+        return self.flag_opt_motion_latent or self.flag_opt_traj_latent
+
+    def run_latent_schedule(self, rin, packed, max_iters=None):
+        """The staged optimisation in LATENT-OPTIMISATION mode (flag_opt_motion_latent / flag_opt_traj_latent; :155-158,434-437,619-622).
+        Every iteration from `opt_latent_start_iter` on re-runs infer_motion_traj with the current latents (:352-392): the infiller's output
+        becomes `smpl_pose`, the trajectory predictor's local trajectory the new `traj_local_pred`, and SMPL gives new joints; the loss
+        reaches `motion_latent` through the reprojection term -> joints -> SMPL (body pose) -> infiller (all windows, autoregressively).
+        `traj_latent` is in the parameter list but never receives a gradient: get_pred_trajectory_base detaches traj_local_pred (:396), and
+        torch.optim.Adam skips a parameter whose grad is None -- its value stays, exactly as in the reference.
+        Launch by launch over the C ABI: taped infiller (glamr_nets_infill_taped), trajectory predictor (glamr_nets_infer), joints-only
+        skinning, one gradient launch of the stage kernel (niters 1, lr 0, grads_out, g_j_local), glamr_smpl_backward, glamr_nets_infill_backward,
+        glamr_adam_step on the scene parameters and on the latents (torch.optim.Adam's arithmetic; a parameter's step count advances only
+        when it has a gradient)."""
+        import ctypes
+        from ... import parallel
+        dev, L = self.device, _lib.lib()
+        S, P, T = packed.S, packed.P, packed.T
+        n_slots = S * P
+        meps, teps = packed.latents
+        meps, teps = meps.clone(), teps.clone()
+        pa = packed.person_arrays
+        h = self.mt_model.handle
+        lens = np.ascontiguousarray(rin.lens, dtype=np.int32)
+        fr_start = packed.t['fr_start'].cpu().numpy()
+        occupied = rin.seq_len_slot.cpu().numpy() > 0                    # (person slots a scene with fewer persons leaves empty are skipped)
+        rows = [(k, int(fr_start[k]), int(lens[k])) for k in range(n_slots) if occupied[k]]
+        smpl_h = self.smpl._handle(dev)
+        zeros3 = torch.zeros((n_slots * T, 3), device=dev)
+        packed.t['g_j_local'] = torch.zeros((n_slots, T, packing.NJ, 3), device=dev)
+        params = packed.t['params']
+        m_lat, v_lat, lat_step = torch.zeros_like(meps), torch.zeros_like(meps), 0
+        has_wd = False
+        for stage, spec in self.opt_stage_specs.items():
+            n = spec['opt_niters'] if max_iters is None else min(max_iters, spec['opt_niters'])
+            start = spec.get('opt_latent_start_iter', 0)                 # optimize() :581
+            m, v = torch.zeros_like(params), torch.zeros_like(params)
+            m_lat.zero_(); v_lat.zero_(); lat_step = 0                   # init_opt creates a fresh optimiser per stage (:635-644)
+            for it in range(n):
+                tape = None
+                if it >= start:
+                    # infer_motion_traj with the current latents (:352-392)
+                    pose_out, tape = h.infill_taped(pa['nets_pose'], pa['nets_vis'], lens, meps)
+                    tr = h.infer(pose_out, None, lens, traj_eps=teps, infill=False, traj=True)
+                    for k, fs, nk in rows:
+                        pa['smpl_pose'][k, fs:fs + nk] = pose_out[k, :nk]
+                        packed.t['traj_local_pred'][k, :nk] = tr['local_traj'][k, :nk]
+                    with torch.no_grad():
+                        jl = self.smpl(global_orient=zeros3, body_pose=pa['smpl_pose'].view(-1, 69), betas=pa['smpl_beta'].view(-1, 10), root_trans=zeros3,
+                                       return_verts=False).joints
+                    packed.t['j_local'] = jl.view(n_slots, T, packing.NJ, 3)
+                sd = packing.stage_desc(spec, self.specs, has_wd, niters=1)
+                sd.lr = 0.0
+                if it > 0:
+                    sd.flags |= packing.FLAG_KEEP_CAM_PARAMS
+                grads = parallel._device_run_stage(packed, sd, True)
+                if tape is not None and self.flag_opt_motion_latent:
+                    # dL/d j_local -> body pose (skinning, blend shapes, chain, re-anchoring in reverse) -> latents (all windows)
+                    pose72 = torch.cat([zeros3, pa['smpl_pose'].view(-1, 69)], dim=1).contiguous()
+                    g_pose = torch.empty((n_slots * T, 72), device=dev)
+                    ws = torch.empty(L.glamr_smpl_backward_workspace_bytes(smpl_h, n_slots * T, 0), dtype=torch.uint8, device=dev)
+                    _lib.check(L.glamr_smpl_backward(smpl_h, n_slots * T, _lib.ptr(pose72), _lib.ptr(pa['smpl_beta'].view(-1, 10)), _lib.ptr(zeros3), None, None, None,
+                                                     None, _lib.ptr(packed.t['g_j_local']), _lib.ptr(g_pose), None, None, None, 0, _lib.ptr(ws), _lib.current_stream()))
+                    g_body = g_pose.view(n_slots, T, 72)[:, :, 3:]
+                    g_out = torch.zeros((n_slots, T, 69), device=dev)
+                    for k, fs, nk in rows:
+                        g_out[k, :nk] = g_body[k, fs:fs + nk]
+                    g_lat = h.infill_backward(tape, g_out)
+                    if getattr(self, 'latent_trace', None) is not None and not self.latent_trace:      # first gradient of the run, for the parity tests
+                        self.latent_trace.update(g_motion_latent=g_lat.detach().cpu().numpy(), losses=packed.t['losses'].detach().cpu().numpy(),
+                                                 smpl_pose=pa['smpl_pose'].detach().cpu().numpy(), traj_local_pred=packed.t['traj_local_pred'].detach().cpu().numpy())
+                    lat_step += 1
+                    parallel._device_adam_step(meps.view(-1), m_lat.view(-1), v_lat.view(-1), g_lat.view(-1), spec['opt_lr'], lat_step)
+                parallel._device_adam_step(params.view(-1), m.view(-1), v.view(-1), grads.view(-1), spec['opt_lr'], it + 1)
+            has_wd = has_wd or 'world_dheading' in spec['opt_variables']
+            if spec.get('reinitialize_cam', False):
+                packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
+        packed.has_world_dheading = has_wd
+        packed.stage_ws = []
+        packed.latents = (meps, teps)
+        packed.t['g_j_local'] = None
+        return packed
 
     def collect(self, datas, packed, fetched=None):
         """Device arrays -> the reference's output dictionaries (numpy): one device->host copy per array.  Waits for this batch only."""
@@ -782,6 +874,14 @@ class GlobalReconOptimizer:
             all_vars = self._all_vars()
             packed.unpack_into(datas, {'opt_variables': all_vars} if self.opt_stage_specs else None, self.specs, as_torch=False)
             self.last_losses = packed.t['losses'].cpu().numpy()
+        if self.latent_mode and getattr(packed, 'latents', None) is not None and rin is not None:
+            # the optimised draws, per person as the reference keeps them in pose_dict (:155-158)
+            meps, teps = (x.detach().cpu().numpy() for x in packed.latents)
+            for si, d in enumerate(datas):
+                for pi, idx in enumerate(packed.person_ids[si]):
+                    k = si * packed.P + pi
+                    d['person_data'][idx]['motion_latent'] = meps[k, :num_windows(int(rin.lens[k]))].copy()
+                    d['person_data'][idx]['traj_latent'] = teps[k][None].copy()
         if getattr(self, 'kernel_ms', None) is not None and getattr(packed, 'stage_ws', None):
             self.kernel_ms.extend(self.launch_ms(ws) for ws in packed.stage_ws)
         self.timings['unpack'] = time.time() - t0
@@ -827,6 +927,12 @@ class GlobalReconOptimizer:
 
     def optimize_batch(self, in_dicts, latents=None, max_iters=None):
         """Host dictionaries in, host dictionaries out (optimize() of the reference for a batch of independent sequences)."""
+        if self.latent_mode:
+            if self.cam_fix_frames != [(0, None)]:
+                raise NotImplementedError('latent-optimisation mode with non-default cam_fix_frames')
+            rin = self.stage_inputs(in_dicts, latents)
+            datas, packed = self.optimize_resident(rin, max_iters)
+            return self.collect(datas, packed)
         datas, packed = self.init_data_batch(in_dicts, latents, init_forward=not self._schedule_overwrites_init())
         t0 = time.time()
         self.run_schedule(packed, max_iters)

@@ -273,6 +273,10 @@ typedef struct glamr_scene_batch {
    * relative-transform pairs, the camera average and every normaliser (vis, fr_start, fr_end must be its own), has no residuals of its
    * own, receives no gradient and its outputs are not written.  NULL = nobody is frozen. */
   const int32_t* frozen;                 /* (slots) or NULL */
+  /* out, optional: gradient of the (weighted, normalised) loss of the LAST evaluation w.r.t. the cached joints j_local -- the hand-over to
+   * glamr_smpl_backward when the body pose itself depends on optimisation variables (latent-optimisation mode, global_recon_model.py:434-437).
+   * Only the reprojection term reaches the joints; rows of joints without weight and of invisible frames are zero. */
+  float* g_j_local;                      /* (slots, max_len, n_joints, 3) or NULL */
 } glamr_scene_batch;
 
 /* Offsets (in floats) of each variable block inside one scene's parameter vector; see glamr_grecon_param_layout().

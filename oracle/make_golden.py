@@ -414,6 +414,68 @@ def gen_full(which=('gap', 'nogap')):
 # (|projection| < 3000 px after init_data).  The synthetic checkpoints are random-initialised, so the predicted trajectories wander and in
 # most seeds somebody walks through the camera plane of the estimate (projections of 1e6 px, gradients that are rounding noise): seed 3
 # with 4 persons is such a scene -- the reference's own 700-iteration result there is not reproducible to better than metres.
+LATENT_CASES = [('glamr_dynamic', 100, 1, 12), ('glamr_static', 130, 1, 8)]
+
+
+def gen_grecon_latent(cases=LATENT_CASES):
+    """LATENT-OPTIMISATION mode of the unmodified reference (flag_opt_motion_latent = flag_opt_traj_latent = True,
+    global_recon_model.py:43-44,155-158,434-437,619-622): the priors run inside the Adam loop, `motion_latent` / `traj_latent` are parameters.
+    Stored: the first iteration's gradients (the latents' included: traj_latent's is None in the reference -- get_pred_trajectory_base :396
+    detaches the predicted trajectory -- stored as zeros) and the state after K iterations of every stage (opt_latent_start_iter 0, as
+    optimize() :581 passes it)."""
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    for cfg_id, T, P, K in cases:
+        model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+        model.flag_opt_motion_latent = model.flag_opt_traj_latent = True
+        in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md)
+        latents = latents_for(in_dict, 3)
+        mt = model.mt_model
+        order = iter(sorted(latents.keys()))
+        state = {}
+
+        def motion_latent(seq_len, order=order, state=state, latents=latents):
+            state['idx'] = next(order)
+            return torch.tensor(latents[state['idx']]['motion'])
+
+        def traj_latent(seq_len, state=state, latents=latents):
+            return torch.tensor(latents[state['idx']]['traj'])
+        mt.get_motion_latent, mt.get_traj_latent = motion_latent, traj_latent
+        data = model.init_data(in_dict)
+        out = {'init_' + k: v for k, v in _flatten_state(data, PERSON_KEYS_INIT, TOP_KEYS).items()}
+        for si, (stage, spec) in enumerate(cfg.opt_stage_specs.items()):
+            meta = {'stage': stage, 'opt_latent_start_iter': spec.get('opt_latent_start_iter', 0)}
+            if si == 0:
+                params = model.get_parameter(data, spec['opt_variables'])
+                for p in params:
+                    p.requires_grad_(True)
+                    p.grad = None
+                model.cur_iter = 0
+                model.forward(data, spec['opt_variables'], meta)
+                loss, ld, lud = model.compute_loss(data, spec['loss_cfg'])
+                loss.backward()
+                out['%s_loss_total' % stage] = _np(loss)
+                for name, v in lud.items():
+                    out['%s_loss_%s' % (stage, name)] = _np(torch.as_tensor(v))
+                for idx, pd in data['person_data'].items():
+                    for key in ('motion_latent', 'traj_latent'):
+                        g = pd[key].grad
+                        out['%s_grad_p%d_%s' % (stage, idx, key)] = _np(g) if g is not None else np.zeros(tuple(pd[key].shape), np.float32)
+                        out['%s_gradnone_p%d_%s' % (stage, idx, key)] = np.array(g is None)
+                    out['%s_fwd_p%d_smpl_pose' % (stage, idx)] = _np(pd['smpl_pose'])
+                    out['%s_fwd_p%d_traj_local_pred' % (stage, idx)] = _np(pd['traj_local_pred'])
+                for p in params:
+                    p.requires_grad_(False)
+                    p.grad = None
+            model.optimize_main(data, spec['opt_variables'], spec['opt_lr'], min(K, spec['opt_niters']), spec['loss_cfg'], meta)
+        keys = PERSON_KEYS_OPT + ['smpl_pose', 'traj_local_pred', 'motion_latent', 'traj_latent']
+        out.update({'opt_' + k: v for k, v in _flatten_state(data, keys, TOP_KEYS).items()})
+        out['niters'] = np.array(K)
+        np.savez_compressed(os.path.join(GOLD, 'grecon_latent_%s_T%d_P%d.npz' % (cfg_id, T, P)), **out)
+        print('wrote latent case', cfg_id, T, P, {k: float(np.abs(v).max()) for k, v in out.items() if '_grad_' in k})
+
+
 FULL_CASES = [('glamr_3dpw', 300, 1, 4), ('glamr_dynamic_multi', 300, 2, 3), ('glamr_static_multi', 300, 4, 38), ('glamr_static', 300, 1, 4),
               ('glamr_h36m', 300, 2, 4)]
 FULL_SEED = {(c, T, P): s for c, T, P, s in FULL_CASES}
@@ -600,7 +662,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'eval': gen_eval}[name]()
         print('done', name)
 
 

@@ -459,6 +459,9 @@ FULL_TOL_GPU = {                                                              # 
     ('glamr_3dpw', 1, True): (0.1, 1e-3),                                     # 0.027 px   3.4e-4 m
     ('glamr_dynamic_multi', 2, False): (0.01, 5e-5),                          # 0.0016 px  8.6e-6 m
     ('glamr_static_multi', 4, True): (0.05, 2e-4),                            # 0.0147 px  5.4e-5 m   BASELINE configs[3]
+    ('glamr_static_multi', 4, False): (0.03, 2e-4),                           # 0.0073 px  5.2e-5 m
+    ('glamr_static', 1, False): (0.01, 2e-5),                                 # 0.0027 px  2.9e-6 m
+    ('glamr_static', 1, True): (0.1, 6e-5),                                   # 0.0347 px  1.8e-5 m
 }
 
 
