@@ -741,6 +741,13 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         sc.cp[lo.cam_trans + t * 3 + r] = M[r * 4 + 3];
       }
     }
+  } else if (var_cam && AF) {
+    // a stage continued launch by launch: the camera parameters of the batch array are current -- into the on-chip block
+    const int rows = fixed_cam ? 1 : T;
+    for (int t = rt.tid(); t < rows; t += rt.nthreads()) {
+      for (int k = 0; k < 6; ++k) sc.cp[lo.cam_rot6d + t * 6 + k] = sc.cp_g[l.cam_rot6d + t * 6 + k];
+      for (int k = 0; k < 3; ++k) sc.cp[lo.cam_trans + t * 3 + k] = sc.cp_g[l.cam_trans + t * 3 + k];
+    }
   }
   for (int p = 0; p < P; ++p)
     for (int t = rt.tid(); frame_in(t, T); t += fstep) {

@@ -566,7 +566,7 @@ def gen_full_family():
 FAMILY_CFG = [('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-6_seed0', dict(eps=1e-6, seed=0)), ('eps1e-6_seed1', dict(eps=1e-6, seed=1))]
 
 
-def gen_full_family_cfg(cfg_id='glamr_dynamic_multi', T=300, P=2):
+def gen_full_family_cfg(cfg_id='glamr_dynamic_multi', T=300, P=2, gap=True, members=None):
     """The reference's own spread on a full-schedule case WITH detection gaps (as gen_full_family does for configs[1]): per-frame cameras of
     frames the first person is not seen in start as zero matrices, and the result then hangs on the last bit of the first camera gradients.
     Members: another intra-op thread count, initial cam_pose x (1 + eps U(-1, 1)) right before each stage's optimiser is created."""
@@ -575,13 +575,13 @@ def gen_full_family_cfg(cfg_id='glamr_dynamic_multi', T=300, P=2):
     from glamr_amd.utils import synth
     md = synth.make_smpl_model()
     seed = FULL_SEED[(cfg_id, T, P)]
-    base = np.load(os.path.join(GOLD, full_name(cfg_id, T, P) + '.npz'))
+    base = np.load(os.path.join(GOLD, full_name(cfg_id, T, P, gap) + '.npz'))
     out = {}
     keep_threads = torch.get_num_threads()
-    for name, opt in FAMILY_CFG:
+    for name, opt in (members or FAMILY_CFG):
         torch.set_num_threads(opt.get('threads', keep_threads))
         model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
-        in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=md)
+        in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=md, gap=None if gap else (0, 0))
         keep = model.init_opt
         done = []
 
@@ -604,7 +604,7 @@ def gen_full_family_cfg(cfg_id='glamr_dynamic_multi', T=300, P=2):
         out[name + '_cam_pose'] = _np(data['cam_pose'])
         print('family member %-16s %.0f s: max %.3f px from the committed golden' % (name, time.time() - t0, worst), flush=True)
     torch.set_num_threads(keep_threads)
-    np.savez_compressed(os.path.join(GOLD, full_name(cfg_id, T, P) + '_family.npz'), **out)
+    np.savez_compressed(os.path.join(GOLD, full_name(cfg_id, T, P, gap) + '_family.npz'), **out)
 
 
 EVAL_CASES = [('glamr_dynamic', 300, 1, '3DPW'), ('glamr_static_multi', 120, 2, '')]
@@ -662,7 +662,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

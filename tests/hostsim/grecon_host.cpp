@@ -113,6 +113,29 @@ extern "C" int hostsim_grecon_run_stage_arena(const glamr_scene_batch* b, const 
   return 0;
 }
 
+// The full-arena single-person instance (parameters + Adam moments in the "on-chip" arena) WITH the gradient record: what a stage driven
+// launch by launch from outside runs on the device for one-person scenes (latent-optimisation mode, GLAMR_FLAG_KEEP_CAM_PARAMS).
+extern "C" int hostsim_grecon_run_stage_arena_grads(const glamr_scene_batch* b, const glamr_stage_desc* st, float* grads_out) {
+  if (b->max_persons != 1) return -1;
+  glamr_param_layout l;
+  param_layout(1, b->max_len, l);
+  std::vector<float> ws(scene_workspace_floats(1, b->max_len));
+  const size_t fast_floats = scene_fast_floats(1, b->max_len, 1) + (size_t)2 * 6 * b->max_len;
+  std::vector<float> arena(fast_floats);
+  std::vector<float> tab(2 * (size_t)(st->niters > 0 ? st->niters : 1));
+  for (int i = 0; i < st->niters; ++i) adam_coef_host(st->lr, i + 1, &tab[2 * (size_t)i]);
+  HostRT rt;
+  rt.arena_ = arena.data(); rt.ws_ = ws.data();
+  for (int si = 0; si < b->n_scenes; ++si) {
+    Scene sc;
+    assemble_scene(*b, l, st, si, 1, b->seq_len[si], ws.data(), grads_out, sc, arena.data(), fast_floats, 1, 0);
+    sc.adam_tab = st->niters > 0 ? tab.data() : nullptr;
+    const int cam = camera_mode(*st);
+    if (cam == 1) run_scene<1, true, 1>(rt, sc, *st, l); else if (cam == 2) run_scene<1, true, 2>(rt, sc, *st, l); else run_scene<1, true, 0>(rt, sc, *st, l);
+  }
+  return 0;
+}
+
 // the optimiser's Adam update on a flat vector (compared bit for bit with torch.optim.Adam in tests/test_adam_exact.py)
 extern "C" void hostsim_adam_step(int n, float* p, float* m, float* v, const float* g, double lr, int step) {
   float tab[2];

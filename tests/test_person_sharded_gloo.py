@@ -130,3 +130,25 @@ def test_camera_from_person_stages_are_refused(asset_root):
     run, _ = gc.hostsim_runner()
     with pytest.raises(NotImplementedError, match='derives the camera'):
         parallel.PersonShardedSchedule(rank=0, world=1, run_stage=run, adam_step=_adam_host()).run(packed, cfg['opt_stage_specs'], cfg['grecon_model_specs'], max_iters=1)
+
+
+@pytest.mark.parametrize('cfg_id,T', [('glamr_static', 90), ('glamr_dynamic', 100)])
+def test_launch_by_launch_stage_with_the_state_on_chip(asset_root, cfg_id, T):
+    """One-person scenes run the instance that keeps parameters and Adam moments in the on-chip arena; driven launch by launch (the
+    latent-optimisation mode does that) the camera parameters must be taken from the batch array, not re-derived from cam_pose and not
+    left at whatever the arena held (GLAMR_FLAG_KEEP_CAM_PARAMS).  CPU runtime, arena in host memory, against the plain fused stage."""
+    from tests import hostsim
+    from glamr_amd import _lib, parallel
+    lib = hostsim.build('grecon_host')
+    fn = lib.hostsim_grecon_run_stage_arena_grads
+    fn.argtypes = [ctypes.POINTER(_lib.SceneBatch), ctypes.POINTER(_lib.StageDesc), ctypes.c_void_p]
+
+    def run(packed, sd, want_grads):
+        sb = packed.struct()
+        grads = torch.zeros_like(packed.t['params']) if want_grads else None
+        assert fn(ctypes.byref(sb), ctypes.byref(sd), ctypes.c_void_p(grads.data_ptr()) if want_grads else None) == 0
+        return grads
+    ref = _fused(asset_root, cfg_id, T, 1)
+    cfg, packed = _scene(asset_root, cfg_id, T, 1)
+    parallel.PersonShardedSchedule(rank=0, world=1, run_stage=run, adam_step=_adam_host()).run(packed, cfg['opt_stage_specs'], cfg['grecon_model_specs'], max_iters=K)
+    _compare(ref, {k: packed.t[k].numpy().copy() for k in KEYS}, 'on-chip state, launch by launch')
