@@ -69,6 +69,7 @@ _SIGNATURES = {
     'glamr_nets_create': (c_int, [POINTER(c_void_p), c_void_p, POINTER(TensorDesc), c_int, c_void_p, POINTER(TensorDesc), c_int, c_void_p, c_void_p]),
     'glamr_nets_destroy': (c_int, [c_void_p]),
     'glamr_nets_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
+    'glamr_nets_precision': (c_int, [c_void_p, c_void_p]),
     'glamr_nets_tape_bytes': (c_size_t, [c_void_p, c_int, c_int]),
     'glamr_nets_infill_taped': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3),
     'glamr_nets_infill_backward': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 2 + [c_int] + [c_void_p] * 4),

@@ -26,8 +26,9 @@ namespace {
 
 constexpr int D = 256, FF = 512, NZ = 128, WIN = 50, PAST = 10, CUR = 30, XLD = 96;
 
-struct Lin { float* W = nullptr; float* b = nullptr; int N = 0, K = 0; unsigned short* Ws = nullptr; };   // W: [Npad][K]; Ws: its two fp16 planes
-struct LN { float* g = nullptr; float* b = nullptr; };
+struct Lin { float* W = nullptr; float* b = nullptr; int N = 0, K = 0; unsigned short* Ws = nullptr;   // W: [Npad][K]; Ws: its two fp16 planes
+             double rowabs = 0, babs = 0, wabs = 0; };      // max_j sum_k |W_jk|, max |b_j|, max |W_jk|: the range analysis of glamr_nets_create
+struct LN { float* g = nullptr; float* b = nullptr; double bound = 0; };      // bound: max_k |gamma_k| sqrt(255) + |beta_k| -- no LayerNorm output exceeds it
 struct EncLayer { Lin qkv, o, f1, f2; LN n1, n2; };
 struct DecLayer { Lin sa_qkv, sa_o, ca_q, ca_kv, ca_o, f1, f2; LN n1, n2, n3; };
 
@@ -87,6 +88,13 @@ int up_vec(float** dst, const std::vector<double>& v, size_t pad_to = 0) {
 int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
   L.N = W.r;
   L.K = (W.c + 31) / 32 * 32;
+  L.rowabs = L.babs = L.wabs = 0;
+  for (int i = 0; i < W.r; ++i) {
+    double sum = 0;
+    for (int j = 0; j < W.c; ++j) { const double a = std::fabs(W.at(i, j)); sum += a; L.wabs = std::max(L.wabs, a); }
+    L.rowabs = std::max(L.rowabs, sum);
+  }
+  if (bias) for (double b : *bias) L.babs = std::max(L.babs, std::fabs(b));
   const int Np = (W.r + 63) / 64 * 64;
   std::vector<float> f((size_t)Np * L.K, 0.0f);
   for (int i = 0; i < W.r; ++i) for (int j = 0; j < W.c; ++j) f[(size_t)i * L.K + j] = (float)W.at(i, j);
@@ -151,6 +159,10 @@ struct glamr_nets {
   // outlives the call
   int32_t* capture_lens = nullptr;
   size_t capture_lens_used = 0;
+  // Range analysis (glamr_nets_create): worst-case magnitude of any value the fp16-split kernels convert, from the weights alone.  Above
+  // fp16's range the handle runs the plain fp32 kernels everywhere (fp32_only): slower, never wrong.
+  bool fp32_only = false;
+  double worst_activation = 0, worst_weight = 0;
   std::map<const Lin*, Lin> lin_T;      // transposed weights of the layers the infiller's backward multiplies with (nets_tape.inc), made on first use
 };
 constexpr size_t GRAPH_CACHE_MAX = 24, CAPTURE_LENS_INTS = 256 * 1024;
@@ -320,10 +332,45 @@ Ws ws_layout(int B, int max_len, char* base) {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// set by every entry point from its handle: 1 = the plain fp32 kernels only (range analysis of glamr_nets_create)
+thread_local int tl_fp32 = 0;
+
+// attention in plain fp32 (fp32_only handles): 8 heads x 32 dims, Lq, Lk <= 64, one workgroup per (sequence, head), lane = query row;
+// same contract as attention_mfma_kernel (key_mask != 0 -> key ignored, a fully masked row yields zeros)
+__global__ __launch_bounds__(64) void attention_f32_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
+                                                           float* O, int ldo, int Lq, int Lk, int q_shared) {
+  __shared__ float sK[64][33], sV[64][33];
+  __shared__ unsigned char sM[64];
+  const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  for (int idx = lane; idx < 64 * 32; idx += 64) {
+    const int j = idx >> 5, d = idx & 31;
+    sK[j][d] = j < Lk ? K[(size_t)(b * Lk + j) * ldk + h * 32 + d] : 0.f;
+    sV[j][d] = j < Lk ? V[(size_t)(b * Lk + j) * ldk + h * 32 + d] : 0.f;
+  }
+  sM[lane] = (lane < Lk) ? (key_mask ? key_mask[(size_t)b * Lk + lane] : 0) : 1;
+  __syncthreads();
+  if (lane >= Lq) return;
+  float q[32], sc[64], o[32];
+  for (int d = 0; d < 32; ++d) { q[d] = Q[(size_t)((q_shared ? 0 : b * Lq) + lane) * ldq + h * 32 + d]; o[d] = 0.f; }
+  float mx = -3.0e38f;
+  for (int j = 0; j < Lk; ++j) {
+    float s = 0.f;
+    for (int d = 0; d < 32; ++d) s = fmaf(q[d], sK[j][d], s);
+    sc[j] = s * 0.17677669529663687f;
+    if (!sM[j]) mx = fmaxf(mx, sc[j]);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < Lk; ++j) { const float e = sM[j] ? 0.f : expf(sc[j] - mx); sc[j] = e; sum += e; }
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  for (int j = 0; j < Lk; ++j) { const float p = sc[j] * inv; for (int d = 0; d < 32; ++d) o[d] = fmaf(p, sV[j][d], o[d]); }
+  for (int d = 0; d < 32; ++d) O[(size_t)(b * Lq + lane) * ldo + h * 32 + d] = o[d];
+}
+
 template <class... A>
 void launch_attention(dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldk,
                       const unsigned char* mask, float* O, int ldo, int Lq, int Lk, int q_shared) {
-  hipLaunchKernelGGL(attention_mfma_kernel, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
+  if (tl_fp32) hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(64), 0, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
+  else hipLaunchKernelGGL(attention_mfma_kernel, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
 }
 
 int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, int rows) {
@@ -333,7 +380,7 @@ int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, in
 constexpr int FUSE_MIN_ROWS = 2048;
 inline bool fuse_attention(int M) {
   static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE_ATTN") != nullptr || std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;      // development aid
-  return !no_fuse && M >= FUSE_MIN_ROWS;
+  return !no_fuse && !tl_fp32 && M >= FUSE_MIN_ROWS;
 }      // below this the launches are latency-bound either way: separate small-M kernels
 // Y = LayerNorm(X W^T + b + R): attention out-projection + residual + norm in one pass over the rows
 int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const float* R, float* Y, float* tmp, int M);
@@ -382,7 +429,13 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
   Blob I{ib, idesc, n_inf}, Tj{tb, tdesc, n_trj};
   tl_allocs = &h->allocs;                          // (a failed create leaks what it uploaded so far: the handle is never returned)
   auto lin_plain = [&](Lin& L, const Blob& B, int iw) { const std::vector<double> bias = vec_of(B.get(iw + 1)); return up_lin(L, B.get(iw), &bias); };
-  auto lnorm = [&](LN& n, const Blob& B, int i) { int rc = up_vec(&n.g, vec_of(B.get(i))); return rc ? rc : up_vec(&n.b, vec_of(B.get(i + 1))); };
+  auto lnorm = [&](LN& n, const Blob& B, int i) {
+    const std::vector<double> g = vec_of(B.get(i)), be = vec_of(B.get(i + 1));
+    n.bound = 0;
+    for (size_t k = 0; k < g.size(); ++k) n.bound = std::max(n.bound, std::fabs(g[k]) * std::sqrt(255.0) + std::fabs(be[k]));
+    int rc = up_vec(&n.g, g);
+    return rc ? rc : up_vec(&n.b, be);
+  };
 
   // ---- infiller: context encoder ------------------------------------------------------------------------------------------
   {
@@ -544,6 +597,82 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
   }
   RC(upload_t(&h->rest_joints, fk_rest_joints, (size_t)72));
   RC(upload_t(&h->parents, parents, (size_t)24));
+
+  // ---- range analysis: can any value the fp16-split kernels convert leave fp16's range? -----------------------------------------------
+  // Worst case from the weights alone (triangle inequality with scalar bounds; LayerNorm outputs are bounded by |gamma| sqrt(255) + |beta|
+  // whatever comes in; attention outputs are convex combinations of the value rows; LSTM states are in [-1, 1]).  Inputs are taken within:
+  // body pose rotation vectors |x| <= 10, root-relative joint positions <= 4 m, heading-frame translations <= 200 m, latent |z| <= 100.  Default-initialised and
+  // trained checkpoints stay orders of magnitude below the limit; a checkpoint that does not (or weights beyond fp16 themselves) makes the
+  // handle run the plain fp32 kernels everywhere: fp32_only.  GLAMR_NETS_FORCE_FP32=1 selects that mode by hand.
+  {
+    double worst = 0, wmax = 0;
+    auto see = [&](double b) { worst = std::max(worst, b); return b; };
+    auto out_of = [&](const Lin& L, double in) { wmax = std::max(wmax, L.wabs); return L.rowabs * in + L.babs; };
+    auto table_abs = [&](const float* dev, size_t n) {            // |.|max of a bias table already uploaded
+      std::vector<float> t(n);
+      if (hipMemcpy(t.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1e30;
+      double m = 0;
+      for (float v : t) m = std::max(m, (double)std::fabs(v));
+      return m;
+    };
+    const double POSE = 10.0, JOINTS = 4.0, TRANS = 200.0, ZMAX = 100.0;
+    auto enc_layer = [&](const EncLayer& E, double x) {             // x: bound of the layer's input rows (converted: qkv GEMM operand)
+      see(x);
+      see(out_of(E.qkv, x));                                        // Q, K, V: converted by the attention kernels; its output <= the V bound
+      see(out_of(E.f1, E.n1.bound));                                // hidden rows (the o-projection's output goes through LayerNorm first)
+      see(E.n1.bound);
+      return E.n2.bound;
+    };
+    auto dec_layer_b = [&](const DecLayer& Dl, double x, double ctx) {
+      see(x); see(ctx);
+      see(out_of(Dl.sa_qkv, x));
+      see(Dl.n1.bound); see(out_of(Dl.ca_q, Dl.n1.bound)); see(out_of(Dl.ca_kv, ctx));
+      see(Dl.n2.bound); see(out_of(Dl.f1, Dl.n2.bound));
+      return Dl.n3.bound;
+    };
+    // infiller
+    const double h0 = see(out_of(h->enc_in, see(POSE)) + table_abs(h->enc_pe, (size_t)WIN * D));
+    const double ctx = enc_layer(h->enc[1], enc_layer(h->enc[0], h0));
+    see(out_of(h->prior_kv, ctx)); see(h->prior_n2.bound); see(out_of(h->prior_f1, h->prior_n2.bound)); see(h->prior_n3.bound);
+    double q = see(out_of(h->dec_z, see(ZMAX)) + table_abs(h->dec_pe, (size_t)CUR * D));
+    q = dec_layer_b(h->dec[1], dec_layer_b(h->dec[0], q, ctx), ctx);
+    const double o1 = see(out_of(h->out1, q));
+    see(out_of(h->out2, o1));
+    // its posterior encoder (training-mode / reconstruction passes)
+    double qe = see(out_of(h->qe_in, POSE) + table_abs(h->qe_table, (size_t)32 * D));
+    qe = dec_layer_b(h->qe[1], dec_layer_b(h->qe[0], qe, ctx), ctx);
+    see(qe);
+    // trajectory predictor: root-relative joints, recurrent states in [-1, 1]
+    auto mlp = [&](const Lin& a, const Lin& b, double in) { const double hd = see(out_of(a, see(in))); return see(out_of(b, hd)); };
+    see(mlp(h->t_in1, h->t_in2, JOINTS));
+    for (int l = 0; l < 2; ++l) wmax = std::max(wmax, h->t_ih[l].wabs);
+    const double tctx = mlp(h->t_out1, h->t_out2, 1.0);
+    see(mlp(h->t_pr1, h->t_pr2, tctx));
+    const double dh = see(h->t_dctx.rowabs * tctx + h->t_dz.rowabs * ZMAX + h->t_dz.babs);
+    see(out_of(h->t_d2, dh));
+    see(mlp(h->te_in1, h->te_in2, TRANS));
+    const double te = mlp(h->te_out1, h->te_out2, 1.0);
+    see(mlp(h->te_f1, h->te_f2, std::max(te, tctx)));
+    for (const Lin* L : {&h->prior_o, &h->prior_f2, &h->prior_pz, &h->outfc, &h->qe_pz, &h->t_pz, &h->t_dfc, &h->te_qz, &h->te_ih[0], &h->te_ih[1]}) wmax = std::max(wmax, L->wabs);
+    for (int l = 0; l < 2; ++l)
+      for (const Lin* L : {&h->enc[l].o, &h->enc[l].f2, &h->dec[l].sa_o, &h->dec[l].ca_o, &h->dec[l].f2, &h->qe[l].sa_o, &h->qe[l].ca_o, &h->qe[l].f2}) wmax = std::max(wmax, L->wabs);
+    h->worst_activation = worst;
+    h->worst_weight = wmax;
+    const double LIMIT = 3.0e4;                                      // half of fp16's largest number
+    h->fp32_only = !(worst < LIMIT) || !(wmax < LIMIT) || std::getenv("GLAMR_NETS_FORCE_FP32") != nullptr;
+    if (h->fp32_only) {
+      // no fp16 planes: launch_gemm then runs the fp32-MFMA kernel for every shape, and the fused row-block / attention kernels are never chosen
+      Lin* all[] = {&h->enc_in, &h->prior_kv, &h->prior_o, &h->prior_f1, &h->prior_f2, &h->prior_pz, &h->dec_z, &h->out1, &h->out2, &h->outfc, &h->qe_in, &h->qe_pz,
+                    &h->t_in1, &h->t_in2, &h->t_ih[0], &h->t_ih[1], &h->t_out1, &h->t_out2, &h->t_pr1, &h->t_pr2, &h->t_pz, &h->t_dz, &h->t_dctx, &h->t_d2, &h->t_dfc,
+                    &h->te_in1, &h->te_in2, &h->te_ih[0], &h->te_ih[1], &h->te_out1, &h->te_out2, &h->te_f1, &h->te_f2, &h->te_qz};
+      for (Lin* L : all) L->Ws = nullptr;
+      for (int l = 0; l < 2; ++l) {
+        for (Lin* L : {&h->enc[l].qkv, &h->enc[l].o, &h->enc[l].f1, &h->enc[l].f2}) L->Ws = nullptr;
+        for (DecLayer* Dl : {&h->dec[l], &h->qe[l]})
+          for (Lin* L : {&Dl->sa_qkv, &Dl->sa_o, &Dl->ca_q, &Dl->ca_kv, &Dl->ca_o, &Dl->f1, &Dl->f2}) L->Ws = nullptr;
+      }
+    }
+  }
   GLAMR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->capture_lens), CAPTURE_LENS_INTS * sizeof(int32_t), hipHostMallocDefault));
   tl_allocs = nullptr;
   *out = h;
@@ -805,7 +934,7 @@ int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const
 void bilstm(glamr_nets* h, hipStream_t st, const float* G, float* const hh[2], const int* lens, float* H, int max_len, int B) {
   LstmArgs la{G, hh[0], hh[1], lens, H, max_len};
   // large batches: 16 sequences per workgroup on the matrix cores; small ones: one sequence per workgroup keeps every CU busy
-  if (B >= 512) hipLaunchKernelGGL(lstm_mfma_kernel, dim3((B + 15) / 16, 2), dim3(512), 0, st, la, B);
+  if (B >= 512 && !tl_fp32) hipLaunchKernelGGL(lstm_mfma_kernel, dim3((B + 15) / 16, 2), dim3(512), 0, st, la, B);
   else hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(512), 0, st, la);
 }
 
@@ -895,6 +1024,7 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   const int n_win = (longest - PAST + CUR - 1) / CUR;
   GLAMR_REQUIRE(!do_infill || n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  tl_fp32 = h->fp32_only ? 1 : 0;
   Ws w = ws_layout(B, max_len, static_cast<char*>(workspace));
   // A caller that is CAPTURING this stream (its whole step as one graph) gets the plain launch sequence recorded into its graph,
   // INCLUDING the upload of the lengths: they are copied to a pinned table the handle owns (alive until glamr_nets_destroy), and the
@@ -980,6 +1110,7 @@ extern "C" int glamr_nets_infiller_window(glamr_nets* h, int B, int mode, const 
   GLAMR_REQUIRE(mode == GLAMR_VAE_INFER || io->body_pose, "the posterior encoder (train / recon) needs body_pose");
   GLAMR_REQUIRE(mode == GLAMR_VAE_RECON || io->eps, "sampling (infer / train) needs eps");
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  tl_fp32 = h->fp32_only ? 1 : 0;
   Ws w = ws_layout(B, WIN, static_cast<char*>(workspace));
   hipLaunchKernelGGL(window_in_kernel, dim3(B, WIN), dim3(XLD), 0, st, io->in_body_pose, io->frame_mask, w.x, w.mask);
   if (mode != GLAMR_VAE_INFER) hipLaunchKernelGGL(window_in_kernel, dim3(B, WIN), dim3(XLD), 0, st, io->body_pose, io->frame_mask, w.gx, (unsigned char*)nullptr);
@@ -999,6 +1130,7 @@ extern "C" int glamr_nets_traj_clip(glamr_nets* h, int B, int T, int mode, const
   GLAMR_REQUIRE(mode == GLAMR_VAE_RECON || io->eps, "sampling (infer / train) needs eps");
   GLAMR_REQUIRE(io->out_local_traj, "out_local_traj is required");
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  tl_fp32 = h->fp32_only ? 1 : 0;
   Ws w = ws_layout(B, T, static_cast<char*>(workspace));
   std::vector<int> run(B, T), valid(B, T);
   if (io->valid_len > 0 && io->valid_len < T) std::fill(valid.begin(), valid.end(), io->valid_len);      // zero-padded chunk (get_seg_data)
@@ -1074,6 +1206,7 @@ extern "C" int glamr_nets_infill_taped(glamr_nets* h, int B, int max_len, const 
   RC(tape_windows(lens_host, B, max_len, &n_win));
   GLAMR_REQUIRE(n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  tl_fp32 = h->fp32_only ? 1 : 0;
   Tape t = tape_layout(B, max_len, static_cast<char*>(tape_));
   GLAMR_HIP_CHECK(hipMemcpyAsync(t.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(pose_in_kernel, dim3(B, t.Tpad), dim3(XLD), 0, st, body_pose, max_len, t.Tpad, t.pose);
@@ -1097,6 +1230,7 @@ extern "C" int glamr_nets_infill_backward(glamr_nets* h, int B, int max_len, con
   RC(tape_windows(lens_host, B, max_len, &n_win));
   GLAMR_REQUIRE(n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  tl_fp32 = h->fp32_only ? 1 : 0;
   Tape t = tape_layout(B, max_len, static_cast<char*>(tape_));
   GLAMR_HIP_CHECK(hipMemsetAsync(t.pose + t.values, 0, t.values * sizeof(float), st));            // every gradient starts at zero
   GLAMR_HIP_CHECK(hipMemsetAsync(g_motion_eps, 0, (size_t)B * n_win_max * NZ * sizeof(float), st));
@@ -1111,4 +1245,13 @@ extern "C" int glamr_nets_infill_backward(glamr_nets* h, int B, int max_len, con
   }
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
+}
+
+// 0 = fp32-grade products on the fp16 matrix cores (two-plane operands), 1 = plain fp32 kernels only (the range analysis of
+// glamr_nets_create found a value that could leave fp16's range, or GLAMR_NETS_FORCE_FP32).  worst_case[0] = largest possible magnitude of
+// a converted activation, worst_case[1] = largest weight (either may be NULL).
+extern "C" int glamr_nets_precision(const glamr_nets* h, double* worst_case) {
+  if (!h) return -1;
+  if (worst_case) { worst_case[0] = h->worst_activation; worst_case[1] = h->worst_weight; }
+  return h->fp32_only ? 1 : 0;
 }

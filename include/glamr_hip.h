@@ -103,6 +103,12 @@ int glamr_nets_create(glamr_nets** out, const float* infiller_blob, const glamr_
                       const float* fk_rest_joints /* host (24,3): J_regressor @ v_template */, const int32_t* parents);
 int glamr_nets_destroy(glamr_nets* h);
 size_t glamr_nets_workspace_bytes(const glamr_nets* h, int n_seq, int max_len);
+/* Arithmetic of this handle: 0 = fp32-grade products on the fp16 matrix cores (every fp32 operand as two fp16 planes: 2^-22 of a product,
+ * range 6e-8 .. 65504), 1 = plain fp32 kernels only.  glamr_nets_create decides from the WEIGHTS: a worst-case bound of every value the
+ * split kernels convert (LayerNorm outputs are bounded whatever comes in, attention outputs by the value rows, LSTM states by 1; inputs
+ * taken within |pose| <= 10, root-relative joints <= 4 m, translations <= 200 m, |z| <= 100) must stay below 3e4, and so must the weights -- otherwise (or with
+ * GLAMR_NETS_FORCE_FP32 set) the handle never uses the fp16 planes.  worst_case[2] (may be NULL): that bound, and the largest weight. */
+int glamr_nets_precision(const glamr_nets* h, double* worst_case);
 
 /* Batched infiller + trajectory predictor over n_seq independent sequences (one "person" each).
  * dev in : body_pose (n_seq, max_len, 69) zero outside each sequence's [0,len) and on invisible frames

@@ -320,3 +320,74 @@ def test_infiller_gradient_wrt_the_latent_matches_reference_autograd(priors, gol
     _, tape_b = priors.infill_taped(b2['in_body_pose'], b2['frame_mask'], [T - 37], b2['in_motion_latent'][None])
     alone = priors.infill_backward(tape_b, W[:, :T - 37].contiguous())[0].cpu().numpy()
     assert np.abs(both[1, :alone.shape[0]] - alone).max() < 1e-5
+
+
+def test_range_analysis_selects_the_fp32_kernels_for_a_checkpoint_outside_fp16(asset_root, priors, golden):
+    """The fp16-split kernels hold every fp32 operand as two fp16 numbers: fine for O(1) activations and O(0.05) weights, wrong above 65 504.
+    glamr_nets_create bounds, from the weights alone, every value those kernels could convert; a checkpoint that can leave fp16's range runs
+    the plain fp32 kernels everywhere (slower, never wrong).  Checked three ways: the shipped (default-initialised) checkpoints keep the fast
+    path; weights x 300 in one feed-forward block (hidden rows ~ 1e5) switch the handle to fp32 and its outputs equal the CPU oracle's with the
+    same weights; GLAMR_NETS_FORCE_FP32 gives the reference values on the shipped checkpoints at batch size (the fp32 path is exercised)."""
+    import ctypes
+    from glamr_amd import _lib
+    from glamr_amd.models.priors import MotionPriorsHandle
+    from glamr_amd.utils import synth
+    from oracle.port import nets as onets
+    dev = torch.device('cuda:0')
+    wc = (ctypes.c_double * 2)()
+    assert _lib.lib().glamr_nets_precision(priors.h, wc) == 0
+    print('shipped checkpoints: worst-case converted activation %.0f, largest weight %.3f -> fp16-split kernels' % (wc[0], wc[1]))
+    assert wc[0] < 3e4 and wc[1] < 10
+    sd = {}
+    for name, sub in (('inf', 'motion_filler/motion_infiller_demo'), ('trj', 'traj_pred/traj_pred_demo')):
+        path = sorted(glob.glob(os.path.join(asset_root, 'results', sub, 'version_*', 'checkpoints', '*best*.ckpt')))[-1]
+        sd[name] = torch.load(path, map_location='cpu', weights_only=False)['state_dict']
+    md = synth.make_smpl_model()
+    rest = (md['J_regressor'].astype(np.float64) @ md['v_template'].astype(np.float64)).astype(np.float32)
+    big = {k: v.clone() for k, v in sd['inf'].items()}
+    big['context_encoder.temporal_net.layers.0.linear1.weight'] *= 300.0          # hidden rows of the first feed-forward block: ~1e5
+    big['context_encoder.temporal_net.layers.0.linear2.weight'] /= 300.0
+    hb = MotionPriorsHandle(big, sd['trj'], rest, synth.SMPL_PARENTS, dev)
+    assert _lib.lib().glamr_nets_precision(hb.h, wc) == 1 and wc[0] > 3e4
+    T = 120
+    b = {k: torch.tensor(v, device=dev) for k, v in mg.net_inputs(T).items()}
+    B = 48                                                                            # 48 x 50 rows >= 2048: the shapes the split kernels would take
+    pose, vis = b['in_body_pose'].repeat(B, 1, 1), b['frame_mask'].repeat(B, 1)
+    eps = b['in_motion_latent'][None].repeat(B, 1, 1)
+    out = hb.infer(pose, vis, [T] * B, motion_eps=eps, traj_eps=b['in_traj_latent'].repeat(B, 1))
+    assert torch.isfinite(out['pose']).all() and torch.equal(out['pose'][0], out['pose'][B - 1])
+    ora = onets.MotionInfillerVAE()
+    ora.load_state_dict({k: v.float() for k, v in big.items() if not k.startswith('smpl.')}, strict=True)
+    with torch.no_grad():
+        d = ora.inference_multi_step({'in_body_pose': b['in_body_pose'].cpu(), 'frame_mask': b['frame_mask'].cpu(), 'in_motion_latent': b['in_motion_latent'].cpu()})
+    err = _err(out['pose'][0].cpu(), d['infer_out_body_pose'][0, 0])
+    print('weights x 300 (hidden rows ~1e5): fp32 kernels vs CPU oracle %.2e' % err)
+    assert err < 1e-4
+    hb.close()
+
+
+def test_forced_fp32_kernels_match_the_reference(asset_root, golden, monkeypatch):
+    import ctypes
+    from glamr_amd import _lib
+    from glamr_amd.models.priors import MotionPriorsHandle
+    from glamr_amd.utils import synth
+    monkeypatch.setenv('GLAMR_NETS_FORCE_FP32', '1')
+    dev = torch.device('cuda:0')
+    sd = {}
+    for name, sub in (('inf', 'motion_filler/motion_infiller_demo'), ('trj', 'traj_pred/traj_pred_demo')):
+        path = sorted(glob.glob(os.path.join(asset_root, 'results', sub, 'version_*', 'checkpoints', '*best*.ckpt')))[-1]
+        sd[name] = torch.load(path, map_location='cpu', weights_only=False)['state_dict']
+    md = synth.make_smpl_model()
+    rest = (md['J_regressor'].astype(np.float64) @ md['v_template'].astype(np.float64)).astype(np.float32)
+    hf = MotionPriorsHandle(sd['inf'], sd['trj'], rest, synth.SMPL_PARENTS, dev)
+    assert _lib.lib().glamr_nets_precision(hf.h, None) == 1
+    g = golden('nets')
+    T, B = 300, 600                                                                    # 600 sequences: the batch sizes of the MFMA LSTM and the fused kernels
+    b = {k: torch.tensor(v, device=dev) for k, v in mg.net_inputs(T).items()}
+    out = hf.infer(b['in_body_pose'].repeat(B, 1, 1), b['frame_mask'].repeat(B, 1), [T] * B, motion_eps=b['in_motion_latent'][None].repeat(B, 1, 1),
+                   traj_eps=b['in_traj_latent'].repeat(B, 1))
+    e = (_err(out['pose'][B - 1].cpu(), g['T%d_body_pose' % T][0, 0]), _err(out['local_traj'][B - 1].cpu(), g['T%d_local_traj' % T][:, 0, 0]),
+         _err(out['trans'][B - 1].cpu(), g['T%d_trans' % T][0, 0]))
+    print('fp32-only kernels at batch 600 vs reference: body pose %.2e, local trajectory %.2e, translation %.2e' % e)
+    assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 2e-4
+    hf.close()

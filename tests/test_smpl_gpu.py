@@ -161,3 +161,53 @@ def test_smpl_backward_wrt_body_pose_and_betas(models, variant):
         print('%s: d/d%s relative error %.2e (largest %.2e)' % (variant, name, err, r.abs().max().item()))
         assert err < 2e-4, (variant, name, err)
     assert ref['body_pose'].abs().max() > 1e-3 and ref['betas'].abs().max() > 1e-3
+
+
+def test_sparse_regressors_as_the_real_model_stores_them(tmp_path):
+    """The published SMPL pickle keeps J_regressor as a scipy.sparse matrix with ~200 non-zeros per joint, and J_regressor_extra is as sparse.
+    A model of that kind (the synthetic one cut to the 200 largest weights per joint, rows renormalised, stored as CSC) through the loader,
+    the full-mesh tiling, the virtual-vertex tiling of the joints-only call (24 virtual vertices per regressed joint built FROM the sparse
+    rows) and the general backward -- against the CPU restatement on the same files."""
+    import pickle
+    import scipy.sparse as sp
+    from glamr_amd.utils import synth
+    from glamr_amd.lib.models.smpl import SMPL
+    from oracle.port.smpl import SMPL as OracleSMPL
+    md = synth.make_smpl_model()
+
+    def cut(R, keep=200):
+        R = np.array(R, dtype=np.float64)
+        for r in range(R.shape[0]):
+            small = np.argsort(R[r])[:-keep]
+            R[r, small] = 0.0
+            R[r] /= R[r].sum()
+        return R.astype(np.float32)
+    Jr, Jx = cut(md['J_regressor']), cut(md['J_regressor_extra'])
+    assert (Jr != 0).sum(1).max() <= 200 and (Jx != 0).sum(1).max() <= 200
+    mdir = tmp_path / 'data' / 'body_models' / 'smpl'
+    os.makedirs(mdir)
+    model = {k: v for k, v in md.items() if k != 'J_regressor_extra' and not k.startswith('_')}
+    model['J_regressor'] = sp.csc_matrix(Jr)
+    with open(mdir / 'SMPL_NEUTRAL.pkl', 'wb') as f:
+        pickle.dump(model, f, protocol=2)
+    np.save(tmp_path / 'data' / 'J_regressor_extra.npy', Jx)
+    dev = torch.device('cuda:0')
+    mine = SMPL(str(mdir), pose_type='body26fk', extra_regressor_path=str(tmp_path / 'data' / 'J_regressor_extra.npy')).to(dev)
+    ora = OracleSMPL(str(mdir), pose_type='body26fk', extra_regressor_path=str(tmp_path / 'data' / 'J_regressor_extra.npy'))
+    gen = torch.Generator().manual_seed(3)
+    B = 45
+    pose, betas, trans = torch.randn(B, 72, generator=gen) * 0.4, torch.randn(B, 10, generator=gen), torch.randn(B, 3, generator=gen)
+    ref = ora(global_orient=pose[:, :3], body_pose=pose[:, 3:], betas=betas, root_trans=trans)
+    full = mine(global_orient=pose[:, :3].to(dev), body_pose=pose[:, 3:].to(dev), betas=betas.to(dev), root_trans=trans.to(dev))
+    jonly = mine(global_orient=pose[:, :3].to(dev), body_pose=pose[:, 3:].to(dev), betas=betas.to(dev), root_trans=trans.to(dev), return_verts=False)
+    e = (_err(full.joints, ref.joints), _err(full.vertices, ref.vertices), _err(jonly.joints, ref.joints))
+    print('sparse regressors: joints %.2e, vertices %.2e, joints-only tiling %.2e' % e)
+    assert max(e) < TOL
+    # gradients w.r.t. body pose / betas through the joints-only tiling
+    wj = torch.randn(B, 26, 3, generator=gen)
+    bp_c, be_c = pose[:, 3:].clone().requires_grad_(True), betas.clone().requires_grad_(True)
+    (ora(global_orient=pose[:, :3], body_pose=bp_c, betas=be_c, root_trans=trans).joints * wj).sum().backward()
+    bp_g, be_g = pose[:, 3:].clone().to(dev).requires_grad_(True), betas.clone().to(dev).requires_grad_(True)
+    (mine(global_orient=pose[:, :3].to(dev), body_pose=bp_g, betas=be_g, root_trans=trans.to(dev), return_verts=False).joints * wj.to(dev)).sum().backward()
+    for a, b, name in ((bp_g.grad.cpu(), bp_c.grad, 'body_pose'), (be_g.grad.cpu(), be_c.grad, 'betas')):
+        assert (a - b).abs().max().item() / max(1.0, b.abs().max().item()) < 2e-4, name
