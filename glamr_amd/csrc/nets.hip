@@ -660,6 +660,7 @@ extern "C" int glamr_nets_create(glamr_nets** out, const float* ib, const glamr_
     h->worst_weight = wmax;
     const double LIMIT = 3.0e4;                                      // half of fp16's largest number
     h->fp32_only = !(worst < LIMIT) || !(wmax < LIMIT) || std::getenv("GLAMR_NETS_FORCE_FP32") != nullptr;
+    if (std::getenv("GLAMR_NETS_FORCE_FP16")) h->fp32_only = false;      // development aid (tests): keep the split kernels whatever the analysis says
     if (h->fp32_only) {
       // no fp16 planes: launch_gemm then runs the fp32-MFMA kernel for every shape, and the fused row-block / attention kernels are never chosen
       Lin* all[] = {&h->enc_in, &h->prior_kv, &h->prior_o, &h->prior_f1, &h->prior_f2, &h->prior_pz, &h->dec_z, &h->out1, &h->out2, &h->outfc, &h->qe_in, &h->qe_pz,

@@ -256,32 +256,36 @@ struct RowsArgs {
 // KS1 > 0: the k steps of the first GEMM phase are known at compile time (16 for the 256-wide transformer layers): every phase is then
 // straight-line code -- around a loop back edge the compiler cannot count the weight fragments in flight and waits for all of them at
 // the loop head, which defeats the three-steps-ahead prefetch.
-template <bool TWO, int KS1 = 0>
-__global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
+// RT: 32-row tiles per workgroup.  2 = 64 rows (135 KB of LDS with two layers: ONE workgroup per CU, its staging and epilogue overlap nobody's
+// MFMAs); 1 = 32 rows at half the LDS and <= 128 registers: TWO workgroups per CU, each wave then re-reads the weight fragments for half the
+// rows (twice the L2 traffic per row, still a fraction of its bandwidth).
+template <bool TWO, int KS1 = 0, int RT = 2>
+__global__ __launch_bounds__(512, RT == 1 ? 4 : 1) void rows_fused_kernel(RowsArgs a) {      // (second argument: waves per SIMD)
+  constexpr int RB = 32 * RT;                                       // rows per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NJ = 1;                                             // 8 waves: one 32-column tile each (x 2 row tiles)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, kg = lane >> 5;
-  const int m0 = blockIdx.x * 64;
+  const int m0 = blockIdx.x * RB;
   const int K1 = a.K1, XS = (K1 + 8) * 2;                         // bytes per row of one X plane
   constexpr int HS = (256 + 8) * 2;                               // bytes per row of one hidden plane
   unsigned char* sX = smem;                                       // [2][64][XS]
-  unsigned char* sH = smem + 2 * 64 * XS;                         // [2][64][HS] (two layers only)
+  unsigned char* sH = smem + 2 * RB * XS;                         // [2][RB][HS] (two layers only)
   // the fp32 output rows [64][260] reuse the hidden planes (two layers) or the X planes (one layer, K1 = 256: 67.6 KB -> two workgroups per CU)
   float* sOut = reinterpret_cast<float*>(TWO ? sH : sX);
   // ---- X tile -> planes ---------------------------------------------------------------------------------------------------------
-  for (int f = tid; f < 64 * (K1 / 4); f += 512) {
+  for (int f = tid; f < RB * (K1 / 4); f += 512) {
     const int row = f / (K1 / 4), c4 = (f % (K1 / 4)) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + c4);
     unsigned h0, l0, h1, l1;
     split2((f32x2){v[0], v[1]}, h0, l0);
     split2((f32x2){v[2], v[3]}, h1, l1);
     *reinterpret_cast<uint2*>(sX + row * XS + c4 * 2) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(sX + 64 * XS + row * XS + c4 * 2) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(sX + RB * XS + row * XS + c4 * 2) = make_uint2(l0, l1);
   }
   __syncthreads();
   // one GEMM phase: acc[i][j] += A(rows 32 i.., K) * W(cols of this wave's tiles j, k range) with A planes in LDS
   // KSC > 0: compile-time number of k steps (fully unrolled, no branches); KSC == 0: `ksteps_here` at run time
-  auto phase = [&](auto ksc_tag, const unsigned char* sA, int AS, int ksteps_here, const unsigned short* Ws, size_t plane, int ksteps_w, int kstep0, int nb0, f32x16 (&acc)[2][NJ]) {
+  auto phase = [&](auto ksc_tag, const unsigned char* sA, int AS, int ksteps_here, const unsigned short* Ws, size_t plane, int ksteps_w, int kstep0, int nb0, f32x16 (&acc)[RT][NJ]) {
     constexpr int KSC = decltype(ksc_tag)::value;
     const uint4* wf[2][NJ];
 #pragma unroll
@@ -291,11 +295,11 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
     // weight fragments THREE k steps ahead (a wave has one other wave on its SIMD to hide an L2 round trip behind: 3 x 6 MFMAs do)
     uint4 vb[4][2][NJ];
     auto step = [&](int kstep, int u) {
-      f16x8 xa[2][2], xb[2][NJ];
+      f16x8 xa[2][RT], xb[2][NJ];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xa[p][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + p * 64 * AS + (i * 32 + c) * AS + kstep * 32 + kg * 16));
+        for (int i = 0; i < RT; ++i) xa[p][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + p * RB * AS + (i * 32 + c) * AS + kstep * 32 + kg * 16));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) xb[p][j] = __builtin_bit_cast(f16x8, vb[u][p][j]);
       }
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[PA[term]][i], xb[PB[term]][j], acc[i][j], 0, 0, 0);
     };
@@ -349,16 +353,16 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
   };
   using ks1_t = std::integral_constant<int, KS1>;
   using ks16_t = std::integral_constant<int, 16>;
-  f32x16 acc2[2][NJ];
+  f32x16 acc2[RT][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc2[i][j] = (f32x16){0};
   if (TWO) {
     for (int hh = 0; hh < 2; ++hh) {
-      f32x16 acc1[2][NJ];
+      f32x16 acc1[RT][NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc1[i][j] = (f32x16){0};
       phase(ks1_t{}, sX, XS, K1 / 16, a.W1s, a.w1_plane, K1 / 16, 0, hh * 8 + wave * NJ, acc1);
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
         const int nloc = (wave * NJ + j) * 32 + c, n = hh * 256 + nloc;
         const float b = a.b1 ? a.b1[n] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);
             *reinterpret_cast<_Float16*>(sH + row * HS + nloc * 2) = h;
-            *reinterpret_cast<_Float16*>(sH + 64 * HS + row * HS + nloc * 2) = l;
+            *reinterpret_cast<_Float16*>(sH + RB * HS + row * HS + nloc * 2) = l;
           }
       }
       __syncthreads();
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
     const int n = (wave * NJ + j) * 32 + c;
     const float b = a.b2 ? a.b2[n] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
   }
   __syncthreads();
   // rows out: one wave per row, 4 columns per lane (coalesced 1 KB rows); residual and LayerNorm as add_layernorm_kernel
-  for (int row = wave; row < 64; row += 8) {
+  for (int row = wave; row < RB; row += 8) {
     const int m = m0 + row;
     if (m >= a.M) break;
     f32x4 v = *reinterpret_cast<const f32x4*>(sOut + row * 260 + lane * 4);
@@ -425,9 +429,9 @@ __global__ __launch_bounds__(512) void rows_fused_kernel(RowsArgs a) {
   }
 }
 
-inline size_t rows_fused_lds(int K1, bool two) {
-  const size_t x = (size_t)2 * 64 * (K1 + 8) * 2, h = (size_t)2 * 64 * (256 + 8) * 2;
-  return two ? x + h : (x > (size_t)64 * 260 * 4 ? x : (size_t)64 * 260 * 4);
+inline size_t rows_fused_lds(int K1, bool two, int rb = 64) {
+  const size_t x = (size_t)2 * rb * (K1 + 8) * 2, h = (size_t)2 * rb * (256 + 8) * 2;
+  return two ? x + h : (x > (size_t)rb * 260 * 4 ? x : (size_t)rb * 260 * 4);
 }
 
 // Multi-head attention for short sequences on the matrix cores: 8 heads x 32 dims, Lq, Lk <= 64; ONE wave per (sequence, head).
@@ -1018,19 +1022,32 @@ inline int launch_rows(hipStream_t st, const float* X, int ldx, int M, int K1, c
   if (K1 % 32 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || (W1s && (K1 > 256 || K2 != 512)) || (!W1s && (K1 > 256 || K2 != K1)))
     return fail(GLAMR_E_INVALID, "fused rows: unsupported shape K1=%d K2=%d", K1, K2);
   RowsArgs a{X, ldx, M, K1, W1s, w1_plane, b1, rowbias, rpg, ldrb, W2s, w2_plane, K2, b2, act2, R, ldr, gamma, beta, Y, ldy};
-  const size_t lds = rows_fused_lds(K1, W1s != nullptr);
+  // 32-row blocks: two workgroups per CU (measured on 1024 x 300 frames, both priors: 20.6 ms against 21.7 with 64-row blocks);
+  // GLAMR_ROWS_RT=2 selects the 64-row instances (A/B runs)
+  static const int rt_env = std::getenv("GLAMR_ROWS_RT") ? std::atoi(std::getenv("GLAMR_ROWS_RT")) : 0;
+  const int rt = rt_env == 1 || rt_env == 2 ? rt_env : 1;
+  const int rb = 32 * rt;
+  const size_t lds = rows_fused_lds(K1, W1s != nullptr, rb);
   static bool attr_done = false;
   if (!attr_done) {
     const void* kerns[] = {reinterpret_cast<const void*>(rows_fused_kernel<true>), reinterpret_cast<const void*>(rows_fused_kernel<false>),
-                           reinterpret_cast<const void*>(rows_fused_kernel<true, 16>), reinterpret_cast<const void*>(rows_fused_kernel<false, 16>)};
+                           reinterpret_cast<const void*>(rows_fused_kernel<true, 16>), reinterpret_cast<const void*>(rows_fused_kernel<false, 16>),
+                           reinterpret_cast<const void*>(rows_fused_kernel<true, 0, 1>), reinterpret_cast<const void*>(rows_fused_kernel<false, 0, 1>),
+                           reinterpret_cast<const void*>(rows_fused_kernel<true, 16, 1>), reinterpret_cast<const void*>(rows_fused_kernel<false, 16, 1>)};
     for (const void* k : kerns)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) return fail(GLAMR_E_HIP, "hipFuncSetAttribute(rows_fused_kernel) failed");
     attr_done = true;
   }
   // K1 = 256 (every transformer block): the instances whose phases are straight-line code
   const bool k256 = K1 == 256;
-  if (W1s) { if (k256) hipLaunchKernelGGL((rows_fused_kernel<true, 16>), dim3((M + 63) / 64), dim3(512), lds, st, a); else hipLaunchKernelGGL(rows_fused_kernel<true>, dim3((M + 63) / 64), dim3(512), lds, st, a); }
-  else { if (k256) hipLaunchKernelGGL((rows_fused_kernel<false, 16>), dim3((M + 63) / 64), dim3(512), lds, st, a); else hipLaunchKernelGGL(rows_fused_kernel<false>, dim3((M + 63) / 64), dim3(512), lds, st, a); }
+  const dim3 grid((M + rb - 1) / rb), block(512);
+  if (rt == 1) {
+    if (W1s) { if (k256) hipLaunchKernelGGL((rows_fused_kernel<true, 16, 1>), grid, block, lds, st, a); else hipLaunchKernelGGL((rows_fused_kernel<true, 0, 1>), grid, block, lds, st, a); }
+    else { if (k256) hipLaunchKernelGGL((rows_fused_kernel<false, 16, 1>), grid, block, lds, st, a); else hipLaunchKernelGGL((rows_fused_kernel<false, 0, 1>), grid, block, lds, st, a); }
+  } else {
+    if (W1s) { if (k256) hipLaunchKernelGGL((rows_fused_kernel<true, 16>), grid, block, lds, st, a); else hipLaunchKernelGGL(rows_fused_kernel<true>, grid, block, lds, st, a); }
+    else { if (k256) hipLaunchKernelGGL((rows_fused_kernel<false, 16>), grid, block, lds, st, a); else hipLaunchKernelGGL(rows_fused_kernel<false>, grid, block, lds, st, a); }
+  }
   return GLAMR_OK;
 }
 

@@ -322,12 +322,12 @@ def test_infiller_gradient_wrt_the_latent_matches_reference_autograd(priors, gol
     assert np.abs(both[1, :alone.shape[0]] - alone).max() < 1e-5
 
 
-def test_range_analysis_selects_the_fp32_kernels_for_a_checkpoint_outside_fp16(asset_root, priors, golden):
+def test_range_analysis_selects_the_fp32_kernels_for_a_checkpoint_outside_fp16(asset_root, priors, golden, monkeypatch):
     """The fp16-split kernels hold every fp32 operand as two fp16 numbers: fine for O(1) activations and O(0.05) weights, wrong above 65 504.
     glamr_nets_create bounds, from the weights alone, every value those kernels could convert; a checkpoint that can leave fp16's range runs
     the plain fp32 kernels everywhere (slower, never wrong).  Checked three ways: the shipped (default-initialised) checkpoints keep the fast
-    path; weights x 300 in one feed-forward block (hidden rows ~ 1e5) switch the handle to fp32 and its outputs equal the CPU oracle's with the
-    same weights; GLAMR_NETS_FORCE_FP32 gives the reference values on the shipped checkpoints at batch size (the fp32 path is exercised)."""
+    path; a LayerNorm gain x 3e4 (rows of ~1e5 entering a feed-forward block) switches the handle to fp32 and its outputs equal the CPU oracle's
+    with the same weights -- while the split kernels, forced onto that checkpoint, do not."""
     import ctypes
     from glamr_amd import _lib
     from glamr_amd.models.priors import MotionPriorsHandle
@@ -345,8 +345,7 @@ def test_range_analysis_selects_the_fp32_kernels_for_a_checkpoint_outside_fp16(a
     md = synth.make_smpl_model()
     rest = (md['J_regressor'].astype(np.float64) @ md['v_template'].astype(np.float64)).astype(np.float32)
     big = {k: v.clone() for k, v in sd['inf'].items()}
-    big['context_encoder.temporal_net.layers.0.linear1.weight'] *= 300.0          # hidden rows of the first feed-forward block: ~1e5
-    big['context_encoder.temporal_net.layers.0.linear2.weight'] /= 300.0
+    big['context_encoder.temporal_net.layers.0.norm1.weight'] *= 3.0e4           # rows of ~1e5 enter the first feed-forward block: beyond fp16
     hb = MotionPriorsHandle(big, sd['trj'], rest, synth.SMPL_PARENTS, dev)
     assert _lib.lib().glamr_nets_precision(hb.h, wc) == 1 and wc[0] > 3e4
     T = 120
@@ -356,13 +355,24 @@ def test_range_analysis_selects_the_fp32_kernels_for_a_checkpoint_outside_fp16(a
     eps = b['in_motion_latent'][None].repeat(B, 1, 1)
     out = hb.infer(pose, vis, [T] * B, motion_eps=eps, traj_eps=b['in_traj_latent'].repeat(B, 1))
     assert torch.isfinite(out['pose']).all() and torch.equal(out['pose'][0], out['pose'][B - 1])
-    ora = onets.MotionInfillerVAE()
+    ora = onets.MotionInfillerVAE().eval()
     ora.load_state_dict({k: v.float() for k, v in big.items() if not k.startswith('smpl.')}, strict=True)
     with torch.no_grad():
-        d = ora.inference_multi_step({'in_body_pose': b['in_body_pose'].cpu(), 'frame_mask': b['frame_mask'].cpu(), 'in_motion_latent': b['in_motion_latent'].cpu()})
+        d = ora.inference({'in_body_pose': b['in_body_pose'].cpu(), 'frame_mask': b['frame_mask'].cpu(), 'in_motion_latent': b['in_motion_latent'].cpu()},
+                          sample_num=1, multi_step=True)
     err = _err(out['pose'][0].cpu(), d['infer_out_body_pose'][0, 0])
-    print('weights x 300 (hidden rows ~1e5): fp32 kernels vs CPU oracle %.2e' % err)
+    print('LayerNorm gain x 3e4 (rows ~1e5): fp32 kernels vs CPU oracle %.2e' % err)
     assert err < 1e-4
+    # ... and what the split kernels would have made of it (analysis overridden): not the right values
+    monkeypatch.setenv('GLAMR_NETS_FORCE_FP16', '1')
+    hw = MotionPriorsHandle(big, sd['trj'], rest, synth.SMPL_PARENTS, dev)
+    monkeypatch.delenv('GLAMR_NETS_FORCE_FP16')
+    assert _lib.lib().glamr_nets_precision(hw.h, None) == 0
+    bad = hw.infer(pose, vis, [T] * B, motion_eps=eps, traj_eps=b['in_traj_latent'].repeat(B, 1))['pose'][0].cpu()
+    wrong = (not bool(torch.isfinite(bad).all())) or _err(bad, d['infer_out_body_pose'][0, 0]) > 1e-3
+    print('the fp16-split kernels on the same checkpoint: finite %s, error %.2e' % (bool(torch.isfinite(bad).all()), _err(torch.nan_to_num(bad), d['infer_out_body_pose'][0, 0])))
+    assert wrong
+    hw.close()
     hb.close()
 
 
