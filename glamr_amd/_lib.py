@@ -5,7 +5,7 @@ import os
 from ctypes import c_int, c_int32, c_int64, c_size_t, c_uint32, c_float, c_double, c_void_p, c_char_p, POINTER, Structure
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libglamr_hip.so')
+LIB_PATH = os.environ.get('GLAMR_LIB_PATH') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libglamr_hip.so')      # (override: A/B runs of kernel variants, tools/README.md)
 NUM_LOSSES = 13
 
 

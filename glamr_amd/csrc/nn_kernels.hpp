@@ -595,7 +595,10 @@ struct QkvAttnArgs {
   float* O; int ldo;                             // [B][Lq][256]
 };
 
-__global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnArgs a) {
+#ifndef GLAMR_QKV_WAVES
+#define GLAMR_QKV_WAVES 1      // waves per SIMD the register allocation aims at (development knob)
+#endif
+__global__ __launch_bounds__(512, GLAMR_QKV_WAVES) void qkv_attention_kernel(QkvAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int XS = (256 + 8) * 2;                               // bytes per row of one plane
   constexpr int KS = 16;                                          // k steps of the projections (K = 256)
