@@ -506,7 +506,7 @@ def run(argv=None):
         n_out = sum(len(r) for r in model.optimize_stream([in_dicts] * nb))
         host_stream = n_out / (time.time() - t0)
     coll_us = small_collective_latency(dev, world) if use_dist else None
-    latency = one_sequence_latency(model, in_dicts[0]) if (rank == 0 and not args.stub_model and hasattr(model, 'optimize')) else None
+    latency = one_sequence_latency(model, in_dicts[0]) if (rank == 0 and not args.stub_model and not args.no_kernel_lines and hasattr(model, 'optimize')) else None      # (--no-kernel-lines: profiler runs see the batched launches only)
     sharded4 = person_sharded_line(asset_root, dev, rank, world) if (use_dist and not args.stub_model and not args.no_kernel_lines) else None
 
     out = None

@@ -454,6 +454,10 @@ FULL_CFG_CASES = [(c, T, P, gap) for (c, T, P, _seed) in mg.FULL_CASES for gap i
 # multi-person cases WITH detection gaps are the zero-camera situation of DESIGN.md 4 (cameras of frames the first person is not seen in
 # start as zero matrices: 1e9 gradients, the result hangs on the last bit of a sum over joints of TWO persons that no other summation order
 # reproduces): they are held to the reference's own family of solutions instead (full_<cfg>_family.npz) and to its reprojection quality.
+# cases held to the reference's OWN family of solutions: (cfg, gap) -> gap flag of the family fixture.  glamr_dynamic_multi with gaps: the
+# unmodified reference re-run with 3 threads moves by 34.5 px, with cam_pose x (1 + 1e-7 U) by 28.2 px (zero cameras); glamr_h36m (per-frame
+# camera optimised at lr 1e-2 under 1e4-weighted smoothness terms): 3.7 px / 8.0 px -- there is no single reference answer to match.
+FULL_FAMILY = {('glamr_dynamic_multi', True): True, ('glamr_h36m', False): False, ('glamr_h36m', True): False}
 FULL_TOL_GPU = {                                                              # achieved on the MI355X (round 3)
     ('glamr_3dpw', 1, False): (0.1, 1e-3),                                    # 0.030 px   2.5e-4 m
     ('glamr_3dpw', 1, True): (0.1, 1e-3),                                     # 0.027 px   3.4e-4 m
@@ -492,6 +496,18 @@ def test_full_schedule_of_every_config_matches_the_reference(make_model, golden,
     print('full schedule %s T=%d P=%d gap=%s: kp %.4f px (%d frames > 1 px), root in camera %.2e m, world root %.2e m, orientation %.2e; reprojection %.3f vs reference %.3f px'
           % (cfg_id, T, P, gap, w['kp'], w['frames_over_1px'], w['root_cam'], w['root_world'], w['orient'], ours, ref))
     assert abs(ours - ref) < 0.02 * max(ref, 1.0)
+    if (cfg_id, gap) in FULL_FAMILY:
+        # the reference's own spread on this case (oracle/make_golden.py gen_full_family_cfg: another thread count, cam_pose x (1 + 1e-7 .. 1e-6 U))
+        fam = golden(mg.full_name(cfg_id, T, P, FULL_FAMILY[(cfg_id, gap)]) + '_family')
+        base = golden(mg.full_name(cfg_id, T, P, FULL_FAMILY[(cfg_id, gap)]))
+        spread = {}
+        for key, v in fam.items():
+            if key.endswith('_kp_2d_pred'):
+                name, pi = key[:-len('_kp_2d_pred')].rsplit('_p', 1)
+                d = np.abs(v - base['p%s_kp_2d_pred' % pi])[base['p%s_vis_frames' % pi]].max()
+                spread[name] = max(spread.get(name, 0.0), float(d))
+        print('  reference family: %s' % {k: '%.2f px' % v for k, v in spread.items()})
+        assert w['kp'] < 1.5 * max(spread.values()) + 0.5
     if (cfg_id, P, gap) in FULL_TOL_GPU:
         tol_kp, tol_root = FULL_TOL_GPU[(cfg_id, P, gap)]
         assert w['kp'] < tol_kp and w['root_cam'] < tol_root and w['frames_over_1px'] == 0
