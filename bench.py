@@ -414,36 +414,15 @@ def run(argv=None):
     sync()
     step_graphs = None
     if graph_step:
-        # every stream has run the step once (allocations, attribute calls, the priors' own graph): capture it, one graph per stream
+        # every stream has run the step once (allocations, attribute calls, the priors' own graph): capture it, one graph per stream, through
+        # the product's own entry point (GlobalReconOptimizer.capture_resident: capture + bit-for-bit check of a replay against a plain step)
         try:
-            step_graphs = []
-            for st in streams:
-                g = torch.cuda.CUDAGraph()
-                # (thread-local capture mode: a watchdog thread of the process group may query events while this thread captures)
-                with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
-                    _, pk = model.optimize_resident(rin)
-                step_graphs.append((g, pk))
+            step_graphs = [model.capture_resident(rin, stream=st, check=True) for st in streams]
             sync()
-            # self-check: EVERY stream's replay must reproduce a plain step bit for bit (same seed for the sampled latents)
-            for si, st in enumerate(streams):
-                torch.manual_seed(20260926)
-                with torch.cuda.stream(st):
-                    _, ref = model.optimize_resident(rin)
-                sync()
-                want = ref.t['kp_2d_pred'].clone()
-                torch.manual_seed(20260926)
-                with torch.cuda.stream(st):
-                    step_graphs[si][0].replay()
-                sync()
-                got = step_graphs[si][1].t['kp_2d_pred']
-                if not (bool(torch.isfinite(got).all()) and torch.equal(got, want)):
-                    raise RuntimeError('the replayed step of stream %d does not reproduce the plain one (max |diff| %.3g)' % (si, float((got - want).abs().max())))
             eager_step = step
 
             def step(i=0):
-                g, pk = step_graphs[i % len(step_graphs)]
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    g.replay()
+                step_graphs[i % len(step_graphs)].replay()
                 # (no per-launch stamps here: a replay rewrites the ONE workspace its graph was captured with, so the stamps of all but
                 # the last replay are gone by the time the clock stops -- the roofline launches are measured right after, see below)
         except Exception as e:      # noqa: BLE001 -- anything: the plain launches are always available

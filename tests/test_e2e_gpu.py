@@ -511,3 +511,33 @@ def test_full_schedule_of_every_config_matches_the_reference(make_model, golden,
     if (cfg_id, P, gap) in FULL_TOL_GPU:
         tol_kp, tol_root = FULL_TOL_GPU[(cfg_id, P, gap)]
         assert w['kp'] < tol_kp and w['root_cam'] < tol_root and w['frames_over_1px'] == 0
+
+
+def test_captured_resident_step_follows_new_inputs(make_model):
+    """GlobalReconOptimizer.capture_resident: the whole optimize_resident step as one replayable HIP graph over RESIDENT inputs.  A replay
+    after the content of those inputs was overwritten with another batch of the same geometry gives what a plain call on that batch gives."""
+    md = synth.make_smpl_model()
+    model = make_model('glamr_dynamic')
+    batch_a = [synth.make_in_dict(seed=80 + i, num_frames=96, num_persons=1, smpl_model=md) for i in range(5)]
+    batch_b = [synth.make_in_dict(seed=90 + i, num_frames=96, num_persons=1, smpl_model=md) for i in range(5)]
+    lat_a, lat_b = [mg.latents_for(d, 80 + i) for i, d in enumerate(batch_a)], [mg.latents_for(d, 90 + i) for i, d in enumerate(batch_b)]
+    st = torch.cuda.Stream()
+    rin = model.stage_inputs(batch_a, lat_a)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        model.optimize_resident(rin, max_iters=6)                    # first run on this stream: allocations, attribute calls
+    torch.cuda.synchronize()
+    rg = model.capture_resident(rin, max_iters=6, stream=st, check=True)
+    # new content into the SAME resident buffers
+    rin_b = model.stage_inputs(batch_b, lat_b)
+    torch.cuda.synchronize()
+    for k in rin.g:
+        rin.g[k].copy_(rin_b.g[k])
+    rin.meps.copy_(rin_b.meps)
+    rin.teps.copy_(rin_b.teps)
+    torch.cuda.synchronize()
+    got = rg.replay().t['kp_2d_pred'].clone()
+    torch.cuda.synchronize()
+    want = model.optimize_resident(rin_b, max_iters=6)[1].t['kp_2d_pred']
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and bool(torch.isfinite(got).all())
