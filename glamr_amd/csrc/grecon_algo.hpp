@@ -563,12 +563,16 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
     for (int p = 0; p < P; ++p) n += sc.pc[p].vis[t] != 0.f ? 1 : 0;
     sc.n_vis_persons[t] = n;
   }
-  for (int p = 0; p < P; ++p)
-    for (int t = rt.tid(); frame_in(t, T); t += rt.nthreads()) {
-      int r = -1;
-      if (sc.pc[p].vis[t] != 0.f) { r = 0; for (int u = 0; u < t; ++u) r += sc.pc[p].vis[u] != 0.f ? 1 : 0; }
-      sc.pc[p].vis_rank[t] = r;
-    }
+  // index among the visible frames = inclusive prefix count - 1 (a block scan over a scratch row: the per-thread walk over all earlier
+  // frames it replaces was 300 dependent memory round trips for the last thread -- most of a forward-only launch's 0.65 ms)
+  for (int p = 0; p < P; ++p) {
+    float* cnt = sc.ps[p].g_theta;                      // free until the first evaluation; [T]
+    for (int t = rt.tid(); frame_in(t, T); t += rt.nthreads()) cnt[t] = sc.pc[p].vis[t] != 0.f ? 1.0f : 0.0f;
+    rt.sync();
+    rt.scan(cnt, T, 1, false);
+    for (int t = rt.tid(); frame_in(t, T); t += rt.nthreads()) sc.pc[p].vis_rank[t] = sc.pc[p].vis[t] != 0.f ? (int)cnt[t] - 1 : -1;
+    rt.sync();
+  }
   for (int i = rt.tid(); i < P * P; i += rt.nthreads()) {
     const int a = i / P, b = i % P;
     int first = -1;

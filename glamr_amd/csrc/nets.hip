@@ -222,32 +222,51 @@ __global__ void pose_out_kernel(const float* pose, int max_len, int Tpad, const 
   if (c < 69) out_pose[((size_t)b * max_len + t) * 69 + c] = (t < lens[b]) ? pose[((size_t)b * Tpad + t) * XLD + c] : 0.0f;
 }
 // forward kinematics of the 23 body joints relative to the root, zero root orientation, unshaped template
-// (TrajPredVAE.get_joint_pos :384-394 -> SMPL.get_joints smpl.py:318-343); one thread per frame
-__global__ void fk_joints_kernel(const float* pose, int Tpad, int max_len, const int* lens, const float* rest, const int32_t* parents, float* x) {
-  const int b = blockIdx.x, t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= max_len) return;
+// (TrajPredVAE.get_joint_pos :384-394 -> SMPL.get_joints smpl.py:318-343); a thread per (frame, joint), the chain one tree level at a
+// time through LDS (a thread per frame walking all 24 joints with its matrices in scratch memory took 0.33 ms per 1024 x 300 frames)
+constexpr int FK_FRAMES = 10;      // 10 x 24 = 240 of 256 threads
+__global__ __launch_bounds__(256) void fk_joints_kernel(const float* pose, int Tpad, int max_len, const int* lens, const float* rest, const int32_t* parents, float* x) {
+  __shared__ float sG[FK_FRAMES][24][9], sP[FK_FRAMES][24][3];
+  __shared__ int sLev[24];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int fl = tid / 24, j = tid % 24;
+  const int t = blockIdx.y * FK_FRAMES + fl;
+  if (tid < 24) {
+    int lev = 0;
+    for (int a = parents[tid]; a >= 0; a = parents[a]) ++lev;
+    sLev[tid] = lev;
+  }
+  __syncthreads();
+  int nlev = 0;
+  for (int k = 0; k < 24; ++k) nlev = sLev[k] > nlev ? sLev[k] : nlev;
+  const bool active = fl < FK_FRAMES && t < max_len && t < lens[b];
+  const int pa = parents[j], lev = sLev[j];
+  float R[9];
+  if (active) {
+    if (j == 0) { const float z[3] = {0.f, 0.f, 0.f}; rm::aa_to_rotmat_s(z, R); }      // root: rodrigues of the zero vector with smplx's epsilon convention
+    else rm::aa_to_rotmat_s(pose + ((size_t)b * Tpad + t) * XLD + (j - 1) * 3, R);
+    if (j == 0) {
+      for (int e = 0; e < 9; ++e) sG[fl][0][e] = R[e];
+      for (int c = 0; c < 3; ++c) sP[fl][0][c] = rest[c];
+    }
+  }
+  __syncthreads();
+  for (int L = 1; L <= nlev; ++L) {
+    if (active && lev == L) {
+      float G[9], o[3];
+      rm::mat3_mul(sG[fl][pa], R, G);
+      const float d[3] = {rest[j * 3] - rest[pa * 3], rest[j * 3 + 1] - rest[pa * 3 + 1], rest[j * 3 + 2] - rest[pa * 3 + 2]};
+      rm::mat3_vec(sG[fl][pa], d, o);
+      for (int e = 0; e < 9; ++e) sG[fl][j][e] = G[e];
+      for (int c = 0; c < 3; ++c) sP[fl][j][c] = sP[fl][pa][c] + o[c];
+    }
+    __syncthreads();
+  }
+  if (fl >= FK_FRAMES || t >= max_len) return;
   float* xo = x + ((size_t)b * max_len + t) * XLD;
-  if (t >= lens[b]) { for (int c = 0; c < XLD; ++c) xo[c] = 0.0f; return; }
-  const float* p = pose + ((size_t)b * Tpad + t) * XLD;
-  float G[24][9], pos[24][3];
-  for (int e = 0; e < 9; ++e) G[0][e] = (e % 4 == 0) ? 1.0f : 0.0f;
-  {   // root: rodrigues of the zero vector with smplx's epsilon convention
-    const float z[3] = {0.f, 0.f, 0.f};
-    rm::aa_to_rotmat_s(z, G[0]);
-  }
-  for (int c = 0; c < 3; ++c) pos[0][c] = rest[c];
-  for (int j = 1; j < 24; ++j) {
-    const int pa = parents[j];
-    float R[9];
-    rm::aa_to_rotmat_s(p + (j - 1) * 3, R);
-    rm::mat3_mul(G[pa], R, G[j]);
-    const float d[3] = {rest[j * 3] - rest[pa * 3], rest[j * 3 + 1] - rest[pa * 3 + 1], rest[j * 3 + 2] - rest[pa * 3 + 2]};
-    float o[3];
-    rm::mat3_vec(G[pa], d, o);
-    for (int c = 0; c < 3; ++c) pos[j][c] = pos[pa][c] + o[c];
-  }
-  for (int j = 1; j < 24; ++j) for (int c = 0; c < 3; ++c) xo[(j - 1) * 3 + c] = pos[j][c] - pos[0][c];
-  for (int c = 69; c < XLD; ++c) xo[c] = 0.0f;
+  if (!active) { for (int c = j * 4; c < j * 4 + 4; ++c) xo[c] = 0.0f; return; }      // 24 threads x 4 columns = the 96 of a padded row
+  if (j > 0) for (int c = 0; c < 3; ++c) xo[(j - 1) * 3 + c] = sP[fl][j][c] - sP[fl][0][c];
+  else for (int c = 69; c < XLD; ++c) xo[c] = 0.0f;
 }
 __global__ void masked_mean_kernel(const float* ctx, int max_len, const int* lens, float* mean) {   // [B][max_len][256] -> [B][256]
   const int b = blockIdx.x, k = threadIdx.x, n = lens[b];
@@ -1004,7 +1023,7 @@ int enqueue_infer(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, int 
   if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(XLD), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
   if (!do_traj) return GLAMR_OK;
   // ---- trajectory predictor -----------------------------------------------------------------------------------------------------
-  hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + 63) / 64), dim3(64), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
+  hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + FK_FRAMES - 1) / FK_FRAMES), dim3(256), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
   return traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr);
 }
 }  // namespace
@@ -1141,7 +1160,7 @@ extern "C" int glamr_nets_traj_clip(glamr_nets* h, int B, int T, int mode, const
     hipLaunchKernelGGL(joints_in_kernel, dim3(B, T), dim3(XLD), 0, st, io->in_joint_pos, T, w.lens2, w.tx);
   } else {
     hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(XLD), 0, st, io->in_body_pose, T, w.Tpad, w.pose);
-    hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (T + 63) / 64), dim3(64), 0, st, w.pose, w.Tpad, T, w.lens2, h->rest_joints, h->parents, w.tx);
+    hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (T + FK_FRAMES - 1) / FK_FRAMES), dim3(256), 0, st, w.pose, w.Tpad, T, w.lens2, h->rest_joints, h->parents, w.tx);
   }
   const float* init = nullptr;
   if (io->trans && io->orient) {

@@ -536,8 +536,9 @@ def test_captured_resident_step_follows_new_inputs(make_model):
     rin.meps.copy_(rin_b.meps)
     rin.teps.copy_(rin_b.teps)
     torch.cuda.synchronize()
-    got = rg.replay().t['kp_2d_pred'].clone()
+    rg.replay()                                                     # enqueued on the side stream
     torch.cuda.synchronize()
+    got = rg.packed.t['kp_2d_pred'].clone()
     want = model.optimize_resident(rin_b, max_iters=6)[1].t['kp_2d_pred']
     torch.cuda.synchronize()
     assert torch.equal(got, want) and bool(torch.isfinite(got).all())
