@@ -942,34 +942,45 @@ class GlobalReconOptimizer:
         launches on a compute stream), the host scatters and uploads batch i + 1 (copy stream, pinned staging) and cuts the output
         dictionaries of batch i - 1 from its device->host copies (copy stream, after that batch's own event -- never a device-wide wait)."""
         dev = self.device
-        compute = self.__dict__.setdefault('_compute_stream', torch.cuda.Stream(device=dev))
-        copy = self.__dict__.setdefault('_copy_stream', torch.cuda.Stream(device=dev))
+        # consecutive batches alternate over two compute streams (the launch seams and tails of one batch are covered by the next, as in bench.py)
+        computes = self.__dict__.setdefault('_compute_streams', [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
+        # uploads and downloads on streams of their own: on ONE copy stream the upload of batch i + 1 queued behind the download of batch i,
+        # which waits for batch i's compute -- every batch then paid upload + download (~15 ms) on top of its device time
+        up = self.__dict__.setdefault('_upload_stream', torch.cuda.Stream(device=dev))
+        down = self.__dict__.setdefault('_download_stream', torch.cuda.Stream(device=dev))
         it = iter(batches)
         lat = iter(latents) if latents is not None else None
 
         def stage(batch):
-            with torch.cuda.stream(copy):
+            with torch.cuda.stream(up):
                 return self.stage_inputs(batch, next(lat) if lat is not None else None)
         nxt = next(it, None)
         if nxt is None:
             return
         rin = stage(nxt)
         prev = None
+        turn = 0
         while rin is not None:
+            compute = computes[turn % len(computes)]
+            turn += 1
             with torch.cuda.stream(compute):
                 compute.wait_event(rin.upload_done)
-                datas, packed = self.init_resident(rin, init_forward=not self._schedule_overwrites_init())
-                self.run_schedule(packed, max_iters)
+                datas, packed = self.optimize_resident(rin, max_iters) if self.latent_mode else self._resident_for_stream(rin, max_iters)
                 done = torch.cuda.Event()
                 done.record()
-            copy.wait_event(done)
-            fetched = self._fetch_async(packed, copy)                  # queued behind this batch only
+            down.wait_event(done)
+            fetched = self._fetch_async(packed, down)                  # queued behind this batch only
             nxt = next(it, None)
             rin = stage(nxt) if nxt is not None else None              # host work under the device's
             if prev is not None:
                 yield self.collect(*prev)
             prev = (datas, packed, fetched)
         yield self.collect(*prev)
+
+    def _resident_for_stream(self, rin, max_iters):
+        datas, packed = self.init_resident(rin, init_forward=not self._schedule_overwrites_init())
+        self.run_schedule(packed, max_iters)
+        return datas, packed
 
     def optimize_batch(self, in_dicts, latents=None, max_iters=None):
         """Host dictionaries in, host dictionaries out (optimize() of the reference for a batch of independent sequences)."""
