@@ -490,24 +490,36 @@ class GlobalReconOptimizer:
                     teps[si * P + pi] = np.asarray(latents[si][idx]['traj'], np.float32).reshape(-1)
             rin.meps, rin.teps = torch.from_numpy(meps).to(dev), torch.from_numpy(teps).to(dev)
         rin.meta = [{'seq_name': d['seq_name'], 'seq_len': Ts[si], 'gt': d.get('gt', {}), 'gt_meta': d.get('gt_meta', {})} for si, d in enumerate(in_dicts)]
-        # value checks of the wire format on the device (asynchronous; the verdict is read by check_inputs()): every number of a detection
-        # row finite, the 24 matrices of `smpl_pose_quat_wroot` orthonormal to 1e-2 (the field is named after quaternions, demo.py:320)
+        # one event for "uploaded", on the stream this call ran on: the staging set is rewritten only after it and a pipelined caller's compute
+        # stream waits for it.  The VALUE checks of the wire format run on the device later, on the stream that consumes the batch
+        # (value_checks(), called by init_resident): as kernels of the upload stream they gated `upload_done` while competing for CUs with
+        # the previous batch's optimiser stage -- a pipelined caller's next batch started 15 ms late.
         rin.verdict = None
-        if validate:
-            m = rin.g['exist'] != 0
-            R = rin.g['rot'].view(n_slots, T, 24, 3, 3)
-            dots = [(R[..., i, :] * R[..., j, :]).sum(-1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(i, 3)]
-            err = torch.stack(dots, -1).abs().amax(dim=(-1, -2))                                     # (n_slots, T)
-            fin = torch.stack([torch.isfinite(rin.g[k]).reshape(n_slots, T, -1).all(-1) for k in ('rot', 'betas', 'trans', 'kp', 'K')], -1).all(-1)
-            bad_rot = (m & ~(err <= 1e-2)).any(-1)
-            rin.verdict = torch.stack([bad_rot, (m & ~fin).any(-1)], 0)                              # (2, n_slots) on the device
-        # one event for "uploaded and checked", on the stream this call ran on: the staging set is rewritten only after it, a pipelined
-        # caller's compute stream waits for it, and check_inputs() reads the verdict after it
+        rin.validate = bool(validate)
         stg['event'] = torch.cuda.Event()
         stg['event'].record()
         rin.upload_done = stg['event']
         self.timings['host_pre'] = time.time() - t0
         return rin
+
+    @staticmethod
+    def value_checks(rin):
+        """Every number of a detection row finite, the 24 matrices of `smpl_pose_quat_wroot` orthonormal to 1e-2 (the field is named after
+        quaternions, demo.py:320): a handful of elementwise kernels on the current stream, once per ResidentInputs; the verdict (2, n_slots)
+        stays on the device until check_inputs() / collect() reads it."""
+        if not getattr(rin, 'validate', False) or rin.verdict is not None:
+            return
+        n_slots, T = rin.S * rin.P, rin.T
+        m = rin.g['exist'] != 0
+        R = rin.g['rot'].view(n_slots, T, 24, 3, 3)
+        dots = [(R[..., i, :] * R[..., j, :]).sum(-1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(i, 3)]
+        err = torch.stack(dots, -1).abs().amax(dim=(-1, -2))                                     # (n_slots, T)
+        fin = torch.stack([torch.isfinite(rin.g[k]).reshape(n_slots, T, -1).all(-1) for k in ('rot', 'betas', 'trans', 'kp', 'K')], -1).all(-1)
+        bad_rot = (m & ~(err <= 1e-2)).any(-1)
+        rin.verdict = torch.stack([bad_rot, (m & ~fin).any(-1)], 0)                              # (2, n_slots) on the device
+        rin.verdict_ready = torch.cuda.Event()
+        rin.verdict_ready.record()
+        rin.validate = False
 
     @staticmethod
     def _copy_threads():
@@ -518,7 +530,7 @@ class GlobalReconOptimizer:
         if getattr(rin, 'verdict', None) is None:
             return
         from glamr_amd.utils import wire
-        rin.upload_done.synchronize()
+        rin.verdict_ready.synchronize()                                 # computed on the stream that consumed the batch
         v = rin.verdict.cpu().numpy()
         rin.verdict = None
         for kind, msg in ((0, 'smpl_pose_quat_wroot does not hold rotation matrices (|R R^T - I| > 1e-2); the field is named after quaternions but '
@@ -537,6 +549,8 @@ class GlobalReconOptimizer:
         dev, L = self.device, _lib.lib()
         S, P, T, g = rin.S, rin.P, rin.T, rin.g
         n_slots = S * P
+        if not torch.cuda.is_current_stream_capturing():
+            self.value_checks(rin)                                       # (first use of this batch only)
         packed = packing.PackedScenes.empty(S, P, T, dev)
         packed.person_ids = rin.ids
         packed.t['cam_K'] = g['K']
