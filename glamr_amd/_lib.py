@@ -81,6 +81,7 @@ _SIGNATURES = {
     'glamr_host_scatter': (c_int, [c_int, c_void_p, c_int, POINTER(HostStaging), c_void_p, c_void_p, c_int]),
     'glamr_init_workspace_bytes': (c_size_t, [c_int, c_int]),
     'glamr_init_prepare': (c_int, [POINTER(RawBatch), POINTER(SceneBatch), POINTER(PersonArrays), c_int, c_void_p, c_void_p]),
+    'glamr_check_inputs': (c_int, [POINTER(RawBatch), c_void_p, c_void_p, c_void_p]),
     'glamr_init_scenes': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays)] + [c_void_p] * 6),
     'glamr_init_cam_all_frames': (c_int, [POINTER(SceneBatch), c_void_p]),
     'glamr_grecon_param_layout': (c_int, [c_int, c_int, POINTER(ParamLayout)]),

@@ -405,6 +405,39 @@ extern "C" size_t glamr_init_workspace_bytes(int n_slots, int max_len) {
   return (size_t)n_slots * max_len * 74 * sizeof(float);
 }
 
+
+// Value checks of the wire format on the uploaded arrays (glamr_amd/utils/wire.py: keys and shapes are checked on the host, VALUES here):
+// per detected frame every number finite, the 24 matrices of `smpl_pose_quat_wroot` orthonormal to 1e-2.  One pass over the raw batch
+// (1.2 KB per frame), a wave per frame; verdict[0][slot] |= bad rotation, verdict[1][slot] |= non-finite value.
+__global__ __launch_bounds__(256) void check_inputs_kernel(int n_slots, int T, const float* exist, const float* rot, const float* betas, const float* trans,
+                                                           const float* kp, const float* K, int32_t* verdict) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + wave;
+  if (row >= (size_t)n_slots * T) return;
+  if (exist[row] == 0.f) return;
+  const int slot = (int)(row / T);
+  bool nonfinite = false, bad_rot = false;
+  auto fin = [&](float v) { if (!(fabsf(v) <= 3.0e38f)) nonfinite = true; };
+  if (lane < 24) {
+    const float* R = rot + (row * 24 + lane) * 9;
+    float m[9];
+    for (int e = 0; e < 9; ++e) { m[e] = R[e]; fin(m[e]); }
+    for (int i = 0; i < 3; ++i)
+      for (int j = i; j < 3; ++j) {
+        const float d = m[i * 3] * m[j * 3] + m[i * 3 + 1] * m[j * 3 + 1] + m[i * 3 + 2] * m[j * 3 + 2] - (i == j ? 1.0f : 0.0f);
+        if (!(fabsf(d) <= 1e-2f)) bad_rot = true;
+      }
+  } else if (lane < 24 + 48) {        // (lanes 24..63 and a second trip below cover the 48 keypoint values)
+    fin(kp[row * 48 + (lane - 24)]);
+  }
+  if (lane < 8) fin(kp[row * 48 + 40 + lane]);
+  if (lane < 10) fin(betas[row * 10 + lane]);
+  if (lane < 3) fin(trans[row * 3 + lane]);
+  if (lane < 9) fin(K[row * 9 + lane]);
+  if (__any(bad_rot ? 1 : 0) && lane == 0) atomicOr(&verdict[slot], 1);
+  if (__any(nonfinite ? 1 : 0) && lane == 0) atomicOr(&verdict[n_slots + slot], 1);
+}
+
 extern "C" int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, int filter_pose,
                                   void* workspace, void* stream_) {
   GLAMR_REQUIRE(raw && batch && pa && workspace, "null argument");
@@ -418,6 +451,18 @@ extern "C" int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_
              const_cast<float*>(batch->base_trans), const_cast<int32_t*>(batch->fr_start), const_cast<int32_t*>(batch->fr_end),
              pa->nets_pose, pa->nets_vis, static_cast<float*>(workspace)};
   hipLaunchKernelGGL(prep_person_kernel, dim3(raw->n_slots), dim3(256), 0, stream, a);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_check_inputs(const glamr_raw_batch* raw, const float* cam_K, int32_t* verdict, void* stream_) {
+  GLAMR_REQUIRE(raw && cam_K && verdict, "null argument");
+  GLAMR_REQUIRE(raw->exist && raw->rotmats && raw->betas && raw->root_trans && raw->kp_2d, "a raw input array is NULL");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GLAMR_HIP_CHECK(hipMemsetAsync(verdict, 0, (size_t)2 * raw->n_slots * sizeof(int32_t), stream));
+  const size_t rows = (size_t)raw->n_slots * raw->max_len;
+  hipLaunchKernelGGL(check_inputs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, raw->n_slots, raw->max_len, raw->exist, raw->rotmats, raw->betas,
+                     raw->root_trans, raw->kp_2d, cam_K, verdict);
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }

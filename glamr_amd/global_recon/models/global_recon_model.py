@@ -505,18 +505,20 @@ class GlobalReconOptimizer:
     @staticmethod
     def value_checks(rin):
         """Every number of a detection row finite, the 24 matrices of `smpl_pose_quat_wroot` orthonormal to 1e-2 (the field is named after
-        quaternions, demo.py:320): a handful of elementwise kernels on the current stream, once per ResidentInputs; the verdict (2, n_slots)
-        stays on the device until check_inputs() / collect() reads it."""
+        quaternions, demo.py:320): glamr_check_inputs, ONE pass over the uploaded arrays on the current stream (the torch expressions it
+        replaces were 5 ms of reductions per 1024 sequences), once per ResidentInputs; the verdict (2, n_slots) stays on the device until
+        check_inputs() / collect() reads it."""
         if not getattr(rin, 'validate', False) or rin.verdict is not None:
             return
-        n_slots, T = rin.S * rin.P, rin.T
-        m = rin.g['exist'] != 0
-        R = rin.g['rot'].view(n_slots, T, 24, 3, 3)
-        dots = [(R[..., i, :] * R[..., j, :]).sum(-1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(i, 3)]
-        err = torch.stack(dots, -1).abs().amax(dim=(-1, -2))                                     # (n_slots, T)
-        fin = torch.stack([torch.isfinite(rin.g[k]).reshape(n_slots, T, -1).all(-1) for k in ('rot', 'betas', 'trans', 'kp', 'K')], -1).all(-1)
-        bad_rot = (m & ~(err <= 1e-2)).any(-1)
-        rin.verdict = torch.stack([bad_rot, (m & ~fin).any(-1)], 0)                              # (2, n_slots) on the device
+        import ctypes
+        n_slots, T, g = rin.S * rin.P, rin.T, rin.g
+        raw = _lib.RawBatch()
+        raw.n_slots, raw.max_len = n_slots, T
+        for name, ten in (('seq_len', rin.seq_len_slot), ('exist', g['exist']), ('rotmats', g['rot']), ('betas', g['betas']), ('root_trans', g['trans']), ('kp_2d', g['kp'])):
+            setattr(raw, name, ctypes.c_void_p(ten.data_ptr()))
+        verdict = torch.empty((2, n_slots), dtype=torch.int32, device=g['exist'].device)
+        _lib.check(_lib.lib().glamr_check_inputs(ctypes.byref(raw), _lib.ptr(g['K']), _lib.ptr(verdict), _lib.current_stream()))
+        rin.verdict = verdict                                                                    # (2, n_slots) on the device
         rin.verdict_ready = torch.cuda.Event()
         rin.verdict_ready.record()
         rin.validate = False

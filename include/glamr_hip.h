@@ -367,6 +367,11 @@ int glamr_host_scatter(int n_persons, const int64_t* table, int max_len, const g
 size_t glamr_init_workspace_bytes(int n_slots, int max_len);
 /* Fills vis, kp_2d, kp_score, orient_cam, base_orient, base_trans, fr_start, fr_end of `batch` (declared const there because the
  * optimiser only reads them) and every array of `pa`.  cam_K is written by the host directly. */
+/* Value checks of the wire format on the uploaded raw batch (keys and shapes are checked on the host, glamr_amd/utils/wire.py): per detected
+ * frame every number finite and the 24 matrices of `smpl_pose_quat_wroot` orthonormal to 1e-2 (the field is named after quaternions but holds
+ * 3 x 3 matrices, demo.py:320).  One pass over the arrays.  dev out: verdict (2, n_slots) int32: [0][slot] != 0 = a matrix that is no
+ * rotation, [1][slot] != 0 = a non-finite value.  cam_K: dev (n_slots, max_len, 9). */
+int glamr_check_inputs(const glamr_raw_batch* raw, const float* cam_K, int32_t* verdict, void* stream);
 int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, int filter_pose,
                        void* workspace, void* stream);
 /* After glamr_nets_infer: scatters its outputs, fills traj_local_pred, person2cam, rel_transform_cam, cam_pose of `batch`. */
