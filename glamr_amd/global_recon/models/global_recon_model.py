@@ -960,27 +960,28 @@ class GlobalReconOptimizer:
         dev = self.device
         # consecutive batches alternate over two compute streams (the launch seams and tails of one batch are covered by the next, as in bench.py)
         computes = self.__dict__.setdefault('_compute_streams', [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
-        # uploads and downloads on streams of their own: on ONE copy stream the upload of batch i + 1 queued behind the download of batch i,
-        # which waits for batch i's compute -- every batch then paid upload + download (~15 ms) on top of its device time
-        up = self.__dict__.setdefault('_upload_stream', torch.cuda.Stream(device=dev))
+        # A batch's upload goes on ITS OWN compute stream (enqueued while the previous batch computes on the other one: the copy engines run it
+        # right away), downloads on a third stream.  Not more: the runtime multiplexes HIP streams onto 4 hardware queues, and with a separate
+        # upload stream (5 streams with the default one) two of them shared a queue -- a batch then started only when the previous one had
+        # finished (tools/stream_timeline.py).  (One copy stream for both directions was worse still: the upload of batch i + 1 queued behind
+        # the download of batch i, which waits for batch i's compute.)
         down = self.__dict__.setdefault('_download_stream', torch.cuda.Stream(device=dev))
         it = iter(batches)
         lat = iter(latents) if latents is not None else None
+        turn = [0]
 
         def stage(batch):
-            with torch.cuda.stream(up):
+            with torch.cuda.stream(computes[turn[0] % len(computes)]):
                 return self.stage_inputs(batch, next(lat) if lat is not None else None)
         nxt = next(it, None)
         if nxt is None:
             return
         rin = stage(nxt)
         prev = None
-        turn = 0
         while rin is not None:
-            compute = computes[turn % len(computes)]
-            turn += 1
+            compute = computes[turn[0] % len(computes)]
+            turn[0] += 1
             with torch.cuda.stream(compute):
-                compute.wait_event(rin.upload_done)
                 datas, packed = self.optimize_resident(rin, max_iters) if self.latent_mode else self._resident_for_stream(rin, max_iters)
                 done = torch.cuda.Event()
                 done.record()

@@ -10,26 +10,27 @@ m = build_model(root, dev)
 md = synth.make_smpl_model()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 base = [synth.make_in_dict(seed=s, num_frames=300, num_persons=1, smpl_model=md) for s in range(B)]
-list(m.optimize_stream([base, base, base]))
+for _ in m.optimize_stream([base] * 5):
+    pass
 torch.cuda.synchronize()
-computes = m._compute_streams; up = m._upload_stream; down = m._download_stream
+computes = m._compute_streams; down = m._download_stream
 T0 = time.time()
 now = lambda: (time.time() - T0) * 1e3
 log = []
-def stage():
+def stage(k):
     t = now()
-    with torch.cuda.stream(up):
+    with torch.cuda.stream(computes[k % 2]):
         r = m.stage_inputs(base)
     return r, t, now()
-rin, a, b = stage()
+rin, a, b = stage(0)
 log.append(('stage', 0, a, b))
 prev = None
 ev = []
-for k in range(6):
+NB = 8
+for k in range(NB):
     cs = computes[k % 2]
     t_e0 = now()
     with torch.cuda.stream(cs):
-        cs.wait_event(rin.upload_done)
         e0 = torch.cuda.Event(enable_timing=True); e0.record()
         datas, packed = m._resident_for_stream(rin, None)
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
@@ -40,14 +41,14 @@ for k in range(6):
     t_f = now()
     ev.append((e0, e1))
     log.append(('enqueue', k, t_e0, t_e1)); log.append(('fetch_enq', k, t_e1, t_f))
-    if k < 5:
-        rin, a, b = stage(); log.append(('stage', k + 1, a, b))
+    if k < NB - 1:
+        rin, a, b = stage(k + 1); log.append(('stage', k + 1, a, b))
     if prev is not None:
         t = now(); m.collect(*prev); log.append(('collect', k - 1, t, now()))
     prev = (datas, packed, fetched)
-t = now(); m.collect(*prev); log.append(('collect', 5, t, now()))
+t = now(); m.collect(*prev); log.append(('collect', NB - 1, t, now()))
 torch.cuda.synchronize()
-print('total %.1f ms for 6 batches = %.1f ms per batch' % (now(), now() / 6))
+print('total %.1f ms for %d batches = %.1f ms per batch' % (now(), NB, now() / NB))
 for name, k, a, b in log:
     print('%-10s batch %d  %7.1f -> %7.1f  (%5.1f ms)' % (name, k, a, b, b - a))
 base_ev = ev[0][0]
