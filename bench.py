@@ -484,7 +484,7 @@ def run(argv=None):
         # 400 MB each: a one-off ~100 ms the 6-batch figure of rounds 1-2 carried); the timed pass re-uses them
         for _ in model.optimize_stream([in_dicts] * 4):
             pass
-        nb = 8
+        nb = 12
         t0 = time.time()
         n_out = sum(len(r) for r in model.optimize_stream([in_dicts] * nb))
         host_stream = n_out / (time.time() - t0)
