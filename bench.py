@@ -210,6 +210,24 @@ def kernel_lines(asset_root, model, dev):
         'scenes_per_sec': round(B4 / dt, 1), 'ms': round(dt * 1e3, 2), 'stage_launch_ms': [round(x, 2) for x in stage_ms],
         'us_per_scene_iteration': [round(x * 1e3 / n, 1) for x, n in zip(stage_ms, iters)],
         'shared_camera_reduction': 'in-kernel block reduction of the 9 shared camera gradients (one workgroup per scene); see `collective_alternative`'}
+    # latent-optimisation mode: the priors inside the Adam loop, one 300-frame sequence (what the mode is used on)
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.global_recon.models import model_dict
+    cfg = get_config(CFG_ID)
+    cfg['grecon_model_specs'].update(flag_opt_motion_latent=True, flag_opt_traj_latent=True)
+    ml = model_dict['global_recon_model'](cfg, dev, None, smpl=smpl, mt_model=model.mt_model)
+    one = synth.make_in_dict(seed=0, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md)
+    K = 10
+    ml.optimize(one, max_iters=2)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ml.optimize(one, max_iters=K)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    out['latent_optimisation_mode'] = {'workload': 'cfg %s with flag_opt_motion_latent / flag_opt_traj_latent, one %d-frame sequence, %d iterations (init_data included)' % (CFG_ID, NUM_FRAMES, K),
+                                       'ms_per_iteration': round(dt * 1e3 / K, 2),
+                                       'note': 'per iteration: taped infiller (10 windows) + trajectory predictor + skinning + one gradient launch of the stage kernel + '
+                                               'SMPL backward + infiller backward + Adam: ~1 300 launches, host-orchestrated (latency-bound by design: no shipped config uses the mode)'}
     return out
 
 
@@ -490,7 +508,28 @@ def run(argv=None):
         host_stream = n_out / (time.time() - t0)
     coll_us = small_collective_latency(dev, world) if use_dist else None
     latency = one_sequence_latency(model, in_dicts[0]) if (rank == 0 and not args.stub_model and not args.no_kernel_lines and hasattr(model, 'optimize')) else None      # (--no-kernel-lines: profiler runs see the batched launches only)
-    sharded4 = person_sharded_line(asset_root, dev, rank, world) if (use_dist and not args.stub_model and not args.no_kernel_lines) else None
+    sharded4 = None
+    if not args.stub_model and not args.no_kernel_lines:
+        if use_dist:
+            sharded4 = person_sharded_line(asset_root, dev, rank, world)
+        elif world == 1 and on_gpu:
+            # a single-GPU run has no process group: one of ONE rank is created for this line alone, so that the RCCL calls of the
+            # person-sharded schedule execute here too (nothing crosses a link: the figure is the launch + completion cost per iteration)
+            try:
+                import socket
+                sk = socket.socket()
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+                sk.close()
+                os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+                dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+                try:
+                    sharded4 = person_sharded_line(asset_root, dev, 0, 1)
+                finally:
+                    dist.destroy_process_group()
+            except Exception as e:      # noqa: BLE001 -- the headline must not depend on this line
+                sys.stderr.write('bench: person-sharded line skipped (%s)\n' % e)
+                sharded4 = None
 
     out = None
     if rank == 0:
