@@ -606,6 +606,10 @@ def run(argv=None):
 
 def main():
     run()
+    # ONE JSON line on stdout: RCCL prints a version banner to stdout when the process exits (after the line above) -- whatever is
+    # written from here on goes to stderr
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
 
 if __name__ == '__main__':
