@@ -822,15 +822,16 @@ class GlobalReconOptimizer:
         rg = ResidentGraph(graph, datas, packed, st)
         if check:
             torch.cuda.synchronize(self.device)
-            seed = 20260926
-            torch.manual_seed(seed)
-            with torch.cuda.stream(st):
-                _, ref = self.optimize_resident(rin, max_iters)
-            torch.cuda.synchronize(self.device)
-            want = ref.t['kp_2d_pred'].clone()
-            torch.manual_seed(seed)
-            rg.replay()
-            torch.cuda.synchronize(self.device)
+            with torch.random.fork_rng(devices=[self.device]):          # the caller's generators are left as they were
+                seed = 20260926
+                torch.manual_seed(seed)
+                with torch.cuda.stream(st):
+                    _, ref = self.optimize_resident(rin, max_iters)
+                torch.cuda.synchronize(self.device)
+                want = ref.t['kp_2d_pred'].clone()
+                torch.manual_seed(seed)
+                rg.replay()
+                torch.cuda.synchronize(self.device)
             got = packed.t['kp_2d_pred']
             if not (bool(torch.isfinite(got).all()) and torch.equal(got, want)):
                 raise RuntimeError('the replayed step does not reproduce the plain one (max |diff| %.3g)' % float((got - want).abs().max()))
@@ -860,6 +861,10 @@ class GlobalReconOptimizer:
         meps, teps = meps.clone(), teps.clone()
         pa = packed.person_arrays
         h = self.mt_model.handle
+        tape_gb = L.glamr_nets_tape_bytes(h.h, n_slots, T) / 2.0 ** 30
+        if tape_gb > 96:
+            raise ValueError('latent-optimisation mode keeps every activation of the infiller for its backward: %.0f GB for %d person slots of %d frames; '
+                             'run it on smaller batches (the reference runs it on one sequence at a time)' % (tape_gb, n_slots, T))
         lens = np.ascontiguousarray(rin.lens, dtype=np.int32)
         fr_start = packed.t['fr_start'].cpu().numpy()
         occupied = rin.seq_len_slot.cpu().numpy() > 0                    # (person slots a scene with fewer persons leaves empty are skipped)
