@@ -180,12 +180,6 @@ __global__ void window_gather_kernel(const float* pose, const float* visible, co
   x[((size_t)b * WIN + j) * XLD + c] = (t < n) ? pose[((size_t)b * Tpad + t) * XLD + c] : 0.0f;
   if (c == 0) mask[(size_t)b * WIN + j] = (t >= n) ? 1 : ((j >= PAST && visible[(size_t)b * max_len + t] == 0.0f) ? 1 : 0);
 }
-__global__ void add_table_kernel(float* y, const float* table, int rows_per_seq, int n) {   // y[b][i][:] += table[i][:]
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)n) return;
-  const size_t row = idx / D;
-  y[idx] += table[(row % rows_per_seq) * D + idx % D];
-}
 __global__ void tile_rows_kernel(float* y, const float* src, int rows_per_seq, int n) {      // y[b][i][:] = src[i][:]
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)n) return;
@@ -908,8 +902,7 @@ __global__ __launch_bounds__(256) void traj_to_global2_kernel(const float* raw, 
 // mode 0: z sampled from the prior (eps), 1: from the posterior (needs w.gx = the full window, eps), 2: posterior mode.
 int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const float* eps, int eps_stride, float* q_out, float* p_out) {
   const int M = B * WIN;
-  RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M));
-  hipLaunchKernelGGL(add_table_kernel, dim3((M * D + 255) / 256), dim3(256), 0, st, w.h0, h->enc_pe, WIN, M * D);
+  RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M, ACT_NONE, nullptr, 0, h->enc_pe, -WIN, D));      // + the position table, in the GEMM's epilogue
   RC(encoder_layer(st, h->enc[0], w, w.h0, w.h1, B));
   RC(encoder_layer(st, h->enc[1], w, w.h1, w.h0, B));
   float* ctx = w.h0;
@@ -917,8 +910,7 @@ int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const
     // posterior: [mu token, logvar token, 30 current frames] attend to each other and to the context (DataEncoder.forward :204-249)
     float* x32 = w.dq;
     hipLaunchKernelGGL(posterior_rows_kernel, dim3(B, 32), dim3(XLD), 0, st, w.gx, w.h1);      // w.h1 is free after the encoder: [B][32][96] rows
-    RC(lin(st, h->qe_in, w.h1, XLD, x32, D, B * 32));
-    hipLaunchKernelGGL(add_table_kernel, dim3((B * 32 * D + 255) / 256), dim3(256), 0, st, x32, h->qe_table, 32, B * 32 * D);
+    RC(lin(st, h->qe_in, w.h1, XLD, x32, D, B * 32, ACT_NONE, nullptr, 0, h->qe_table, -32, D));
     RC(decoder_layer(st, h->qe[0], w, x32, ctx, B, 32));
     RC(decoder_layer(st, h->qe[1], w, x32, ctx, B, 32));
     hipLaunchKernelGGL(take_rows_kernel, dim3(B, 2), dim3(D), 0, st, x32, 32, 2, w.q2);

@@ -237,8 +237,7 @@ void attn_bwd(const TapeCtx& c, const float* Q, int ldq, const float* K, const f
 // ---- forward of one window, every activation kept (mirrors infiller_window / encoder_layer / decoder_layer, small-batch path) -------
 int taped_window(glamr_nets* h, hipStream_t st, WinTape& w, int B, const float* eps, int eps_stride) {
   const int M = B * WIN, MC = B * CUR;
-  RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M));
-  hipLaunchKernelGGL(add_table_kernel, dim3((M * D + 255) / 256), dim3(256), 0, st, w.h0, h->enc_pe, WIN, M * D);
+  RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M, ACT_NONE, nullptr, 0, h->enc_pe, -WIN, D));
   const float* hin = w.h0;
   for (int l = 0; l < 2; ++l) {
     const EncLayer& E = h->enc[l];

@@ -19,6 +19,7 @@ constexpr int GT_M = 64, GT_N = 64, GT_K = 32, GT_LD = 36;   // LDS row stride 3
 enum Act { ACT_NONE = 0, ACT_RELU = 1 };
 
 // Y[M,N] = act(X[M,K] W[N,K]^T + bias[N] + (rowbias ? rowbias[row / rows_per_group][N] : 0)) + (R ? R[M,N] : 0)
+// (rows_per_group < 0: a per-POSITION table instead, rowbias[row % -rows_per_group][N] -- the folded position codes of a window's tokens)
 //   X: ldx >= K (K multiple of 32, zero padded), W: [Npad][K] with Npad a multiple of 64 (zero rows), Y/R: ldy.
 // Tile 64x64 per 256-thread workgroup, each wave owns a 32x32 accumulator (v_mfma_f32_32x32x2_f32); both operands are staged
 // through LDS in 32-deep K chunks; lanes 0-31 / 32-63 consume the low / high 16 k of a chunk so every lane reads contiguous k.
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
     if (m >= a.M) continue;
     float v = acc[r] + b;
-    if (a.rowbias) v += a.rowbias[(size_t)(m / a.rows_per_group) * a.ldrb + n];
+    if (a.rowbias) v += a.rowbias[(size_t)(a.rows_per_group > 0 ? m / a.rows_per_group : m % (-a.rows_per_group)) * a.ldrb + n];
     if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
     if (a.R) v += a.R[(size_t)m * a.ldr + n];
     a.Y[(size_t)m * a.ldy + n] = v;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
         const int m = m0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
         if (m >= a.M) continue;
         float v = acc[i][j][q] + b;
-        if (a.rowbias) v += a.rowbias[(size_t)(m / a.rows_per_group) * a.ldrb + n];
+        if (a.rowbias) v += a.rowbias[(size_t)(a.rows_per_group > 0 ? m / a.rows_per_group : m % (-a.rows_per_group)) * a.ldrb + n];
         if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
         if (a.R) v += a.R[(size_t)m * a.ldr + n];
         a.Y[(size_t)m * a.ldy + n] = v;

@@ -401,3 +401,40 @@ def test_forced_fp32_kernels_match_the_reference(asset_root, golden, monkeypatch
     print('fp32-only kernels at batch 600 vs reference: body pose %.2e, local trajectory %.2e, translation %.2e' % e)
     assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 2e-4
     hf.close()
+
+
+def test_graph_cache_and_resident_sets_are_bounded(priors):
+    """The priors replay a call they have seen twice as a HIP graph, keyed by geometry and buffer addresses; the handle keeps at most 24
+    graphs (least recently used evicted, its executable destroyed) and the Python side at most three resident buffer sets per stream: a
+    dataset of videos of many lengths must not grow device memory or graph count without bound.  30 geometries, each called twice on its
+    own persistent buffers; the first one -- evicted by then -- still gives the values it gave before."""
+    dev = torch.device('cuda:0')
+    outs = {}
+    bufs = {}
+    for T in range(41, 71):
+        b = {k: torch.tensor(v, device=dev) for k, v in mg.net_inputs(T, seed=T).items()}
+        nw = b['in_motion_latent'].shape[0]
+        rs = dict(pose=torch.empty(1, T, 69, device=dev), local_traj=torch.empty(1, T, 11, device=dev), trans=torch.empty(1, T, 3, device=dev),
+                  orient=torch.empty(1, T, 3, device=dev),
+                  ws=torch.empty(_ws_bytes(priors, 1, T), dtype=torch.uint8, device=dev), persistent=False)
+        bufs[T] = (b, rs)
+        for _ in range(2):          # second call: captured
+            o = priors.infer(b['in_body_pose'], b['frame_mask'], [T], motion_eps=b['in_motion_latent'][None], traj_eps=b['in_traj_latent'], buffers=rs)
+        outs[T] = {k: v.clone() for k, v in o.items()}
+    b, rs = bufs[41]
+    for _ in range(3):              # plain, captured again, replayed
+        o = priors.infer(b['in_body_pose'], b['frame_mask'], [41], motion_eps=b['in_motion_latent'][None], traj_eps=b['in_traj_latent'], buffers=rs)
+        for k in o:
+            assert torch.equal(o[k], outs[41][k]), k
+    # resident sets: least recently used dropped beyond three per stream
+    for i, T in enumerate((50, 60, 70, 80, 90)):
+        priors.resident_set(2, T, 3)
+    sid = torch.cuda.current_stream(dev).cuda_stream
+    assert len(priors._ring[sid]) == priors.RESIDENT_GEOMETRIES == 3 and (2, 50, 3) not in priors._ring[sid] and (2, 90, 3) in priors._ring[sid]
+    first = priors.resident_set(2, 90, 3)
+    assert first['uses'] == 2 and first['persistent']          # a set tells the library to capture from its second use on
+
+
+def _ws_bytes(priors, B, T):
+    from glamr_amd import _lib
+    return _lib.lib().glamr_nets_workspace_bytes(priors.h, B, T)
