@@ -280,7 +280,7 @@ def small_collective_latency(dev, world):
     return (time.time() - t0) / n * 1e6
 
 
-def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8):
+def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8, group=None):
     """BASELINE configs[3] both ways on this job's ranks (SURVEY 8e "measure both and report"): `iters` iterations of every stage of cfg
     glamr_static_multi on `scenes` 4-person 300-frame scenes, (a) the default schedule -- one workgroup per scene, the shared camera's gradient
     reduced on chip, every rank its own scenes -- and (b) the person-sharded schedule (glamr_amd/parallel.py PersonShardedSchedule): the persons
@@ -307,7 +307,7 @@ def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8):
     def sharded():
         torch.manual_seed(4)
         _, packed = m4.init_resident(rin, init_forward=False)
-        sched = parallel.PersonShardedSchedule()
+        sched = parallel.PersonShardedSchedule(group=group)
         torch.cuda.synchronize()
         t0 = time.time()
         sched.run(packed, m4.opt_stage_specs, m4.specs, max_iters=iters)
@@ -511,7 +511,11 @@ def run(argv=None):
     sharded4 = None
     if not args.stub_model and not args.no_kernel_lines:
         if use_dist:
-            sharded4 = person_sharded_line(asset_root, dev, rank, world)
+            # 4 persons: at most 4 ranks take part (a sub-group of the first four on a larger job; every rank creates the group)
+            n_sh = min(world, 4)
+            grp = dist.new_group(list(range(n_sh))) if world > n_sh else None
+            if rank < n_sh:
+                sharded4 = person_sharded_line(asset_root, dev, rank, n_sh, group=grp)
         elif world == 1 and on_gpu:
             # a single-GPU run has no process group: one of ONE rank is created for this line alone, so that the RCCL calls of the
             # person-sharded schedule execute here too (nothing crosses a link: the figure is the launch + completion cost per iteration)

@@ -1029,7 +1029,9 @@ inline int launch_rows(hipStream_t st, const float* X, int ldx, int M, int K1, c
   // 32-row blocks: two workgroups per CU (measured on 1024 x 300 frames, both priors: 20.6 ms against 21.7 with 64-row blocks);
   // GLAMR_ROWS_RT=2 selects the 64-row instances (A/B runs)
   static const int rt_env = std::getenv("GLAMR_ROWS_RT") ? std::atoi(std::getenv("GLAMR_ROWS_RT")) : 0;
-  const int rt = rt_env == 1 || rt_env == 2 ? rt_env : 1;
+  static const int rt_one = std::getenv("GLAMR_ROWS_RT_ONE") ? std::atoi(std::getenv("GLAMR_ROWS_RT_ONE")) : 0;      // (one-layer blocks only)
+  const int rt_sel = (!W1s && (rt_one == 1 || rt_one == 2)) ? rt_one : rt_env;
+  const int rt = rt_sel == 1 || rt_sel == 2 ? rt_sel : 1;
   const int rb = 32 * rt;
   const size_t lds = rows_fused_lds(K1, W1s != nullptr, rb);
   static bool attr_done = false;
