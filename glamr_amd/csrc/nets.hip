@@ -11,6 +11,7 @@
 // cross-attention queries do not depend on the data and are precomputed.
 #include "common.hpp"
 #include "nn_kernels.hpp"
+#include "nn_free.hpp"
 #include "block_rt.hpp"
 #include "rotmath.hpp"
 #include <vector>
@@ -175,45 +176,49 @@ namespace {
 
 // window input rows + key-padding mask (get_seg_data :564-587, mask[:, :10] = False :629)
 __global__ void window_gather_kernel(const float* pose, const float* visible, const int* lens, int Tpad, int max_len, int s, float* x, unsigned char* mask) {
-  const int b = blockIdx.x, j = blockIdx.y, c = threadIdx.x;          // 96 threads
+  const int b = blockIdx.x, j = blockIdx.y;
   const int t = s + j, n = lens[b];
-  x[((size_t)b * WIN + j) * XLD + c] = (t < n) ? pose[((size_t)b * Tpad + t) * XLD + c] : 0.0f;
-  if (c == 0) mask[(size_t)b * WIN + j] = (t >= n) ? 1 : ((j >= PAST && visible[(size_t)b * max_len + t] == 0.0f) ? 1 : 0);
+  for (int c = threadIdx.x; c < XLD; c += blockDim.x) x[((size_t)b * WIN + j) * XLD + c] = (t < n) ? pose[((size_t)b * Tpad + t) * XLD + c] : 0.0f;
+  if (threadIdx.x == 0) mask[(size_t)b * WIN + j] = (t >= n) ? 1 : ((j >= PAST && visible[(size_t)b * max_len + t] == 0.0f) ? 1 : 0);
 }
-__global__ void tile_rows_kernel(float* y, const float* src, int rows_per_seq, int n) {      // y[b][i][:] = src[i][:]
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)n) return;
-  const size_t row = idx / D;
-  y[idx] = src[(row % rows_per_seq) * D + idx % D];
+__global__ void tile_rows_kernel(float* y, const float* src, int rows_per_seq, int n, int frag = 0) {      // y[b][i][:] = src[i][:]
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)blockIdx.x * 256 + 256 && idx < (size_t)n; idx += blockDim.x) {
+    const size_t row = idx / D;
+    y[frag ? x32_off((int)row, (int)(idx % D), D) : idx] = src[(row % rows_per_seq) * D + idx % D];
+  }
 }
 // z = mu + eps * exp(0.5 logvar); pz rows: [b][tok][256] with mu = row tok0 cols [0,128), logvar = row tok1 cols [128,256)
 __global__ void reparam_infiller_kernel(const float* pz, const float* eps, int eps_stride, float* z, int B) {
-  const int b = blockIdx.x, k = threadIdx.x;
-  const float mu = pz[((size_t)b * 2 + 0) * D + k], lv = pz[((size_t)b * 2 + 1) * D + NZ + k];
-  z[(size_t)b * NZ + k] = mu + eps[(size_t)b * eps_stride + k] * expf(0.5f * lv);
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < NZ; k += blockDim.x) {
+    const float mu = pz[((size_t)b * 2 + 0) * D + k], lv = pz[((size_t)b * 2 + 1) * D + NZ + k];
+    z[(size_t)b * NZ + k] = mu + eps[(size_t)b * eps_stride + k] * expf(0.5f * lv);
+  }
 }
 __global__ void reparam_traj_kernel(const float* pz, const float* eps, float* z) {
-  const int b = blockIdx.x, k = threadIdx.x;
-  z[(size_t)b * NZ + k] = pz[(size_t)b * D + k] + eps[(size_t)b * NZ + k] * expf(0.5f * pz[(size_t)b * D + NZ + k]);
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < NZ; k += blockDim.x) z[(size_t)b * NZ + k] = pz[(size_t)b * D + k] + eps[(size_t)b * NZ + k] * expf(0.5f * pz[(size_t)b * D + NZ + k]);
 }
 // q[b][i][:] = zproj[b][:] + table[i][:]
-__global__ void build_queries_kernel(const float* zproj, const float* table, float* q) {
-  const int b = blockIdx.x, i = blockIdx.y, k = threadIdx.x;
-  q[((size_t)b * CUR + i) * D + k] = zproj[(size_t)b * D + k] + table[(size_t)i * D + k];
+__global__ void build_queries_kernel(const float* zproj, const float* table, float* q, int frag = 0) {
+  const int b = blockIdx.x, i = blockIdx.y;
+  for (int k = threadIdx.x; k < D; k += blockDim.x)
+    q[frag ? x32_off(b * CUR + i, k, D) : ((size_t)b * CUR + i) * D + k] = zproj[(size_t)b * D + k] + table[(size_t)i * D + k];
 }
 // write the 30 generated frames of window s back into the running pose buffer (get_res_from_cur_data :604-607)
 __global__ void window_scatter_kernel(const float* y, int ldy, const int* lens, int Tpad, int s, float* pose) {
-  const int b = blockIdx.x, i = blockIdx.y, c = threadIdx.x;          // 69 active of 96
+  const int b = blockIdx.x, i = blockIdx.y;
   const int t = s + PAST + i;
-  if (c < 69 && t < lens[b] && s < lens[b] - PAST) pose[((size_t)b * Tpad + t) * XLD + c] = y[((size_t)b * CUR + i) * ldy + c];
+  if (t < lens[b] && s < lens[b] - PAST)
+    for (int c = threadIdx.x; c < 69; c += blockDim.x) pose[((size_t)b * Tpad + t) * XLD + c] = y[((size_t)b * CUR + i) * ldy + c];
 }
 __global__ void pose_in_kernel(const float* body_pose, int max_len, int Tpad, float* pose) {   // [B][max_len][69] -> [B][Tpad][96]
-  const int b = blockIdx.x, t = blockIdx.y, c = threadIdx.x;
-  pose[((size_t)b * Tpad + t) * XLD + c] = (t < max_len && c < 69) ? body_pose[((size_t)b * max_len + t) * 69 + c] : 0.0f;
+  const int b = blockIdx.x, t = blockIdx.y;
+  for (int c = threadIdx.x; c < XLD; c += blockDim.x) pose[((size_t)b * Tpad + t) * XLD + c] = (t < max_len && c < 69) ? body_pose[((size_t)b * max_len + t) * 69 + c] : 0.0f;
 }
 __global__ void pose_out_kernel(const float* pose, int max_len, int Tpad, const int* lens, float* out_pose) {
-  const int b = blockIdx.x, t = blockIdx.y, c = threadIdx.x;
-  if (c < 69) out_pose[((size_t)b * max_len + t) * 69 + c] = (t < lens[b]) ? pose[((size_t)b * Tpad + t) * XLD + c] : 0.0f;
+  const int b = blockIdx.x, t = blockIdx.y;
+  for (int c = threadIdx.x; c < 69; c += blockDim.x) out_pose[((size_t)b * max_len + t) * 69 + c] = (t < lens[b]) ? pose[((size_t)b * Tpad + t) * XLD + c] : 0.0f;
 }
 // forward kinematics of the 23 body joints relative to the root, zero root orientation, unshaped template
 // (TrajPredVAE.get_joint_pos :384-394 -> SMPL.get_joints smpl.py:318-343); a thread per (frame, joint), the chain one tree level at a
@@ -262,11 +267,13 @@ __global__ __launch_bounds__(256) void fk_joints_kernel(const float* pose, int T
   if (j > 0) for (int c = 0; c < 3; ++c) xo[(j - 1) * 3 + c] = sP[fl][j][c] - sP[fl][0][c];
   else for (int c = 69; c < XLD; ++c) xo[c] = 0.0f;
 }
-__global__ void masked_mean_kernel(const float* ctx, int max_len, const int* lens, float* mean) {   // [B][max_len][256] -> [B][256]
-  const int b = blockIdx.x, k = threadIdx.x, n = lens[b];
-  float s = 0.f;
-  for (int t = 0; t < n; ++t) s += ctx[((size_t)b * max_len + t) * D + k];
-  mean[(size_t)b * D + k] = s / (float)n;
+__global__ void masked_mean_kernel(const float* ctx, int max_len, const int* lens, float* mean, int frag = 0) {   // [B][max_len][256] -> [B][256]
+  const int b = blockIdx.x, n = lens[b];
+  for (int k = blockIdx.y * blockDim.x + threadIdx.x; k < D; k += blockDim.x * gridDim.y) {
+    float s = 0.f;
+    for (int t = 0; t < n; ++t) s += ctx[frag ? x32_off(b * max_len + t, k, D) : ((size_t)b * max_len + t) * D + k];
+    mean[(size_t)b * D + k] = s / (float)n;
+  }
 }
 // local trajectory -> global translation / orientation for one sequence per workgroup (traj_utils.py:65-88 + quat->aa)
 __global__ __launch_bounds__(256) void traj_to_global_kernel(const float* raw, int ldraw, int max_len, const int* lens, float* local, float* trans,
@@ -326,7 +333,7 @@ Ws ws_layout(int B, int max_len, char* base) {
   if (nwin < 1) nwin = 1;
   w.Tpad = std::max(max_len, (nwin - 1) * CUR + WIN);
   size_t off = 0;
-  auto take = [&](size_t nfloats) { float* p = reinterpret_cast<float*>(base + off); off = align_up(off + nfloats * sizeof(float), 256); return p; };
+  auto take = [&](size_t nfloats) { float* p = reinterpret_cast<float*>(base + off); off = align_up(off + (nfloats + 32 * 1024) * sizeof(float), 256); return p; };      // (+ 32 rows: the fragment-major kernels of nn_free.hpp work in whole 32-row blocks)
   const size_t MW = (size_t)B * WIN, MT = (size_t)B * max_len;
   w.pose = take((size_t)B * w.Tpad * XLD);
   w.x = take(MW * XLD); w.h0 = take(MW * D); w.h1 = take(MW * D); w.qkv = take(MW * 3 * D); w.att = take(MW * D); w.tmp = take(MW * D);
@@ -347,6 +354,15 @@ Ws ws_layout(int B, int max_len, char* base) {
 
 // set by every entry point from its handle: 1 = the plain fp32 kernels only (range analysis of glamr_nets_create)
 thread_local int tl_fp32 = 0;
+// set by every entry point from the batch size: 1 = the LDS-free one-wave kernels of nn_free.hpp, which run beside resident workgroups of
+// the optimiser stage (large batches: the other stream of a pipelined caller is inside a stage launch most of the time);
+// GLAMR_NETS_FREE=0 keeps the fused LDS kernels (A/B runs)
+thread_local int tl_free = 0;
+inline size_t cp(int col) { return tl_free ? (size_t)col * 32 : (size_t)col; }      // pointer offset of column `col` (a multiple of 16) in either layout
+inline bool free_allowed() {
+  const char* e = std::getenv("GLAMR_NETS_FREE");      // read per call: A/B runs switch it inside one process
+  return !(e && std::atoi(e) == 0);
+}
 
 // attention in plain fp32 (fp32_only handles): 8 heads x 32 dims, Lq, Lk <= 64, one workgroup per (sequence, head), lane = query row;
 // same contract as attention_mfma_kernel (key_mask != 0 -> key ignored, a fully masked row yields zeros)
@@ -383,43 +399,56 @@ template <class... A>
 void launch_attention(dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldk,
                       const unsigned char* mask, float* O, int ldo, int Lq, int Lk, int q_shared) {
   if (tl_fp32) hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(64), 0, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
+  else if (tl_free) hipLaunchKernelGGL(attention_free_kernel, dim3(grid.x * 8), dim3(64), 0, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
   else hipLaunchKernelGGL(attention_mfma_kernel, grid, block, lds, st, Q, ldq, K, V, ldk, mask, O, ldo, Lq, Lk, q_shared);
 }
 
 int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, int rows) {
+  if (tl_free) { hipLaunchKernelGGL(ln_free_kernel, dim3((rows + 31) / 32), dim3(64), 0, st, X, R, n.g, n.b, Y, rows); return GLAMR_OK; }
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, R, n.g, n.b, Y, rows, D);
   return GLAMR_OK;
 }
 constexpr int FUSE_MIN_ROWS = 2048;
 inline bool fuse_attention(int M) {
   static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE_ATTN") != nullptr || std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;      // development aid
-  return !no_fuse && !tl_fp32 && M >= FUSE_MIN_ROWS;
+  return !no_fuse && !tl_fp32 && !tl_free && M >= FUSE_MIN_ROWS;
 }      // below this the launches are latency-bound either way: separate small-M kernels
 // Y = LayerNorm(X W^T + b + R): attention out-projection + residual + norm in one pass over the rows
 int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const float* R, float* Y, float* tmp, int M);
 // Y = [LayerNorm](act2(relu(X W1^T + b1) W2^T + b2) [+ R]): feed-forward block / two-layer MLP with the hidden rows on chip
 int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float* X, int ldx, const float* R, float* Y, float* hidden, float* tmp, int M,
-         int act2);
+         int act2, int xl = -1);
 
 int lin(hipStream_t st, const Lin& L, const float* X, int ldx, float* Y, int ldy, int M, int act = ACT_NONE, const float* R = nullptr, int ldr = 0,
-        const float* rowbias = nullptr, int rpg = 1, int ldrb = 0) {
+        const float* rowbias = nullptr, int rpg = 1, int ldrb = 0, int xl = -1, int yl = -1) {
+  // xl / yl (free mode only): layout of X, resp. Y and R -- 1 fragment-major (the default there), 0 row-major (what an LDS kernel or a small
+  // elementwise kernel produced / will consume)
+  if (tl_free && L.Ws && M > 0) {
+    if (L.K % 32 != 0 || ldx % 4 != 0 || ldy % 4 != 0) return fail(GLAMR_E_INVALID, "gemm: K=%d must be a multiple of 32, ldx=%d / ldy=%d of 4", L.K, ldx, ldy);
+    GemmArgs a{X, L.W, L.b, rowbias, R, Y, M, L.N, L.K, ldx, ldy, ldr, rpg, ldrb, act};
+    a.Ws = L.Ws;
+    a.ws_plane = (size_t)((L.N + 63) / 64 * 64) * L.K;
+    a.x_frag = xl != 0;
+    a.y_frag = yl != 0;
+    return launch_gemm_free(st, a);
+  }
   return launch_gemm(st, X, ldx, L.W, L.b, Y, ldy, M, L.N, L.K, act, R, ldr, rowbias, rpg, ldrb, L.Ws);
 }
 
 int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const float* R, float* Y, float* tmp, int M) {
   static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;      // development aid: the separate GEMM + LayerNorm launches
-  if (!no_fuse && M >= FUSE_MIN_ROWS && L.N == D && L.K == D && L.Ws)
+  if (!no_fuse && !tl_free && M >= FUSE_MIN_ROWS && L.N == D && L.K == D && L.Ws)
     return launch_rows(st, X, D, M, D, nullptr, 0, nullptr, nullptr, 1, 0, L.Ws, (size_t)D * L.K, L.K, L.b, ACT_NONE, R, D, n.g, n.b, Y, D);
   RC(lin(st, L, X, D, tmp, D, M));
   return ln(st, tmp, R, n, Y, M);
 }
 int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float* X, int ldx, const float* R, float* Y, float* hidden, float* tmp, int M,
-         int act2) {
+         int act2, int xl) {
   static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;
-  if (!no_fuse && M >= FUSE_MIN_ROWS && L1.N == FF && L2.N == D && L2.K == FF && L1.K <= D && L1.Ws && L2.Ws)
+  if (!no_fuse && !tl_free && M >= FUSE_MIN_ROWS && L1.N == FF && L2.N == D && L2.K == FF && L1.K <= D && L1.Ws && L2.Ws)
     return launch_rows(st, X, ldx, M, L1.K, L1.Ws, (size_t)FF * L1.K, L1.b, nullptr, 1, 0, L2.Ws, (size_t)D * L2.K, L2.K, L2.b, act2, R, D,
                        n ? n->g : nullptr, n ? n->b : nullptr, Y, D);
-  RC(lin(st, L1, X, ldx, hidden, FF, M, ACT_RELU));
+  RC(lin(st, L1, X, ldx, hidden, FF, M, ACT_RELU, nullptr, 0, nullptr, 1, 0, xl));
   if (!n) return lin(st, L2, hidden, FF, Y, D, M, act2, R, D);
   RC(lin(st, L2, hidden, FF, tmp, D, M, act2));
   return ln(st, tmp, R, *n, Y, M);
@@ -721,7 +750,7 @@ int encoder_layer(hipStream_t st, const EncLayer& E, Ws& w, float* h_in, float* 
     RC(launch_qkv_attention(st, B, QkvAttnArgs{h_in, WIN, h_in, WIN, E.qkv.Ws, pl, E.qkv.b, 0, E.qkv.Ws, pl, E.qkv.b, 8, 16, w.mask, w.att, D}));
   } else {
     RC(lin(st, E.qkv, h_in, D, w.qkv, 3 * D, M));
-    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, w.mask, w.att, D, WIN, WIN, 0);
+    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + cp(D), w.qkv + cp(2 * D), 3 * D, w.mask, w.att, D, WIN, WIN, 0);
   }
   RC(proj_ln(st, E.o, E.n1, w.att, h_in, h_out, w.tmp, M));
   RC(mlp2(st, E.f1, E.f2, &E.n2, h_out, D, h_out, h_out, w.ff, w.tmp, M, ACT_NONE));
@@ -736,7 +765,7 @@ int decoder_layer(hipStream_t st, const DecLayer& Dl, Ws& w, float* x, const flo
     RC(launch_qkv_attention(st, B, QkvAttnArgs{x, Lq, x, Lq, Dl.sa_qkv.Ws, pl, Dl.sa_qkv.b, 0, Dl.sa_qkv.Ws, pl, Dl.sa_qkv.b, 8, 16, nullptr, w.att, D}));
   } else {
     RC(lin(st, Dl.sa_qkv, x, D, w.qkv, 3 * D, M));
-    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, (const unsigned char*)nullptr, w.att, D, Lq, Lq, 0);
+    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + cp(D), w.qkv + cp(2 * D), 3 * D, (const unsigned char*)nullptr, w.att, D, Lq, Lq, 0);
   }
   RC(proj_ln(st, Dl.sa_o, Dl.n1, w.att, x, x, w.tmp, M));
   if (fuse_attention(M)) {
@@ -745,7 +774,7 @@ int decoder_layer(hipStream_t st, const DecLayer& Dl, Ws& w, float* x, const flo
   } else {
     RC(lin(st, Dl.ca_q, x, D, w.qbuf, D, M));
     RC(lin(st, Dl.ca_kv, ctx, D, w.ctxkv, 2 * D, B * WIN));
-    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qbuf, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, Lq, WIN, 0);
+    launch_attention( dim3(B, 8), dim3(64), 0, st, w.qbuf, D, w.ctxkv, w.ctxkv + cp(D), 2 * D, w.mask, w.att, D, Lq, WIN, 0);
   }
   RC(proj_ln(st, Dl.ca_o, Dl.n2, w.att, x, x, w.tmp, M));
   RC(mlp2(st, Dl.f1, Dl.f2, &Dl.n3, x, D, x, x, w.ff, w.tmp, M, ACT_NONE));
@@ -902,7 +931,7 @@ __global__ __launch_bounds__(256) void traj_to_global2_kernel(const float* raw, 
 // mode 0: z sampled from the prior (eps), 1: from the posterior (needs w.gx = the full window, eps), 2: posterior mode.
 int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const float* eps, int eps_stride, float* q_out, float* p_out) {
   const int M = B * WIN;
-  RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M, ACT_NONE, nullptr, 0, h->enc_pe, -WIN, D));      // + the position table, in the GEMM's epilogue
+  RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M, ACT_NONE, nullptr, 0, h->enc_pe, -WIN, D, 0));      // (w.x is row-major in every mode)      // + the position table, in the GEMM's epilogue
   RC(encoder_layer(st, h->enc[0], w, w.h0, w.h1, B));
   RC(encoder_layer(st, h->enc[1], w, w.h1, w.h0, B));
   float* ctx = w.h0;
@@ -919,25 +948,25 @@ int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const
   }
   // prior: two learned tokens attend to the context
   RC(lin(st, h->prior_kv, ctx, D, w.ctxkv, 2 * D, M));
-  launch_attention( dim3(B, 8), dim3(64), 0, st, h->prior_q, D, w.ctxkv, w.ctxkv + D, 2 * D, w.mask, w.att, D, 2, WIN, 1);
+  launch_attention( dim3(B, 8), dim3(64), 0, st, h->prior_q, D, w.ctxkv, w.ctxkv + cp(D), 2 * D, w.mask, w.att, D, 2, WIN, 1);
   RC(lin(st, h->prior_o, w.att, D, w.tmp, D, B * 2));
-  hipLaunchKernelGGL(tile_rows_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, st, w.dq, h->prior_x1, 2, B * 2 * D);
+  hipLaunchKernelGGL(tile_rows_kernel, dim3((B * 2 * D + 255) / 256), dim3(64), 0, st, w.dq, h->prior_x1, 2, B * 2 * D, tl_free);
   RC(ln(st, w.tmp, w.dq, h->prior_n2, w.dq, B * 2));
   RC(lin(st, h->prior_f1, w.dq, D, w.ff, FF, B * 2, ACT_RELU));
   RC(lin(st, h->prior_f2, w.ff, FF, w.tmp, D, B * 2));
   RC(ln(st, w.tmp, w.dq, h->prior_n3, w.dq, B * 2));
-  RC(lin(st, h->prior_pz, w.dq, D, w.pz, D, B * 2));
+  RC(lin(st, h->prior_pz, w.dq, D, w.pz, D, B * 2, ACT_NONE, nullptr, 0, nullptr, 1, 0, -1, 0));      // row-major out: elementwise kernels read it
   if (p_out) hipLaunchKernelGGL(dist_out_kernel, dim3(B), dim3(NZ), 0, st, w.pz, p_out);
-  if (mode == GLAMR_VAE_INFER) hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.pz, eps, eps_stride, w.z, B);
-  else if (mode == GLAMR_VAE_TRAIN) hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.qpz, eps, eps_stride, w.z, B);
+  if (mode == GLAMR_VAE_INFER) hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(64), 0, st, w.pz, eps, eps_stride, w.z, B);
+  else if (mode == GLAMR_VAE_TRAIN) hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(64), 0, st, w.qpz, eps, eps_stride, w.z, B);
   else hipLaunchKernelGGL(mode_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.qpz, w.z);
   // decoder: 30 queries = position code of z
-  RC(lin(st, h->dec_z, w.z, NZ, w.zproj, D, B));
-  hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(D), 0, st, w.zproj, h->dec_pe, w.dq);
+  RC(lin(st, h->dec_z, w.z, NZ, w.zproj, D, B, ACT_NONE, nullptr, 0, nullptr, 1, 0, 0, 0));
+  hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(64), 0, st, w.zproj, h->dec_pe, w.dq, tl_free);
   RC(decoder_layer(st, h->dec[0], w, w.dq, ctx, B, CUR));
   RC(decoder_layer(st, h->dec[1], w, w.dq, ctx, B, CUR));
   RC(mlp2(st, h->out1, h->out2, nullptr, w.dq, D, nullptr, w.tmp, w.ff, w.tmp, B * CUR, ACT_RELU));
-  RC(lin(st, h->outfc, w.tmp, D, w.y, 128, B * CUR));
+  RC(lin(st, h->outfc, w.tmp, D, w.y, 128, B * CUR, ACT_NONE, nullptr, 0, nullptr, 1, 0, -1, 0));
   return GLAMR_OK;
 }
 
@@ -956,12 +985,12 @@ void bilstm(glamr_nets* h, hipStream_t st, const float* G, float* const hh[2], c
 int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const int* lens_run, int mode, const float* eps, float* q_out, float* p_out,
               const float* init, int ldinit, float* out_orig, float* out_local, float* out_trans, float* out_orient, float* out_orient_q) {
   const int MT = B * max_len;
-  RC(mlp2(st, h->t_in1, h->t_in2, nullptr, w.tx, XLD, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU));
+  RC(mlp2(st, h->t_in1, h->t_in2, nullptr, w.tx, XLD, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU, 0));      // (joint rows: row-major)
   for (int l = 0; l < 2; ++l) {
-    RC(lin(st, h->t_ih[l], w.th, D, w.tg, 1024, MT));
+    RC(lin(st, h->t_ih[l], w.th, D, w.tg, 1024, MT, ACT_NONE, nullptr, 0, nullptr, 1, 0, l == 0 ? -1 : 0, 0));      // the recurrence reads and writes row-major rows
     bilstm(h, st, w.tg, h->t_hh[l], lens_run, w.th, max_len, B);
   }
-  RC(mlp2(st, h->t_out1, h->t_out2, nullptr, w.th, D, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU));          // context [B][max_len][256]
+  RC(mlp2(st, h->t_out1, h->t_out2, nullptr, w.th, D, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU, 0));       // context [B][max_len][256]
   if (mode != GLAMR_VAE_INFER) {
     // posterior (DataEncoder.forward :160-199): [t_h, aa(q_h)] -> in_mlp -> 2 bi-LSTM -> out_mlp; fused with the context, mean over time
     RC(lin(st, h->te_in1, w.e6, 32, w.tg, FF, MT, ACT_RELU));
@@ -975,22 +1004,22 @@ int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const in
     hipLaunchKernelGGL(copy_cols_kernel, dim3(((size_t)MT * D + 255) / 256), dim3(256), 0, st, w.th, D, w.tcat, FF, D, (size_t)MT * D);
     RC(lin(st, h->te_f1, w.tcat, FF, w.tg, FF, MT, ACT_RELU));
     RC(lin(st, h->te_f2, w.tg, FF, w.te, D, MT, ACT_RELU));
-    hipLaunchKernelGGL(masked_mean_kernel, dim3(B), dim3(D), 0, st, w.te, max_len, lens_run, w.tmean);
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(B, 4), dim3(64), 0, st, w.te, max_len, lens_run, w.tmean);
     RC(lin(st, h->te_qz, w.tmean, D, w.tqz, D, B));
     if (q_out) GLAMR_HIP_CHECK(hipMemcpyAsync(q_out, w.tqz, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  hipLaunchKernelGGL(masked_mean_kernel, dim3(B), dim3(D), 0, st, w.th, max_len, lens_run, w.tmean);
-  RC(lin(st, h->t_pr1, w.tmean, D, w.trow, FF, B, ACT_RELU));
-  RC(lin(st, h->t_pr2, w.trow, FF, w.tmean, D, B, ACT_RELU));
-  RC(lin(st, h->t_pz, w.tmean, D, w.pz, D, B));
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(B, 4), dim3(64), 0, st, w.th, max_len, lens_run, w.tmean, tl_free);
+  RC(lin(st, h->t_pr1, w.tmean, D, w.trow, FF, B, ACT_RELU, nullptr, 0, nullptr, 1, 0, 0, 0));      // one row per sequence: row-major throughout
+  RC(lin(st, h->t_pr2, w.trow, FF, w.tmean, D, B, ACT_RELU, nullptr, 0, nullptr, 1, 0, 0, 0));
+  RC(lin(st, h->t_pz, w.tmean, D, w.pz, D, B, ACT_NONE, nullptr, 0, nullptr, 1, 0, 0, 0));
   if (p_out) GLAMR_HIP_CHECK(hipMemcpyAsync(p_out, w.pz, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (mode == GLAMR_VAE_INFER) hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(NZ), 0, st, w.pz, eps, w.z);
-  else if (mode == GLAMR_VAE_TRAIN) hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(NZ), 0, st, w.tqz, eps, w.z);
+  if (mode == GLAMR_VAE_INFER) hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(64), 0, st, w.pz, eps, w.z);
+  else if (mode == GLAMR_VAE_TRAIN) hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(64), 0, st, w.tqz, eps, w.z);
   else hipLaunchKernelGGL(mode_traj_kernel, dim3(B), dim3(NZ), 0, st, w.tqz, w.z);
-  RC(lin(st, h->t_dz, w.z, NZ, w.trow, FF, B));                      // W_z z + b, one row per sequence
+  RC(lin(st, h->t_dz, w.z, NZ, w.trow, FF, B, ACT_NONE, nullptr, 0, nullptr, 1, 0, 0, 0));      // W_z z + b, one row per sequence
   RC(lin(st, h->t_dctx, w.th, D, w.tg, FF, MT, ACT_RELU, nullptr, 0, w.trow, max_len, FF));
   RC(lin(st, h->t_d2, w.tg, FF, w.tq, D, MT, ACT_RELU));
-  RC(lin(st, h->t_dfc, w.tq, D, w.traw, 64, MT));
+  RC(lin(st, h->t_dfc, w.tq, D, w.traw, 64, MT, ACT_NONE, nullptr, 0, nullptr, 1, 0, -1, 0));
   if (out_orig) hipLaunchKernelGGL(rows_out_kernel, dim3(MT), dim3(64), 0, st, w.traw, 64, MT, 11, out_orig);
   hipLaunchKernelGGL(traj_to_global2_kernel, dim3(B), dim3(256), 0, st, w.traw, 64, max_len, lens_run, init, ldinit, 1, out_local, out_trans, out_orient,
                      out_orient_q, w.tscr);
@@ -1004,15 +1033,15 @@ namespace {
 int enqueue_infer(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, int n_win, int n_win_max, bool do_infill, bool do_traj, const float* body_pose,
                   const float* visible, const float* motion_eps, const float* traj_eps, float* out_pose, float* out_local_traj, float* out_trans,
                   float* out_orient) {
-  hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(XLD), 0, st, body_pose, max_len, w.Tpad, w.pose);
+  hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(64), 0, st, body_pose, max_len, w.Tpad, w.pose);
   // ---- motion infiller: autoregressive windows [30 i, 30 i + 50) ------------------------------------------------------------
   for (int i = 0; do_infill && i < n_win; ++i) {
     const int s = i * CUR;
-    hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(XLD), 0, st, w.pose, visible, w.lens, w.Tpad, max_len, s, w.x, w.mask);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(64), 0, st, w.pose, visible, w.lens, w.Tpad, max_len, s, w.x, w.mask);
     RC(infiller_window(h, st, w, B, GLAMR_VAE_INFER, motion_eps + (size_t)i * NZ, n_win_max * NZ, nullptr, nullptr));
-    hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(XLD), 0, st, w.y, 128, w.lens, w.Tpad, s, w.pose);
+    hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(64), 0, st, w.y, 128, w.lens, w.Tpad, s, w.pose);
   }
-  if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(XLD), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
+  if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(64), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
   if (!do_traj) return GLAMR_OK;
   // ---- trajectory predictor -----------------------------------------------------------------------------------------------------
   hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + FK_FRAMES - 1) / FK_FRAMES), dim3(256), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
@@ -1037,6 +1066,7 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   GLAMR_REQUIRE(!do_infill || n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   tl_fp32 = h->fp32_only ? 1 : 0;
+  tl_free = (!tl_fp32 && free_allowed() && (size_t)B * WIN >= (size_t)FUSE_MIN_ROWS) ? 1 : 0;
   Ws w = ws_layout(B, max_len, static_cast<char*>(workspace));
   // A caller that is CAPTURING this stream (its whole step as one graph) gets the plain launch sequence recorded into its graph,
   // INCLUDING the upload of the lengths: they are copied to a pinned table the handle owns (alive until glamr_nets_destroy), and the
@@ -1065,7 +1095,7 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   if (!no_graph && !outer_capture) {
     glamr_nets::GraphKey key;
     std::memset(&key, 0, sizeof(key));
-    key.v[0] = B; key.v[1] = max_len; key.v[2] = n_win; key.v[3] = flags; key.v[4] = n_win_max;
+    key.v[0] = B; key.v[1] = max_len; key.v[2] = n_win; key.v[3] = flags | (tl_free << 16); key.v[4] = n_win_max;
     const void* ptrs[9] = {body_pose, visible, motion_eps, traj_eps, out_pose, out_local_traj, out_trans, out_orient, workspace};
     for (int i = 0; i < 9; ++i) key.p[i] = ptrs[i];
     std::lock_guard<std::mutex> lock(h->graph_mu);
@@ -1123,6 +1153,7 @@ extern "C" int glamr_nets_infiller_window(glamr_nets* h, int B, int mode, const 
   GLAMR_REQUIRE(mode == GLAMR_VAE_RECON || io->eps, "sampling (infer / train) needs eps");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   tl_fp32 = h->fp32_only ? 1 : 0;
+  tl_free = 0;
   Ws w = ws_layout(B, WIN, static_cast<char*>(workspace));
   hipLaunchKernelGGL(window_in_kernel, dim3(B, WIN), dim3(XLD), 0, st, io->in_body_pose, io->frame_mask, w.x, w.mask);
   if (mode != GLAMR_VAE_INFER) hipLaunchKernelGGL(window_in_kernel, dim3(B, WIN), dim3(XLD), 0, st, io->body_pose, io->frame_mask, w.gx, (unsigned char*)nullptr);
@@ -1143,6 +1174,7 @@ extern "C" int glamr_nets_traj_clip(glamr_nets* h, int B, int T, int mode, const
   GLAMR_REQUIRE(io->out_local_traj, "out_local_traj is required");
   hipStream_t st = static_cast<hipStream_t>(stream_);
   tl_fp32 = h->fp32_only ? 1 : 0;
+  tl_free = 0;
   Ws w = ws_layout(B, T, static_cast<char*>(workspace));
   std::vector<int> run(B, T), valid(B, T);
   if (io->valid_len > 0 && io->valid_len < T) std::fill(valid.begin(), valid.end(), io->valid_len);      // zero-padded chunk (get_seg_data)
@@ -1151,7 +1183,7 @@ extern "C" int glamr_nets_traj_clip(glamr_nets* h, int B, int T, int mode, const
   if (io->in_joint_pos) {
     hipLaunchKernelGGL(joints_in_kernel, dim3(B, T), dim3(XLD), 0, st, io->in_joint_pos, T, w.lens2, w.tx);
   } else {
-    hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(XLD), 0, st, io->in_body_pose, T, w.Tpad, w.pose);
+    hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(64), 0, st, io->in_body_pose, T, w.Tpad, w.pose);
     hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (T + FK_FRAMES - 1) / FK_FRAMES), dim3(256), 0, st, w.pose, w.Tpad, T, w.lens2, h->rest_joints, h->parents, w.tx);
   }
   const float* init = nullptr;
@@ -1219,17 +1251,18 @@ extern "C" int glamr_nets_infill_taped(glamr_nets* h, int B, int max_len, const 
   GLAMR_REQUIRE(n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   tl_fp32 = h->fp32_only ? 1 : 0;
+  tl_free = 0;
   Tape t = tape_layout(B, max_len, static_cast<char*>(tape_));
   GLAMR_HIP_CHECK(hipMemcpyAsync(t.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(pose_in_kernel, dim3(B, t.Tpad), dim3(XLD), 0, st, body_pose, max_len, t.Tpad, t.pose);
+  hipLaunchKernelGGL(pose_in_kernel, dim3(B, t.Tpad), dim3(64), 0, st, body_pose, max_len, t.Tpad, t.pose);
   for (int i = 0; i < n_win; ++i) {
     WinTape& w = t.win[i];
     const int s = i * CUR;
-    hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(XLD), 0, st, t.pose, visible, t.lens, t.Tpad, max_len, s, w.x, w.mask);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(64), 0, st, t.pose, visible, t.lens, t.Tpad, max_len, s, w.x, w.mask);
     RC(taped_window(h, st, w, B, motion_eps + (size_t)i * NZ, n_win_max * NZ));
-    hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(XLD), 0, st, w.y, 128, t.lens, t.Tpad, s, t.pose);
+    hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(64), 0, st, w.y, 128, t.lens, t.Tpad, s, t.pose);
   }
-  hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(XLD), 0, st, t.pose, max_len, t.Tpad, t.lens, out_pose);
+  hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(64), 0, st, t.pose, max_len, t.Tpad, t.lens, out_pose);
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }
@@ -1243,6 +1276,7 @@ extern "C" int glamr_nets_infill_backward(glamr_nets* h, int B, int max_len, con
   GLAMR_REQUIRE(n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   tl_fp32 = h->fp32_only ? 1 : 0;
+  tl_free = 0;
   Tape t = tape_layout(B, max_len, static_cast<char*>(tape_));
   GLAMR_HIP_CHECK(hipMemsetAsync(t.pose + t.values, 0, t.values * sizeof(float), st));            // every gradient starts at zero
   GLAMR_HIP_CHECK(hipMemsetAsync(g_motion_eps, 0, (size_t)B * n_win_max * NZ * sizeof(float), st));

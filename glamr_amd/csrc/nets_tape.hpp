@@ -256,16 +256,16 @@ int taped_window(glamr_nets* h, hipStream_t st, WinTape& w, int B, const float* 
   RC(lin(st, h->prior_kv, ctx, D, w.p_ctxkv, 2 * D, M));
   launch_attention(dim3(B, 8), dim3(64), 0, st, h->prior_q, D, w.p_ctxkv, w.p_ctxkv + D, 2 * D, w.mask, w.p_att, D, 2, WIN, 1);
   RC(lin(st, h->prior_o, w.p_att, D, w.p_tmp1, D, B * 2));
-  hipLaunchKernelGGL(tile_rows_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, st, w.p_x1, h->prior_x1, 2, B * 2 * D);
+  hipLaunchKernelGGL(tile_rows_kernel, dim3((B * 2 * D + 255) / 256), dim3(64), 0, st, w.p_x1, h->prior_x1, 2, B * 2 * D);
   RC(ln(st, w.p_tmp1, w.p_x1, h->prior_n2, w.p_a, B * 2));
   RC(lin(st, h->prior_f1, w.p_a, D, w.p_ff, FF, B * 2, ACT_RELU));
   RC(lin(st, h->prior_f2, w.p_ff, FF, w.p_tmp2, D, B * 2));
   RC(ln(st, w.p_tmp2, w.p_a, h->prior_n3, w.p_b, B * 2));
   RC(lin(st, h->prior_pz, w.p_b, D, w.pz, D, B * 2));
-  hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(NZ), 0, st, w.pz, eps, eps_stride, w.z, B);
+  hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(64), 0, st, w.pz, eps, eps_stride, w.z, B);
   // decoder
   RC(lin(st, h->dec_z, w.z, NZ, w.zproj, D, B));
-  hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(D), 0, st, w.zproj, h->dec_pe, w.q0);
+  hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(64), 0, st, w.zproj, h->dec_pe, w.q0);
   const float* xin = w.q0;
   for (int l = 0; l < 2; ++l) {
     const DecLayer& Dl = h->dec[l];

@@ -28,6 +28,7 @@ struct GemmArgs {
   int M, N, K, ldx, ldy, ldr, rows_per_group, ldrb, act;
   const unsigned short* Ws = nullptr;     // the weights split into two fp16 planes in MFMA fragment order (see gemm_split_kernel)
   size_t ws_plane = 0;                    // elements per plane
+  int x_frag = 0, y_frag = 0;             // gemm_free_kernel only (nn_free.hpp): X, resp. Y and R, in fragment-major order
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {

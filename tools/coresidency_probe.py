@@ -79,8 +79,8 @@ def main():
     torch.cuda.synchronize()
     t_stage = min(timed((stage, s1), (None, s2))[0] for _ in range(2))
     print('stage alone (%d scenes, 500 iterations): %.2f ms' % (S, t_stage), flush=True)
-    names = {0: 'MPL8', 1: 'MPL8+split', 2: 'MPL16+split(spills)', 3: 'MPL8+split, 4-wave WG', 4: 'MPL2+split'}
-    mfma = {0: 8, 1: 10, 2: 21, 3: 10, 4: 2}
+    names = {0: 'MPL8', 1: 'MPL8+split', 2: 'MPL16+split(spills)', 3: 'MPL8+split, 4-wave WG', 4: 'MPL2+split', 5: 'MPL8+split, 2-wave WG', 6: 'MPL8+split, 3-wave WG'}
+    mfma = {0: 8, 1: 10, 2: 21, 3: 10, 4: 2, 5: 10, 6: 10}
     # (variant, grid in waves, iterations per launch, launches, LDS bytes)
     cases = [(1, 6144, 20000, 1, 0), (1, 6144, 150, 130, 0), (0, 6144, 20000, 1, 0), (3, 6144, 20000, 1, 0), (3, 6144, 20000, 1, 4096),
              (4, 6144, 40000, 1, 0), (1, 1536, 80000, 1, 0), (1, 24576, 5000, 1, 0), (1, 6144, 20000, 1, 1024)]

@@ -64,6 +64,8 @@ extern "C" int filler_launch(int variant, int grid, const float* W, float* out, 
     case 2: hipLaunchKernelGGL((filler<16, true, 1>), dim3(grid), dim3(64), lds_bytes, st, W, out, iters, nfrag, lds_bytes); break;
     case 3: hipLaunchKernelGGL((filler<8, true, 4>), dim3(grid / 4), dim3(256), lds_bytes, st, W, out, iters, nfrag, lds_bytes); break;
     case 4: hipLaunchKernelGGL((filler<2, true, 1>), dim3(grid), dim3(64), lds_bytes, st, W, out, iters, nfrag, lds_bytes); break;
+    case 5: hipLaunchKernelGGL((filler<8, true, 2>), dim3(grid / 2), dim3(128), lds_bytes, st, W, out, iters, nfrag, lds_bytes); break;
+    case 6: hipLaunchKernelGGL((filler<8, true, 3>), dim3(grid / 3), dim3(192), lds_bytes, st, W, out, iters, nfrag, lds_bytes); break;
     default: return -1;
   }
   return (int)hipGetLastError();
