@@ -355,6 +355,7 @@ def run(argv=None):
     ap.add_argument('--mode', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--total', type=int, default=64, help='--mode strong: sequences in the whole job (BASELINE configs[2]: 64)')
     ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over')
+    ap.add_argument('--no-coschedule', action='store_true', help='two streams left to themselves and the LDS kernels for the priors (the round-2 / early round-3 pipeline)')
     ap.add_argument('--no-graph-step', action='store_true', help='do NOT capture a whole step per stream as one HIP graph after the warm-up (default: capture, check the replay '
                     'against a plain step bit for bit, replay it in the timed region -- a host whose driver calls are slow then no longer paces the ~25 launches of '
                     'a step; any failure of capture or check falls back to plain launches)')
@@ -414,6 +415,14 @@ def run(argv=None):
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))] if on_gpu else [None]
     sync()                                                         # the upload ran on the default stream; the side streams do not wait for it
     keep = []
+    # two streams: batches are STAGGERED (a batch starts when the previous one's priors have finished) and the infiller runs on the kernels
+    # that fit beside a resident stage workgroup -- product code: GlobalReconOptimizer.pipeline_gate, also what optimize_stream() does
+    coschedule = on_gpu and len(streams) >= 2 and not args.no_coschedule and not args.stub_model
+    if coschedule:
+        from glamr_amd.global_recon.models.global_recon_model import PipelineGate, coschedule_enabled
+        coschedule = coschedule_enabled()
+        if coschedule:
+            model.pipeline_gate = PipelineGate()
 
     def step(i=0):
         if on_gpu:
@@ -462,6 +471,8 @@ def run(argv=None):
     if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
+    if coschedule:
+        model.pipeline_gate = None                                   # the single-stream measurements below run the plain step
     elapsed = parallel.max_over_ranks(elapsed, dev)
     n_total = parallel.sum_over_ranks(B, dev)                      # units all ranks processed per step
     if args.stub_model:
@@ -567,7 +578,7 @@ def run(argv=None):
                                    ('BASELINE configs[2]: %d independent %d-frame 1-person sequences (cfg %s, %d iterations) split over %d GPU(s): %d per GPU '
                                     '= %d of %d CUs busy in the optimiser stage' % (args.total, NUM_FRAMES, CFG_ID, iters, world, B, min(B, n_cus), n_cus)),
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
-                       'streams_per_gpu': len(streams), 'step_graph': bool(step_graphs)},
+                       'streams_per_gpu': len(streams), 'step_graph': bool(step_graphs), 'coscheduled_streams': bool(coschedule)},
             'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'latency/issue',
                          'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration: neither HBM nor the matrix pipes limit it; the '
                                        "contract's hbm line (achieved / peak / frac) is kept below and is NOTIONAL",

@@ -359,9 +359,9 @@ thread_local int tl_fp32 = 0;
 // GLAMR_NETS_FREE=0 keeps the fused LDS kernels (A/B runs)
 thread_local int tl_free = 0;
 inline size_t cp(int col) { return tl_free ? (size_t)col * 32 : (size_t)col; }      // pointer offset of column `col` (a multiple of 16) in either layout
-inline bool free_allowed() {
+inline bool free_wanted(int flags) {
   const char* e = std::getenv("GLAMR_NETS_FREE");      // read per call: A/B runs switch it inside one process
-  return !(e && std::atoi(e) == 0);
+  return e ? std::atoi(e) != 0 : (flags & GLAMR_NETS_COSCHEDULE) != 0;
 }
 
 // attention in plain fp32 (fp32_only handles): 8 heads x 32 dims, Lq, Lk <= 64, one workgroup per (sequence, head), lane = query row;
@@ -1044,6 +1044,12 @@ int enqueue_infer(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, int 
   if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(64), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
   if (!do_traj) return GLAMR_OK;
   // ---- trajectory predictor -----------------------------------------------------------------------------------------------------
+  // always on the LDS kernels: its recurrence cannot do without LDS (W_hh does not fit a wave's registers and an L2 round trip per k step
+  // is 30 x the matrix time), so the chain stops at the first LSTM launch until the other stream's stage has retired anyway -- and on an
+  // empty GPU the fused kernels are the faster ones
+  const int free_before = tl_free;
+  tl_free = 0;
+  struct Restore { int v; ~Restore() { tl_free = v; } } restore{free_before};
   hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + FK_FRAMES - 1) / FK_FRAMES), dim3(256), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
   return traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr);
 }
@@ -1066,7 +1072,7 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   GLAMR_REQUIRE(!do_infill || n_win <= n_win_max, "motion_eps holds %d windows per sequence, %d needed", n_win_max, n_win);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   tl_fp32 = h->fp32_only ? 1 : 0;
-  tl_free = (!tl_fp32 && free_allowed() && (size_t)B * WIN >= (size_t)FUSE_MIN_ROWS) ? 1 : 0;
+  tl_free = (!tl_fp32 && free_wanted(flags) && (size_t)B * WIN >= (size_t)FUSE_MIN_ROWS) ? 1 : 0;
   Ws w = ws_layout(B, max_len, static_cast<char*>(workspace));
   // A caller that is CAPTURING this stream (its whole step as one graph) gets the plain launch sequence recorded into its graph,
   // INCLUDING the upload of the lengths: they are copied to a pinned table the handle owns (alive until glamr_nets_destroy), and the

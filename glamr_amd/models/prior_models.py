@@ -511,9 +511,9 @@ class MotionTrajJointModel:
     def get_traj_latent(self, seq_len):
         return self.traj_predictor.get_latent(seq_len)
 
-    def infer_padded(self, body_pose, visible, lens, motion_eps, traj_eps, buffers=None):
+    def infer_padded(self, body_pose, visible, lens, motion_eps, traj_eps, buffers=None, coschedule=False):
         """Batched entry used by GlobalReconOptimizer: ragged sequences padded to a common length."""
-        return self.handle.infer(body_pose, visible, lens, motion_eps=motion_eps, traj_eps=traj_eps, buffers=buffers)
+        return self.handle.infer(body_pose, visible, lens, motion_eps=motion_eps, traj_eps=traj_eps, buffers=buffers, coschedule=coschedule)
 
     def pred_trajectory(self, data, sample_num, recon=False, multi_step=False):
         """motion_traj_joint_model.py:73-133 (in_joint_pos_only False, model_type 'angle'): the infiller's motion through the trajectory

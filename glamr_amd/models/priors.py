@@ -8,7 +8,7 @@ import torch
 from .. import _lib
 from .layouts import INFILLER_LAYOUT, TRAJPRED_LAYOUT
 
-NETS_INFILL, NETS_TRAJ, NETS_PERSISTENT = 1, 2, 4
+NETS_INFILL, NETS_TRAJ, NETS_PERSISTENT, NETS_COSCHEDULE = 1, 2, 4, 8
 VAE_INFER, VAE_TRAIN, VAE_RECON = 0, 1, 2
 PAST, CUR, NZ = 10, 30, 128
 
@@ -87,16 +87,18 @@ class MotionPriorsHandle:
         per_stream[key] = cur
         return cur
 
-    def infer(self, body_pose, visible, lens, motion_eps=None, traj_eps=None, infill=True, traj=True, buffers=None):
+    def infer(self, body_pose, visible, lens, motion_eps=None, traj_eps=None, infill=True, traj=True, buffers=None, coschedule=False):
         """body_pose (B,T,69) fp32 device, visible (B,T) 1/0, lens list[int].  Returns dict of device tensors.  `buffers`: a
-        resident_set() whose output / workspace tensors are used instead of fresh allocations."""
+        resident_set() whose output / workspace tensors are used instead of fresh allocations.  `coschedule`: the caller pipelines batches over
+        two streams (GLAMR_NETS_COSCHEDULE, include/glamr_hip.h): the infiller runs on the kernels that fit beside a resident optimiser stage."""
         L = _lib.lib()
         B, T = body_pose.shape[:2]
         dev = body_pose.device
         body_pose = body_pose.float().contiguous()
         lens_np = np.ascontiguousarray(lens, dtype=np.int32)
         out = {}
-        flags = (NETS_INFILL if infill else 0) | (NETS_TRAJ if traj else 0) | (NETS_PERSISTENT if buffers is not None and buffers.get('persistent', True) else 0)
+        flags = (NETS_INFILL if infill else 0) | (NETS_TRAJ if traj else 0) | (NETS_PERSISTENT if buffers is not None and buffers.get('persistent', True) else 0) \
+            | (NETS_COSCHEDULE if coschedule else 0)
         n_win_max = 0
         new = (lambda name, *shape: buffers[name]) if buffers is not None else (lambda name, *shape: torch.empty(shape, device=dev))
         if infill:

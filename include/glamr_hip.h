@@ -123,6 +123,12 @@ int glamr_nets_precision(const glamr_nets* h, double* worst_case);
                                      only reused on this stream: the ~450 launches are captured as a HIP graph at the first call and replayed
                                      afterwards (without the flag: captured when the identical call is seen a second time).  The handle
                                      keeps at most 24 such graphs; the least recently used one is destroyed when a 25th geometry arrives */
+#define GLAMR_NETS_COSCHEDULE 8   /* the caller pipelines batches over TWO streams, so that this call runs while an optimiser stage
+                                     (glamr_grecon_run_stage) of the other stream is resident: the infiller then runs on kernels that fit BESIDE a
+                                     stage workgroup (no LDS, one wave per workgroup, <= 128 registers, fragment-major activations:
+                                     csrc/nn_free.hpp) -- slower on an empty GPU (26 against 20 ms per 1024 x 300 frames), faster in
+                                     the pipeline.  Same results to ~1e-7 (different summation order in LayerNorm).  Ignored for batches below
+                                     2048 window rows and for fp32-only handles.  GLAMR_NETS_FREE=0 / 1 (environment) overrides the flag */
 /* Under a CALLER's stream capture (the whole step as one graph) the call records its plain launch sequence into that graph, the upload of
  * `lens` included: the lengths are copied into a pinned table owned by the handle (alive until glamr_nets_destroy; room for 262 144
  * lengths over the handle's lifetime, GLAMR_E_INVALID beyond), so the caller's graph carries its own lengths whatever workspace it uses. */

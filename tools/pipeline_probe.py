@@ -55,6 +55,22 @@ def priors(st):
     return h.infer(b['nets_pose'], b['nets_vis'], [T] * B, motion_eps=b['meps'], traj_eps=b['teps'], buffers=b)
 
 
+def priors_split(st, part):
+    """part 0: the infiller only; part 1: the trajectory predictor on the infilled motion"""
+    h = m.mt_model.handle
+    key = (st.cuda_stream, os.environ.get('GLAMR_NETS_FREE'), 'split')
+    if key not in BUF:
+        b = h.resident_set(B, T, num_windows(T))
+        b['nets_pose'].copy_(pose); b['nets_vis'].copy_(vis); b['meps'].copy_(meps); b['teps'].copy_(teps)
+        BUF[key] = dict(b)
+        BUF[key]['ws'] = torch.empty_like(b['ws'])
+    b = BUF[key]
+    b['persistent'] = True
+    if part == 0:
+        return h.infer(b['nets_pose'], b['nets_vis'], [T] * B, motion_eps=b['meps'], traj_eps=None, infill=True, traj=False, buffers=b)
+    return h.infer(b['pose'], None, [T] * B, motion_eps=None, traj_eps=b['teps'], infill=False, traj=True, buffers=b)
+
+
 def run(n, stagger):
     ev_prev = None
     torch.cuda.synchronize()
@@ -64,22 +80,33 @@ def run(n, stagger):
         with torch.cuda.stream(st):
             if stagger and ev_prev is not None:
                 st.wait_event(ev_prev)
-            priors(st)
-            ev_prev = torch.cuda.Event()
-            ev_prev.record(st)
+            if stagger == 2:
+                priors_split(st, 0)
+                ev_prev = torch.cuda.Event()
+                ev_prev.record(st)
+                priors_split(st, 1)
+            else:
+                priors(st)
+                ev_prev = torch.cuda.Event()
+                ev_prev.record(st)
             _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), None, _lib.ptr(wss[i % 2]), ctypes.c_void_p(st.cuda_stream)))
     torch.cuda.synchronize()
     return (time.time() - t0) / n * 1e3
 
 
-for free in ('0', '1'):
+for free in os.environ.get('GLAMR_PP_FREE', '0,1').split(','):
     os.environ['GLAMR_NETS_FREE'] = free
     for st in streams:
         with torch.cuda.stream(st):
             for _ in range(3):
                 priors(st)
     torch.cuda.synchronize()
-    for stagger in (False, True):
+    for st in streams:
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                priors_split(st, 0); priors_split(st, 1)
+    torch.cuda.synchronize()
+    for stagger in [int(v) for v in os.environ.get('GLAMR_PP_STAGGER', '0,1,2').split(',')]:
         run(4, stagger)
         print('GLAMR_NETS_FREE=%s %s: %.2f ms per batch (12 batches)  %.2f (second run)' % (
-            free, 'staggered   ' if stagger else 'free-running', run(12, stagger), run(12, stagger)), flush=True)
+            free, ('free-running', 'staggered   ', 'staggered on the infiller'    )[stagger], run(12, stagger), run(12, stagger)), flush=True)
