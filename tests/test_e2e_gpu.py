@@ -542,3 +542,49 @@ def test_captured_resident_step_follows_new_inputs(make_model):
     want = model.optimize_resident(rin_b, max_iters=6)[1].t['kp_2d_pred']
     torch.cuda.synchronize()
     assert torch.equal(got, want) and bool(torch.isfinite(got).all())
+
+
+@pytest.mark.gpu
+def test_gated_two_stream_step_graphs_use_the_coschedulable_kernels(make_model, monkeypatch):
+    """The staggered two-stream pipeline (PipelineGate): every batch starts when the previous batch's priors are done, its infiller runs on the
+    kernels that fit beside the other stream's optimiser stage (GLAMR_NETS_COSCHEDULE: 48 sequences x 2 windows = 4800 window rows, above the
+    2048-row threshold), and capture_resident cuts the step into two graphs around the gate's event.  With the LDS kernels forced
+    (GLAMR_NETS_FREE=0) the gated, split, replayed step is the ungated plain step BIT FOR BIT: gate and split change nothing but the order
+    of launches across streams.  With the co-schedulable kernels the replays reproduce the plain gated step bit for bit (capture_resident's
+    own check); against the LDS kernels the priors differ by ~1e-7 (tests/test_nets_gpu.py), which six sign-driven Adam steps turn into
+    a few hundredths of a pixel."""
+    from glamr_amd.global_recon.models.global_recon_model import PipelineGate
+    md = synth.make_smpl_model()
+    model = make_model('glamr_dynamic')
+    batch = [synth.make_in_dict(seed=300 + i, num_frames=96, num_persons=1, smpl_model=md) for i in range(48)]
+    lats = [mg.latents_for(d, 300 + i) for i, d in enumerate(batch)]
+    rin = model.stage_inputs(batch, lats)
+    torch.cuda.synchronize()
+    plain = model.optimize_resident(rin, max_iters=6)[1].t['kp_2d_pred'].clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for forced_lds in (True, False):
+        if forced_lds:
+            monkeypatch.setenv('GLAMR_NETS_FREE', '0')
+        else:
+            monkeypatch.delenv('GLAMR_NETS_FREE')
+        model.pipeline_gate = PipelineGate()
+        try:
+            for st in streams:
+                with torch.cuda.stream(st):
+                    model.optimize_resident(rin, max_iters=6)
+            torch.cuda.synchronize()
+            graphs = [model.capture_resident(rin, max_iters=6, stream=st, check=True) for st in streams]
+            assert all(g.tail is not None and g.gate is model.pipeline_gate for g in graphs)
+            for i in range(4):
+                graphs[i % 2].replay()
+            torch.cuda.synchronize()
+            for g in graphs:
+                got = g.packed.t['kp_2d_pred']
+                assert bool(torch.isfinite(got).all())
+                d = float((got - plain).abs().max())
+                print('gated step graph (%s) vs the ungated plain step: %.2e px' % ('LDS kernels' if forced_lds else 'co-schedulable kernels', d))
+                assert d == 0.0 if forced_lds else 0.0 < d < 0.3
+            assert torch.equal(graphs[0].packed.t['kp_2d_pred'], graphs[1].packed.t['kp_2d_pred'])
+        finally:
+            model.pipeline_gate = None

@@ -222,6 +222,44 @@ def test_split_gemm_path_matches_reference_at_batch_size(priors, golden):
     assert torch.equal(out['pose'][0], out['pose'][B - 1])          # and every copy of the sequence gets the same bits
 
 
+def test_coschedulable_kernels_match_reference_at_batch_size(priors, golden):
+    """GLAMR_NETS_COSCHEDULE (infer(..., coschedule=True)): the infiller on the kernels that fit beside a resident optimiser-stage workgroup --
+    no LDS, one wave per workgroup, fragment-major activations (csrc/nn_free.hpp: gemm_free_kernel, ln_free_kernel, attention_free_kernel).
+    64 copies of the reference sequence (a ragged tail included: 64 x 50 and 64 x 30 window rows, 3200 = 100 whole 32-row blocks, so a second
+    batch of 41 sequences covers the partial last block) must match the unmodified reference to 1e-4 and the LDS kernels to a few 1e-6."""
+    g = golden('nets')
+    dev = torch.device('cuda:0')
+    T = 300
+    b = {k: torch.tensor(v, device=dev) for k, v in mg.net_inputs(T).items()}
+    rep = lambda t, B: t.expand(B, *t.shape[1:]).contiguous()
+    for B in (64, 41):
+        args = (rep(b['in_body_pose'], B), rep(b['frame_mask'], B), [T] * B)
+        kw = dict(motion_eps=rep(b['in_motion_latent'][None], B), traj_eps=rep(b['in_traj_latent'], B))
+        lds = priors.infer(*args, **kw)
+        out = priors.infer(*args, coschedule=True, **kw)
+        e = (_err(out['pose'][B - 1].cpu(), g['T300_body_pose'][0, 0]), _err(out['local_traj'][B - 1].cpu(), g['T300_local_traj'][:, 0, 0]),
+             _err(out['trans'][B - 1].cpu(), g['T300_trans'][0, 0]), _err(out['orient'][B - 1].cpu(), g['T300_orient'][0, 0]))
+        d = max(_err(out[k].cpu(), lds[k].cpu()) for k in ('pose', 'local_traj', 'trans', 'orient'))
+        print('co-schedulable kernels (batch %d) vs reference: body pose %.2e, local trajectory %.2e, translation %.2e, orientation %.2e; vs the LDS kernels %.2e' % ((B,) + e + (d,)))
+        assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 2e-4 and e[3] < 2e-4 and d < 2e-5
+        assert d > 0.0                                               # (the other kernels did run: LayerNorm sums in a different order)
+        assert torch.equal(out['pose'][0], out['pose'][B - 1])
+    # ragged lengths: every sequence as if alone
+    lens = [300, 251, 40, 133] * 12
+    Bn = len(lens)
+    pose = rep(b['in_body_pose'], Bn).clone()
+    vis = rep(b['frame_mask'], Bn).clone()
+    for i, n in enumerate(lens):
+        pose[i, n:] = 0
+        vis[i, n:] = 0
+    kw = dict(motion_eps=rep(b['in_motion_latent'][None], Bn), traj_eps=rep(b['in_traj_latent'], Bn))
+    lds = priors.infer(pose, vis, lens, **kw)
+    out = priors.infer(pose, vis, lens, coschedule=True, **kw)
+    d = max(_err(out[k].cpu(), lds[k].cpu()) for k in ('pose', 'local_traj', 'trans', 'orient'))
+    print('co-schedulable kernels, ragged batch of %d: vs the LDS kernels %.2e' % (Bn, d))
+    assert d < 2e-5
+
+
 def test_fused_layer_kernels_match_reference_at_batch_size(joint_model, golden):
     """At M >= 2048 rows the transformer blocks run as fused kernels (qkv_attention_kernel: projections + attention with Q / K / V in
     registers; rows_fused_kernel: out-projection + residual + LayerNorm, feed-forward with the hidden rows on chip).  The training-mode pass
