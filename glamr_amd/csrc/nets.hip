@@ -267,6 +267,47 @@ __global__ __launch_bounds__(256) void fk_joints_kernel(const float* pose, int T
   if (j > 0) for (int c = 0; c < 3; ++c) xo[(j - 1) * 3 + c] = sP[fl][j][c] - sP[fl][0][c];
   else for (int c = 69; c < XLD; ++c) xo[c] = 0.0f;
 }
+// The same chain without LDS (co-schedulable, see nn_free.hpp): two frames per wave, lane = (frame, joint); a joint fetches its parent's
+// transform with twelve lane exchanges per tree level instead of reading it from LDS.  Same arithmetic in the same order.
+__global__ __launch_bounds__(64) void fk_joints_free_kernel(const float* pose, int Tpad, int max_len, const int* lens, const float* rest, const int32_t* parents, float* x) {
+  const int b = blockIdx.x, lane = threadIdx.x, fl = lane >> 5, j = lane & 31;
+  const int t = blockIdx.y * 2 + fl;
+  const bool joint = j < 24;
+  const bool active = joint && t < max_len && t < lens[b];
+  const int pa = joint ? parents[j] : -1;
+  int lev = 0;
+  if (joint) for (int a = pa; a >= 0; a = parents[a]) ++lev;
+  int nlev = lev;
+  for (int off = 32; off > 0; off >>= 1) nlev = max(nlev, __shfl_xor(nlev, off));
+  float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, G[9], P[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+  if (active) {
+    if (j == 0) { const float z[3] = {0.f, 0.f, 0.f}; rm::aa_to_rotmat_s(z, R); }
+    else rm::aa_to_rotmat_s(pose + ((size_t)b * Tpad + t) * XLD + (j - 1) * 3, R);
+    if (j == 0) for (int c = 0; c < 3; ++c) P[c] = rest[c];
+    else for (int c = 0; c < 3; ++c) d[c] = rest[j * 3 + c] - rest[pa * 3 + c];
+  }
+  for (int e = 0; e < 9; ++e) G[e] = R[e];
+  const int src = (lane & 32) + max(pa, 0);
+  for (int L = 1; L <= nlev; ++L) {
+    float pg[9], pp[3];
+    for (int e = 0; e < 9; ++e) pg[e] = __shfl(G[e], src);
+    for (int c = 0; c < 3; ++c) pp[c] = __shfl(P[c], src);
+    if (active && lev == L) {
+      float o[3];
+      rm::mat3_mul(pg, R, G);
+      rm::mat3_vec(pg, d, o);
+      for (int c = 0; c < 3; ++c) P[c] = pp[c] + o[c];
+    }
+  }
+  const int root = lane & 32;
+  float p0[3];
+  for (int c = 0; c < 3; ++c) p0[c] = __shfl(P[c], root);
+  if (!joint || t >= max_len) return;
+  float* xo = x + ((size_t)b * max_len + t) * XLD;
+  if (!active) { for (int c = j * 4; c < j * 4 + 4; ++c) xo[c] = 0.0f; return; }
+  if (j > 0) for (int c = 0; c < 3; ++c) xo[(j - 1) * 3 + c] = P[c] - p0[c];
+  else for (int c = 69; c < XLD; ++c) xo[c] = 0.0f;
+}
 __global__ void masked_mean_kernel(const float* ctx, int max_len, const int* lens, float* mean, int frag = 0) {   // [B][max_len][256] -> [B][256]
   const int b = blockIdx.x, n = lens[b];
   for (int k = blockIdx.y * blockDim.x + threadIdx.x; k < D; k += blockDim.x * gridDim.y) {
@@ -988,6 +1029,7 @@ int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const in
   RC(mlp2(st, h->t_in1, h->t_in2, nullptr, w.tx, XLD, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU, 0));      // (joint rows: row-major)
   for (int l = 0; l < 2; ++l) {
     RC(lin(st, h->t_ih[l], w.th, D, w.tg, 1024, MT, ACT_NONE, nullptr, 0, nullptr, 1, 0, l == 0 ? -1 : 0, 0));      // the recurrence reads and writes row-major rows
+    tl_free = 0;                                                   // from the first recurrence on: the LDS kernels (see enqueue_infer; restored by the caller)
     bilstm(h, st, w.tg, h->t_hh[l], lens_run, w.th, max_len, B);
   }
   RC(mlp2(st, h->t_out1, h->t_out2, nullptr, w.th, D, nullptr, w.th, w.tg, w.tq, MT, ACT_RELU, 0));       // context [B][max_len][256]
@@ -1044,12 +1086,14 @@ int enqueue_infer(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, int 
   if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(64), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
   if (!do_traj) return GLAMR_OK;
   // ---- trajectory predictor -----------------------------------------------------------------------------------------------------
-  // always on the LDS kernels: its recurrence cannot do without LDS (W_hh does not fit a wave's registers and an L2 round trip per k step
-  // is 30 x the matrix time), so the chain stops at the first LSTM launch until the other stream's stage has retired anyway -- and on an
-  // empty GPU the fused kernels are the faster ones
-  const int free_before = tl_free;
-  tl_free = 0;
-  struct Restore { int v; ~Restore() { tl_free = v; } } restore{free_before};
+  // The recurrence cannot do without LDS (W_hh does not fit a wave's registers and an L2 round trip per k step is 30 x the matrix time), so the
+  // chain stops at the first LSTM launch until the other stream's stage has retired: everything BEFORE it stays co-schedulable (it runs in
+  // the slack the infiller leaves beside the stage), everything from it on takes the LDS kernels, the faster ones on an empty GPU (traj_pass).
+  struct Restore { int v; ~Restore() { tl_free = v; } } restore{tl_free};
+  if (tl_free) {
+    hipLaunchKernelGGL(fk_joints_free_kernel, dim3(B, (max_len + 1) / 2), dim3(64), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
+    return traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr);
+  }
   hipLaunchKernelGGL(fk_joints_kernel, dim3(B, (max_len + FK_FRAMES - 1) / FK_FRAMES), dim3(256), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
   return traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr);
 }
