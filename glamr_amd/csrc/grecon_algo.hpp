@@ -983,6 +983,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       rt.sync();
     }
     GLAMR_MARK(rt, 3);
+    // a forward pass that is only there for the world poses (init_data's pass before init_cam_pose(all_frames) :243-246): done
+    if (last && niters == 0 && (st.flags & GLAMR_FLAG_POSES_ONLY)) return;
     // ---- E: residuals and per-frame gradients -----------------------------------------------------------------------------
     const float w_kp = active(GLAMR_LOSS_KP_2D) ? st.loss_weight[GLAMR_LOSS_KP_2D] / n_vis_total : 0.f;
     const float n_ctr = ffo(GLAMR_LOSS_CAM_TRAJ_ROT) ? (float)P : n_vis_total;

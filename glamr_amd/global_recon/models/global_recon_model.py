@@ -146,7 +146,9 @@ class PipelineGate:
     is resident (GlobalReconOptimizer.pipeline_gate).  A stage workgroup leaves three of a CU's four SIMDs half empty and its matrix pipes
     idle, and the infiller's co-schedulable kernels (GLAMR_NETS_COSCHEDULE, csrc/nn_free.hpp) fit into exactly that space -- but two streams
     left to themselves fall into step (both in their priors, then both stages one after the other) and nothing overlaps.  The rule: a batch
-    starts its device work when the PREVIOUS batch's priors have finished, which is when that batch's stage is about to start.  Measured on
+    starts its device work when the PREVIOUS batch's priors have finished, a few milliseconds before that batch's stage starts.  (Measured and
+    dropped: opening the gate only when the stage is launched -- the infiller then loses its head start on an almost empty GPU, does not
+    finish within the stage's 35 ms, and the step goes from 43.4 to 49.0 ms.)  Measured on
     1024 x 300 frames (tools/pipeline_probe.py): 42.6 ms per batch against 47.1 for the LDS kernels free-running."""
 
     def __init__(self):
@@ -644,7 +646,9 @@ class GlobalReconOptimizer:
             jl = self.smpl(global_orient=zeros, body_pose=pa_t['smpl_pose'].view(-1, 69), betas=pa_t['smpl_beta'].view(-1, 10), root_trans=zeros,
                            return_verts=False).joints
         packed.t['j_local'] = jl.view(n_slots, T, 26, 3)
-        self._run(packed, self._forward_only_desc())
+        # with flag_init_cam_all_frames this pass is only there for the world poses the cameras are initialised from; whoever needs the 'init'
+        # outputs gets them from the second pass (init_forward), or from the first stage's last evaluation
+        self._run(packed, self._forward_only_desc(poses_only=self.flag_init_cam_all_frames or not init_forward))
         if self.flag_init_cam_all_frames:
             sb = packed.struct()
             _lib.check(L.glamr_init_cam_all_frames(ctypes.byref(sb), st))
@@ -795,11 +799,13 @@ class GlobalReconOptimizer:
         """True when the configured schedule has at least one stage: its last evaluation rewrites all outputs of the 'init' forward pass."""
         return len(self.opt_stage_specs) > 0
 
-    def _forward_only_desc(self):
+    def _forward_only_desc(self, poses_only=False):
         first = next(iter(self.opt_stage_specs.values()))
         sd = packing.stage_desc(first, self.specs, has_world_dheading=False, niters=0)
         sd.var_mask = 0
         sd.flags &= ~packing.FLAG_CAM_FROM_PERSON           # stage 'init' keeps the initial camera (:473)
+        if poses_only:
+            sd.flags |= packing.FLAG_POSES_ONLY             # only orient_world / trans_world are wanted (the pass before init_cam_pose(all_frames))
         return sd
 
     def _run(self, packed, sd):

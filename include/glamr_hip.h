@@ -226,6 +226,10 @@ int glamr_traj_local_to_global(int n_seq, int T, const float* local_traj, float*
 #define GLAMR_FLAG_NO_CAMERA_TERMS (1u << 4)       /* leave the camera-only residuals (cam_inv_rot_smoothness, cam_origin_smoothness, cam_up_reg,
                                                       cam_inv_trans_residual_reg) out of the gradient: another rank owns them */
 
+#define GLAMR_FLAG_POSES_ONLY (1u << 5)            /* niters == 0 only: stop after orient_world / trans_world (and cam_pose) are written -- no
+                                                      projections, no loss values.  init_data's forward pass before init_cam_pose(all_frames=True)
+                                                      (global_recon_model.py:243-246) is followed by a full one whenever its outputs are used */
+
 /* loss ids (loss_func_dict, loss_func.py:314-340) -- order of glamr_stage_desc.loss_weight[] */
 enum {
   GLAMR_LOSS_KP_2D = 0, GLAMR_LOSS_KP_2D_DIST, GLAMR_LOSS_REL_TRANSFORM, GLAMR_LOSS_CAM_TRAJ_ROT,
