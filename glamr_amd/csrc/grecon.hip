@@ -51,6 +51,11 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
   __shared__ glamr_param_layout s_lay;
   extern __shared__ __attribute__((aligned(16))) float arena[];     // prefix-sum buffers and neighbour-read arrays, when they fit
   const int si = blockIdx.x;
+  // The stage is the pipeline's critical path; the priors' co-schedulable kernels of the other stream (nn_free.hpp) share these SIMDs
+  // and have slack: this kernel's waves win the issue arbitration against them (user priority 0..3, the others stay at 0)
+#ifndef GLAMR_GRECON_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
   if (threadIdx.x == 0) {
     atomicMin(a.stamps, (unsigned long long)wall_clock64());
     s_st = a.st;
