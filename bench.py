@@ -471,7 +471,19 @@ def run(argv=None):
     if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
+    beside = None
     if coschedule:
+        # what a stage launch takes in THIS pipeline (beside the other stream's priors): four more gated steps as plain launches, whose
+        # workspaces carry the kernel's own clock stamps (graph replays share one workspace per graph) -- after the clock has stopped
+        try:
+            del stage_events[:]
+            for i in range(6):
+                (eager_step if step_graphs else step)(i)
+            sync()
+            beside = [round(model.launch_ms(ws), 2) for wss in stage_events[2:5] for ws in wss]      # (the last one has no neighbour)
+        except Exception as e:      # noqa: BLE001
+            sys.stderr.write('bench: co-scheduled stage launches not measured (%s)\n' % e)
+        del stage_events[:]
         model.pipeline_gate = None                                   # the single-stream measurements below run the plain step
     elapsed = parallel.max_over_ranks(elapsed, dev)
     n_total = parallel.sum_over_ranks(B, dev)                      # units all ranks processed per step
@@ -598,6 +610,12 @@ def run(argv=None):
                                       'share the CUs%s' % (len(streams), ' and are graph replays (one workspace per graph: no per-replay stamps)' if step_graphs else '')),
                          'note': 'achieved / frac = %d B per person-iteration (SURVEY.md 8d K5 live state) x %d scenes x %d iterations / launch time: bytes the '
                                  'kernel keeps in LDS and does not move -- notional.  traffic = memory-side bytes (PMC).' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},
+            'pipeline': None if not coschedule else {
+                'coscheduled_streams': True, 'stage_launch_ms_alone': k_avg, 'stage_launch_ms_beside_the_priors': beside,
+                'note': 'two streams, batches staggered by GlobalReconOptimizer.pipeline_gate: a batch starts when the previous one\'s priors are done, so its '
+                        'motion infiller -- LDS-free one-wave kernels on fragment-major activations (csrc/nn_free.hpp) -- runs in the SIMD issue slots and '
+                        'matrix pipes a resident stage workgroup leaves idle.  The stage launch is slower beside them than alone; the step is shorter '
+                        '(--no-coschedule: the LDS kernels, streams left to themselves).  `roofline` describes the stage kernel ALONE'},
             'latency_one_sequence_ms': latency,
             'host_inclusive_sequences_per_sec': host_stream if host_stream is not None else B / host_single,
             'host_inclusive_single_call_sequences_per_sec': B / host_single,
