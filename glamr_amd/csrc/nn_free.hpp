@@ -2,15 +2,18 @@
 //
 // A stage workgroup (grecon.hip) holds 153 of a CU's 160 KB of LDS and five 256-register waves: SIMD 0 is full, SIMDs 1-3 are half
 // empty and issue half of the time, the matrix pipes idle.  Measured with tools/coresidency_probe.py: the hardware places another
-// kernel's workgroup into that space only if it (a) allocates NO LDS at all (1 KB is already refused), (b) is ONE wave, (c) needs <=
-// 128 registers -- and only short launches interleave (a long-running kernel owns the SIMDs before the next stage workgroup arrives).
-// A train of such launches then runs at ~65 % of its stand-alone rate while the stage launch slows by ~9 %, against 0 % overlap for
-// anything with LDS.  The fused row-block / QKV-attention kernels of nn_kernels.hpp are built around 130-140 KB of LDS, so every
-// workgroup of theirs waits for a stage workgroup to retire: priors and stage ADD UP (20 + 29 ms of the 50 ms step).  The kernels here
-// give up on-chip fusion (activations round-trip through L2 / MALL between the GEMMs of a layer) and get the stage's shadow in return.
+// kernel's workgroup into that space only if it (a) allocates NO LDS at all (1 KB is already refused), (b) has at most three waves (a
+// fourth would need SIMD 0), (c) needs <= 128 registers per wave for two waves per free SIMD -- and only short launches interleave (a
+// long-running kernel owns the SIMDs before the next stage workgroup arrives), and only with moderate L2 traffic (the stage re-reads 29 KB
+// per scene-iteration from L2).  A train of such launches then runs at ~65 % of its stand-alone rate while the stage launch slows by
+// ~10-20 %, against 0 % overlap for anything with LDS.  The fused row-block / QKV-attention kernels of nn_kernels.hpp are built around
+// 130-140 KB of LDS, so every workgroup of theirs waits for a stage workgroup to retire: priors and stage ADD UP.  The kernels here give
+// up on-chip fusion (activations round-trip through L2 / MALL between the GEMMs of a layer: alone they are the SLOWER ones) and get the
+// stage's shadow in return.  Callers ask for them per call (GLAMR_NETS_COSCHEDULE); see DESIGN.md section 3 for the measurements.
 //
-// Conventions as in nn_kernels.hpp: fp32 activations, row-major, two fp16 planes per operand, three v_mfma_f32_32x32x16_f16 per k
-// step; weights in the fragment order of glamr_nets_create (`Lin::Ws`).  Every GEMM is computed TRANSPOSED,
+// Conventions as in nn_kernels.hpp -- fp32 values as two fp16 planes, three v_mfma_f32_32x32x16_f16 per k step, weights in the fragment
+// order of glamr_nets_create (`Lin::Ws`) -- except for the memory layout of the activations (fragment-major, below).  Every GEMM is
+// computed TRANSPOSED,
 //   Y^T = W X^T :  A = weight fragment (lane = output column), B = row fragment straight from global memory (lane = row),
 // so that a lane's accumulator registers are 4 CONSECUTIVE output columns of ONE row (16-byte stores, no transposition through LDS).
 #pragma once
