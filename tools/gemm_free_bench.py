@@ -10,24 +10,30 @@ sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np
 import torch
 
-VARIANTS = {1: 'R1 C2 PD1 w4 x1', 2: 'R1 C2 PD1 w4 x2', 3: 'R1 C2 PD1 w4 x3', 4: 'R1 C4 PD1 w2 x3', 5: 'R1 C1 PD2 w4 x3'}
+VARIANTS = {0: '32x64  PD1 w4 (product)', 1: '32x64  PD2 w3', 2: '32x128 PD1 w2', 3: '32x32  PD2 w4'}
 
 
-def lib(so=None):
-    if so:
-        L = ctypes.CDLL(os.path.join(HERE, so))
-        L.gfb_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        return L
+def lib():
     so, src = os.path.join(HERE, '_gemm_free_bench.so'), os.path.join(HERE, 'gemm_free_bench.hip')
     deps = [src, os.path.join(HERE, '..', 'glamr_amd', 'csrc', 'nn_free.hpp'), os.path.join(HERE, '..', 'glamr_amd', 'csrc', 'nn_kernels.hpp')]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
         subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', src,
                                os.path.join(HERE, '..', 'glamr_amd', 'csrc', 'api_common.cpp'), '-o', so])
     L = ctypes.CDLL(so)
-    L.gfb_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+    L.gfb_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     return L
+
+
+def to_frag(X):
+    """row-major [M][ld] (M a multiple of 32, ld of 16) -> fragment-major (csrc/nn_free.hpp x32_off)"""
+    M, ld = X.shape
+    return X.reshape(M // 32, 32, ld // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(M, ld)
+
+
+def from_frag(Y):
+    M, ld = Y.shape
+    return Y.reshape(M // 32, ld // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).contiguous().reshape(M, ld)
 
 
 def planes(W):
@@ -48,8 +54,7 @@ def planes(W):
 
 def main():
     dev = torch.device('cuda:0')
-    abl = os.environ.get('GLAMR_GFB_ABL')            # e.g. "0,1,2,4,8": the ablation builds _gemm_free_bench_abl<N>.so, timing only
-    libs = {('abl%s ' % a): lib('_gemm_free_bench_abl%s.so' % a) for a in abl.split(',')} if abl else {'': lib()}
+    L = lib()
     g = torch.Generator().manual_seed(0)
     shapes = [(51200, 256, 256), (51200, 768, 256), (51200, 256, 512)]
     data = {}
@@ -61,16 +66,13 @@ def main():
         Ws = torch.from_numpy(pl.view(np.int16).copy()).to(dev)
         Y = torch.empty(M, N, device=dev)
         ref = X[:2048].double() @ W.to(dev).double().t() + b[:N].double()
-        data[(M, N, K)] = (X, Ws, plane, b, Y, ref)
+        data[(M, N, K)] = (X, to_frag(X), Ws, plane, b, Y, ref)
     st = torch.cuda.current_stream()
 
-    cur = {'L': next(iter(libs.values()))}
-
-    def launch(v, key, stream=None):
-        L = cur['L']
-        X, Ws, plane, b, Y, _ = data[key]
+    def launch(v, key, frag=1, stream=None):
+        X, Xf, Ws, plane, b, Y, _ = data[key]
         M, N, K = key
-        rc = L.gfb_launch(v, X.data_ptr(), K, Ws.data_ptr(), plane, b.data_ptr(), Y.data_ptr(), N, M, N, K, ctypes.c_void_p((stream or st).cuda_stream))
+        rc = L.gfb_launch(v, frag, (Xf if frag else X).data_ptr(), K, Ws.data_ptr(), plane, b.data_ptr(), Y.data_ptr(), N, M, N, K, ctypes.c_void_p((stream or st).cuda_stream))
         assert rc == 0, rc
 
     def time_of(fn, reps=5):
@@ -86,19 +88,18 @@ def main():
             best = min(best, e0.elapsed_time(e1))
         return best
 
-    for tag, Lx in libs.items():
-      cur['L'] = Lx
-      for v, name in VARIANTS.items():
-        line = '%s%-14s' % (tag, name)
-        for key in shapes:
-            data[key][4].zero_()
-            launch(v, key)
-            torch.cuda.synchronize()
-            err = (data[key][4][:2048].double() - data[key][5]).abs().max().item()
-            ms = time_of(lambda: launch(v, key))
-            line += ' | %s %.3f ms %5.0f TF/s err %.1e' % ('x'.join(map(str, key)), ms, 2.0 * key[0] * key[1] * key[2] / ms / 1e9, err)
-        print(line, flush=True)
-    cur['L'] = next(iter(libs.values()))
+    for frag in (1, 0):
+        for v, name in VARIANTS.items():
+            line = '%-24s %s' % (name, 'fragment-major' if frag else 'row-major     ')
+            for key in shapes:
+                data[key][5].zero_()
+                launch(v, key, frag)
+                torch.cuda.synchronize()
+                Y = from_frag(data[key][5]) if frag else data[key][5]
+                err = (Y[:2048].double() - data[key][6]).abs().max().item()
+                ms = time_of(lambda: launch(v, key, frag))
+                line += ' | %s %.3f ms %5.0f TF/s err %.1e' % ('x'.join(map(str, key)), ms, 2.0 * key[0] * key[1] * key[2] / ms / 1e9, err)
+            print(line, flush=True)
 
     if os.environ.get('GLAMR_GFB_NO_STAGE'):
         return
@@ -149,7 +150,7 @@ def main():
     key = (51200, 768, 256)
     for v, name in VARIANTS.items():
         n = 150
-        fill = lambda: [launch(v, key, s2) for _ in range(n)]
+        fill = lambda: [launch(v, key, 1, s2) for _ in range(n)]
         alone = min(both(False, fill)[1] for _ in range(2))
         t = both(True, fill)
         print('%-14s train of %d x %s: alone %.2f ms | beside the stage: stage %.2f train %.2f | sum %.2f' % (name, n, 'x'.join(map(str, key)), alone, t[0], t[1], 29.4 + alone), flush=True)
