@@ -355,6 +355,7 @@ def run(argv=None):
     ap.add_argument('--mode', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--total', type=int, default=64, help='--mode strong: sequences in the whole job (BASELINE configs[2]: 64)')
     ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over')
+    ap.add_argument('--no-host-stream', action='store_true', help='skip the optimize_stream() measurement (profiler runs of ONE stream: its batches are co-scheduled and would mix into the kernel statistics)')
     ap.add_argument('--no-coschedule', action='store_true', help='two streams left to themselves and the LDS kernels for the priors (the round-2 / early round-3 pipeline)')
     ap.add_argument('--no-graph-step', action='store_true', help='do NOT capture a whole step per stream as one HIP graph after the warm-up (default: capture, check the replay '
                     'against a plain step bit for bit, replay it in the timed region -- a host whose driver calls are slow then no longer paces the ~25 launches of '
@@ -520,7 +521,7 @@ def run(argv=None):
     host_single = time.time() - t0
     tm = dict(model.timings)
     host_stream = None
-    if hasattr(model, 'optimize_stream'):
+    if hasattr(model, 'optimize_stream') and not args.no_host_stream:
         # steady state of the pipelined stream: the first pass creates the three pinned output sets a depth-3 pipeline holds (page-locking
         # 400 MB each: a one-off ~100 ms the 6-batch figure of rounds 1-2 carried); the timed pass re-uses them
         for _ in model.optimize_stream([in_dicts] * 4):

@@ -36,7 +36,7 @@ def per_kernel(rows, name_part):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    bench = 'python %s/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-kernel-lines' % ROOT
+    bench = 'python %s/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-kernel-lines --no-host-stream' % ROOT
     calib = 'python %s/tools/collect_pmc.py calib' % ROOT
     res = {}
     raw = []
