@@ -349,8 +349,8 @@ class _StubModel:
 def run(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=1024, help='independent sequences per GPU per step (weak scaling)')
     ap.add_argument('--mode', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--total', type=int, default=64, help='--mode strong: sequences in the whole job (BASELINE configs[2]: 64)')
