@@ -12,9 +12,16 @@ independent, so ranks share nothing on the data path; the only collectives are t
 time.  `--mode weak` (default): every rank works on its own B sequences; `--mode strong --total 64`: BASELINE configs[2], a fixed set
 of 64 sequences split over the ranks.
 
-After the warm-up the whole step is captured as ONE HIP graph per stream, checked against a plain step bit for bit (same seed for the
-sampled latents) and replayed in the timed region: the same kernels on the same buffers with one launch on the host instead of ~25, so a
-host with slow driver calls does not pace the GPU (`config.step_graph`; `--no-graph-step`, or any failure of capture / check: plain launches).
+After the warm-up the whole step is captured as HIP graphs, one set per stream, checked against a plain step bit for bit (same seed for the
+sampled latents) and replayed in the timed region: the same kernels on the same buffers with a couple of launches on the host instead of ~25,
+so a host with slow driver calls does not pace the GPU (`config.step_graph`; `--no-graph-step`, or any failure of capture / check: plain launches).
+
+With two streams (the default) the batches are CO-SCHEDULED (`config.coscheduled_streams`, `pipeline`): a gate -- product code,
+GlobalReconOptimizer.pipeline_gate, also what optimize_stream() uses -- starts a batch when the previous batch's priors are done, and its
+motion infiller runs on kernels written to fit beside a resident workgroup of that batch's optimiser stage (no LDS, one wave per workgroup,
+fragment-major activations: csrc/nn_free.hpp).  Same work, same results (the infiller's outputs agree with the LDS kernels' to 7e-7); the
+stage launch takes longer beside them than alone, the step is shorter.  `--no-coschedule` / GLAMR_COSCHEDULE=0: the two streams left to
+themselves on the LDS kernels.
 
 Kernel durations come from the kernel's own clock (stamps in the workspace header = what rocprofv3 reports for the dispatch), and the
 roofline launch is measured with the GPU to itself (see run()).
@@ -23,7 +30,8 @@ Prints ONE JSON line on rank 0:
   roofline      the dominant kernel (the fused optimiser stage).  It is LATENCY / ISSUE bound: `us_per_scene_iteration` against the
                 1.45 us dependent-boundary floor is the figure that describes it; `achieved` / `frac` are the contract's NOTIONAL HBM line
                 (SURVEY 8d's live-state bytes over the launch time -- bytes the kernel keeps on chip and does not move); `traffic` are the
-                memory-side bytes of one launch from rocprofv3 PMC passes on the shipped instance (profiles/r02_pmc_stage_kernel.json)
+                memory-side bytes of one launch from rocprofv3 PMC passes on the shipped instance (the newest profiles/rNN_pmc_stage_kernel.json).
+                Measured with the GPU to itself; `pipeline` holds what the launch takes beside the other stream's priors
   kernels       stand-alone rooflines SURVEY 8(d) asks for: SMPL skinning (B = 300 and 19 200, with and without vertices), the priors'
                 GEMMs, and the other BASELINE configs that fit one GPU (configs[0] 120-frame infiller + skinning, configs[3] 4-person scenes)
   cpu_baseline  the CPU oracle (a port of the reference, oracle/port) timed on a bounded sample on this box's host cores
