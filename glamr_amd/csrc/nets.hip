@@ -480,6 +480,11 @@ int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const flo
   static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;      // development aid: the separate GEMM + LayerNorm launches
   if (!no_fuse && !tl_free && M >= FUSE_MIN_ROWS && L.N == D && L.K == D && L.Ws)
     return launch_rows(st, X, D, M, D, nullptr, 0, nullptr, nullptr, 1, 0, L.Ws, (size_t)D * L.K, L.K, L.b, ACT_NONE, R, D, n.g, n.b, Y, D);
+  static const bool res_in_ln = std::getenv("GLAMR_NETS_RES_IN_LN") != nullptr;      // development aid (A/B)
+  if (tl_free && !res_in_ln) {      // the residual in the GEMM's epilogue (same sum, same order): the three-pass LayerNorm then streams ONE array
+    RC(lin(st, L, X, D, tmp, D, M, ACT_NONE, R, D));
+    return ln(st, tmp, nullptr, n, Y, M);
+  }
   RC(lin(st, L, X, D, tmp, D, M));
   return ln(st, tmp, R, n, Y, M);
 }
@@ -491,6 +496,11 @@ int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float*
                        n ? n->g : nullptr, n ? n->b : nullptr, Y, D);
   RC(lin(st, L1, X, ldx, hidden, FF, M, ACT_RELU, nullptr, 0, nullptr, 1, 0, xl));
   if (!n) return lin(st, L2, hidden, FF, Y, D, M, act2, R, D);
+  static const bool res_in_ln2 = std::getenv("GLAMR_NETS_RES_IN_LN") != nullptr;
+  if (tl_free && !res_in_ln2) {
+    RC(lin(st, L2, hidden, FF, tmp, D, M, act2, R, D));
+    return ln(st, tmp, nullptr, *n, Y, M);
+  }
   RC(lin(st, L2, hidden, FF, tmp, D, M, act2));
   return ln(st, tmp, R, *n, Y, M);
 }
