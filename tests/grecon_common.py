@@ -237,3 +237,34 @@ def check_full_schedule(runner, asset_root, golden, cfg_id, T, P, gap):
             cam = data['cam_pose'].numpy() if hasattr(data['cam_pose'], 'numpy') else data['cam_pose']
             report.append((stage, full_schedule_errors(persons, cam, g, P, '' if last else 's1_')))
     return report
+
+
+def check_poses_only(runner, asset_root):
+    """GLAMR_FLAG_POSES_ONLY against the full forward-only launch: same orient_world / trans_world / cam_pose to the bit, projections untouched."""
+    from oracle.port import build
+    from oracle import make_golden as mg
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.utils import synth
+    run, dev = runner
+    for cfg_id, T, P in (('glamr_dynamic', 300, 1), ('glamr_dynamic_multi', 90, 2)):
+        cfg = get_config(cfg_id)
+        in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model())
+        ora = build.load_optimizer(asset_root, cfg)
+        data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 3))
+        jl = j_local_from_oracle(ora.smpl, data)
+        spec = next(iter(cfg['opt_stage_specs'].values()))
+        out = []
+        for poses_only in (False, True):
+            packed = packing.PackedScenes([data], [jl], dev)
+            packed.t['kp_2d_pred'].fill_(-7.0)
+            sd = packing.stage_desc(spec, cfg['grecon_model_specs'], False, niters=0)
+            sd.var_mask = 0
+            sd.flags &= ~packing.FLAG_CAM_FROM_PERSON
+            if poses_only:
+                sd.flags |= packing.FLAG_POSES_ONLY
+            run(packed, sd, False)
+            out.append({k: packed.t[k].cpu().numpy().copy() for k in ('orient_world', 'trans_world', 'cam_pose', 'kp_2d_pred')})
+        for k in ('orient_world', 'trans_world', 'cam_pose'):
+            assert np.array_equal(out[0][k], out[1][k]), (cfg_id, k)
+        assert np.isfinite(out[0]['orient_world']).all() and np.abs(out[0]['trans_world']).max() > 0
+        assert (out[1]['kp_2d_pred'] == -7.0).all() and not (out[0]['kp_2d_pred'] == -7.0).all()

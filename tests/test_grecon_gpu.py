@@ -11,3 +11,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES)
 def test_fused_optimiser_kernel_vs_reference_fixture(asset_root, golden, cfg_id, T, P, K):
     gc.check_case(gc.device_runner(), asset_root, golden, cfg_id, T, P, K)
+
+
+def test_poses_only_forward_pass_writes_the_same_world_poses(asset_root):
+    """GLAMR_FLAG_POSES_ONLY through the C ABI (see tests/test_grecon_hostsim.py)."""
+    gc.check_poses_only(gc.device_runner(), asset_root)

@@ -85,6 +85,13 @@ def test_arena_and_constant_layout_instances_equal_the_plain_one(asset_root):
             assert np.array_equal(ref, other[k]), (k, what, np.abs(ref - other[k]).max())
 
 
+def test_poses_only_forward_pass_writes_the_same_world_poses(asset_root):
+    """GLAMR_FLAG_POSES_ONLY: a forward-only launch (niters 0) that stops after orient_world / trans_world / cam_pose -- init_data's pass before
+    init_cam_pose(all_frames=True), whose other outputs nobody reads.  Same world poses TO THE BIT as the full forward-only launch, on a
+    2-person scene (a person entering late included) and on BASELINE configs[1]'s input; the projections are left untouched."""
+    gc.check_poses_only(gc.hostsim_runner(), asset_root)
+
+
 @pytest.mark.parametrize('cfg_id,T,P,gap', [('glamr_3dpw', 300, 1, True), ('glamr_dynamic_multi', 300, 2, False)])
 def test_full_schedules_of_the_other_configs_follow_the_reference(asset_root, golden, cfg_id, T, P, gap):
     """Every stage to its LAST iteration (200 + 500) from the oracle's initial state, on the CPU runtime of the kernel algorithm, against the
