@@ -186,6 +186,10 @@ def kernel_lines(asset_root, model, dev):
                      'frac_of_f32_mfma_peak': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 3),
                      'frac_of_fp16x3_peak': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12 / FP16X3_PEAK_TFLOPS, 4),
                      'note': 'infiller (10 autoregressive windows) + trajectory predictor; fp32-grade results on the fp16 matrix cores by 2-way operand splitting (3 MFMAs per k step)'}
+    dtc = _timed(lambda: model.mt_model.infer_padded(pose, vis, [T] * Bn, meps, teps, coschedule=True), reps=2)
+    out['priors']['coschedulable_kernels_ms'] = round(dtc * 1e3, 2)
+    out['priors']['coschedulable_note'] = ('the same call with GLAMR_NETS_COSCHEDULE (what the two-stream pipeline uses): infiller on the LDS-free one-wave kernels -- '
+                                           'slower ALONE (no on-chip fusion), but they run beside a resident optimiser stage, which the LDS kernels cannot')
     # BASELINE configs[0]: one 120-frame clip through the infiller, then full skinning with vertices -- batched over 1024 clips
     T0 = 120
     pose0, vis0 = pose[:, :T0].contiguous(), vis[:, :T0].contiguous()
