@@ -72,7 +72,11 @@ __global__ __launch_bounds__(64, MAXW) void gemm_free_kernel(GemmArgs a) {
   auto step = [&](int slot) {
     const float x[8] = {xr[slot][0][0], xr[slot][0][1], xr[slot][0][2], xr[slot][0][3], xr[slot][1][0], xr[slot][1][1], xr[slot][1][2], xr[slot][1][3]};
     f16x8 xh, xl;
+#ifdef GLAMR_GEMM_NOSPLIT      // development aid (tools/gemm_free_bench.py): what the operand split costs beside the stage -- wrong results
+    xh = __builtin_bit_cast(f16x8, xr[slot][0]); xl = __builtin_bit_cast(f16x8, xr[slot][1]);
+#else
     split8(x, xh, xl);
+#endif
     // the two small products first; consecutive MFMAs go to different accumulators
 #pragma unroll
     for (int j = 0; j < C; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wr[slot][1][j]), xh, acc[j], 0, 0, 0);

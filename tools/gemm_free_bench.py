@@ -14,7 +14,7 @@ VARIANTS = {0: '32x64  PD1 w4 (product)', 1: '32x64  PD2 w3', 2: '32x128 PD1 w2'
 
 
 def lib():
-    so, src = os.path.join(HERE, '_gemm_free_bench.so'), os.path.join(HERE, 'gemm_free_bench.hip')
+    so, src = os.path.join(HERE, os.environ.get('GLAMR_GFB_SO', '_gemm_free_bench.so')), os.path.join(HERE, 'gemm_free_bench.hip')
     deps = [src, os.path.join(HERE, '..', 'glamr_amd', 'csrc', 'nn_free.hpp'), os.path.join(HERE, '..', 'glamr_amd', 'csrc', 'nn_kernels.hpp')]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
         subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', src,
