@@ -23,6 +23,15 @@ int fail(int code, const char* fmt, ...);
     if (!(cond)) return ::glamr::fail(GLAMR_E_INVALID, __VA_ARGS__);                                                  \
   } while (0)
 
+// Kernels that sit on the pipeline's critical path (the LDS kernels between two optimiser stages: recurrence, the trajectory predictor's
+// GEMMs, scene assembly, skinning) raise their waves' issue priority over the co-scheduled infiller of the other stream, whose one-wave
+// workgroups share their SIMDs and have slack (user priority 0..3; the stage kernel itself runs at 3)
+#ifndef GLAMR_NO_SETPRIO
+#define GLAMR_CRITICAL_PATH_PRIO() __builtin_amdgcn_s_setprio(2)
+#else
+#define GLAMR_CRITICAL_PATH_PRIO() ((void)0)
+#endif
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <typename T>

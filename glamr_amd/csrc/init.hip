@@ -248,6 +248,7 @@ __device__ void quat_to_rotmat(const float q_[4], float R[9]) {
 }
 
 __global__ __launch_bounds__(256) void init_scene_kernel(SceneInitArgs a) {
+  GLAMR_CRITICAL_PATH_PRIO();
   __shared__ int s_start;
   __shared__ float s_caminv[12];
   const glamr_scene_batch& b = a.b;

@@ -112,6 +112,7 @@ __device__ __forceinline__ void split2(f32x2 x, unsigned& hi, unsigned& lo) {
 // LDS bandwidth; no LDS at all 77 -- L1 bandwidth; this one 85; the plain fp32-MFMA kernel 76.)
 template <int WN>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
+  GLAMR_CRITICAL_PATH_PRIO();
   constexpr int TN = 64 * WN;
   __shared__ __attribute__((aligned(16))) unsigned char sA[NPL][128 * BS_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,6 +264,7 @@ struct RowsArgs {
 // rows (twice the L2 traffic per row, still a fraction of its bandwidth).
 template <bool TWO, int KS1 = 0, int RT = 2>
 __global__ __launch_bounds__(512, RT == 1 ? 4 : 1) void rows_fused_kernel(RowsArgs a) {      // (second argument: waves per SIMD)
+  GLAMR_CRITICAL_PATH_PRIO();
   constexpr int RB = 32 * RT;                                       // rows per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NJ = 1;                                             // 8 waves: one 32-column tile each (x 2 row tiles)
@@ -905,6 +907,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
 __global__ __launch_bounds__(512) void lstm_mfma_kernel(LstmArgs a, int n_seq) {
+  GLAMR_CRITICAL_PATH_PRIO();
   constexpr int HS = 136;                                                   // halves per LDS row
   __shared__ __attribute__((aligned(16))) _Float16 sh[2][2][16][HS];        // [buffer][plane][sequence][unit]
   const int dir = blockIdx.y, s0 = blockIdx.x * 16;

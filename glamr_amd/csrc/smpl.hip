@@ -140,6 +140,7 @@ struct PrepArgs {
 };
 
 __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
+  GLAMR_CRITICAL_PATH_PRIO();
   __shared__ float sG[PREP_FRAMES][NJ][12];   // global transform of each joint: 3x3 rotation | translation
   __shared__ float sJ[PREP_FRAMES][NJ][3];    // rest joints
   const int tid = threadIdx.x;
@@ -251,6 +252,7 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // the only thing that hides a wave's operand fetches); their vertex transpose buffers hold half a frame tile and are used twice.
 template <int NE, bool F16 = false>
 __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
+  GLAMR_CRITICAL_PATH_PRIO();
   constexpr int NW = F16 ? 8 : 4, NT = NW * 64;               // waves, threads
   constexpr int OF = F16 ? TILE_F / 2 : TILE_F;                // frames per transpose pass
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -471,6 +473,7 @@ struct FinishArgs {
 
 // one WAVE per frame, four frames per workgroup (a workgroup per frame was 307 200 launches of 64 threads for a 1024 x 300 batch: 0.27 ms)
 __global__ __launch_bounds__(256) void smpl_finish_kernel(FinishArgs a) {
+  GLAMR_CRITICAL_PATH_PRIO();
   __shared__ float sExtra[4][MAX_EXTRA * 3];
   __shared__ float sPivot[4][3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
