@@ -57,6 +57,7 @@ DEPENDENT_BOUNDARY_US = 1.45
 SMPL_FLOP_PER_FRAME = 15.8e6                  # blend shapes + skinning + regression, with vertices
 SMPL_BYTES_PER_FRAME_VERTS = 6890 * 3 * 4 + 26 * 3 * 4 + 82 * 4      # vertex + joint write-out, pose / shape read
 NETS_FLOP_PER_SEQUENCE = 3.2e9                # infiller 272 MFLOP per window x 10 windows + trajectory predictor 0.93 GFLOP at 300 frames
+PORT_OVER_REFERENCE = 0.80                    # time per iteration, port / unmodified reference, build container, 8 threads (130 vs 162 ms: tests/test_reference_container.py)
 FP16X3_PEAK_TFLOPS = 2500.0 / 3.0             # fp32-grade products on the fp16 matrix cores cost three MFMAs per k step (hi*hi + hi*lo + lo*hi): dense fp16 peak / 3
 
 
@@ -126,8 +127,8 @@ def cpu_baseline(asset_root, iters=40):
     run(iters)
     per_iter = (time.time() - t0) / iters
     total = t_init + per_iter * spec['opt_niters']
-    return {'value': 1.0 / total, 'unit': 'sequences/sec', 'cores': nt, 'kind': 'port (reference absent on this box)',
-            'ms_per_iteration': per_iter * 1e3, 'iterations_timed': iters,
+    return {'value': 1.0 / total, 'unit': 'sequences/sec', 'cores': nt, 'kind': 'port', 'kind_note': 'the reference is absent on this box: oracle/port, pinned to it in the build container',
+            'ms_per_iteration': per_iter * 1e3, 'iterations_timed': iters, 'port_over_reference': PORT_OVER_REFERENCE,
             'port_vs_reference': 'build container, 8 threads: port 130 ms, unmodified reference 162 ms per iteration (tests/test_reference_container.py): the port is the faster baseline',
             'sample': 'oracle/port on 1 sequence of %d frames: init_data (%.2f s) + thread scan %s ms/iter, then %d of %d Adam iterations at %d threads '
                       '(%.1f ms/iter), extrapolated to the full schedule (%.1f s/sequence)'
@@ -166,12 +167,12 @@ def kernel_lines(asset_root, model, dev):
             dt = _timed(lambda: smpl(global_orient=pose[:, :3], body_pose=pose[:, 3:], betas=betas, root_trans=trans, return_verts=verts))
             tf = SMPL_FLOP_PER_FRAME * B / dt / 1e12 if verts else None
             lines.append({'frames': B, 'vertices': verts, 'ms': round(dt * 1e3, 4),
-                          'tflops_algorithmic': None if tf is None else round(tf, 2), 'frac_of_f32_mfma_peak': None if tf is None else round(tf / F32_MFMA_PEAK_TFLOPS, 3),
+                          'tflops_algorithmic': None if tf is None else round(tf, 2),
                           'frac_of_fp16x3_peak': None if tf is None else round(tf / FP16X3_PEAK_TFLOPS, 4),
                           'write_gbs': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9, 1) if verts else None,
                           'frac_of_hbm_peak': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9 / HBM_PEAK_GBS, 3) if verts else None})
     best = max((l['tflops_algorithmic'] or 0.0) for l in lines)
-    out['smpl_lbs'] = {'flop_per_frame': SMPL_FLOP_PER_FRAME, 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'fp16x3_peak_tflops': round(FP16X3_PEAK_TFLOPS, 1),
+    out['smpl_lbs'] = {'flop_per_frame': SMPL_FLOP_PER_FRAME, 'fp16x3_peak_tflops': round(FP16X3_PEAK_TFLOPS, 1),
                        'frac_of_fp16x3_peak': round(best / FP16X3_PEAK_TFLOPS, 4), 'runs': lines}
     # the two priors on 1024 sequences of 300 frames (GEMM-dominated: the fp16-split MFMA kernels)
     md = synth.make_smpl_model()
@@ -183,7 +184,6 @@ def kernel_lines(asset_root, model, dev):
     dt = _timed(lambda: model.mt_model.infer_padded(pose, vis, [T] * Bn, meps, teps), reps=2)
     out['priors'] = {'sequences': Bn, 'frames': T, 'ms': round(dt * 1e3, 2), 'sequences_per_sec': round(Bn / dt, 1),
                      'tflops_fp32_equivalent': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12, 1), 'flop_per_sequence': NETS_FLOP_PER_SEQUENCE,
-                     'frac_of_f32_mfma_peak': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 3),
                      'frac_of_fp16x3_peak': round(NETS_FLOP_PER_SEQUENCE * Bn / dt / 1e12 / FP16X3_PEAK_TFLOPS, 4),
                      'note': 'infiller (10 autoregressive windows) + trajectory predictor; fp32-grade results on the fp16 matrix cores by 2-way operand splitting (3 MFMAs per k step)'}
     dtc = _timed(lambda: model.mt_model.infer_padded(pose, vis, [T] * Bn, meps, teps, coschedule=True), reps=2)
@@ -341,6 +341,44 @@ def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8, group=
                     'shared camera gradient and the Adam launch; the default keeps the scene in one workgroup for all iterations of a stage'}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: this file re-executed under torch.distributed.run (glamr_amd.parallel.self_launch); rank 0's
+    JSON line is the only line on stdout."""
+    from glamr_amd import parallel
+    return parallel.self_launch(n, [os.path.abspath(__file__)], argv, keep_on_stdout=lambda line: line.lstrip().startswith('{"metric"'))
+
+
+def strong_line(model, md, rank, world, dev, total, steps, sync, use_dist):
+    """BASELINE configs[2] in the SAME run as the weak line: a fixed job of `total` (64) independent 300-frame sequences split over the ranks in
+    balanced contiguous blocks (parallel.shard_range), no data-path collective; `steps` passes, barrier + synchronize on both sides, max over
+    ranks.  It cannot scale and is not meant to: 64 scenes occupy 64 of one GPU's 256 CUs for about ONE sequence latency, so N GPUs finish
+    64 / N scenes each in the same time -- the figure exists to show exactly that next to the weak line."""
+    import torch.distributed as dist
+    from glamr_amd import parallel
+    from glamr_amd.utils import synth
+    lo, hi = parallel.shard_range(total, rank, world)
+    in_dicts = [synth.make_in_dict(seed=sd, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md) for sd in range(lo, hi)]
+    rin = model.stage_inputs(in_dicts) if in_dicts else None
+    run_once = (lambda: model.optimize_resident(rin)) if in_dicts else (lambda: None)
+    run_once()
+    sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    t0 = time.time()
+    for _ in range(steps):
+        run_once()
+    sync()
+    if use_dist:
+        dist.barrier()
+    elapsed = parallel.max_over_ranks(time.time() - t0, dev)
+    n = parallel.sum_over_ranks(hi - lo, dev)
+    return {'workload': 'BASELINE configs[2]: %d independent %d-frame 1-person sequences (cfg %s) split over %d rank(s), %d on rank 0' % (total, NUM_FRAMES, CFG_ID, world, hi - lo),
+            'scaling': 'strong', 'sequences_total': n, 'steps': steps, 'ms_per_step': elapsed / steps * 1e3, 'sequences_per_sec': n * steps / elapsed,
+            'note': 'one plain (ungraphed, single-stream) optimize_resident per step; a GPU holds one 300-frame scene per CU, so %d scenes use %d of its CUs '
+                    'for about one sequence latency -- more GPUs cannot shorten that: the weak line is the scaling figure' % (hi - lo, hi - lo)}
+
+
 class _StubModel:
     """CPU stand-in used by tests/test_parallel_gloo.py to run this file's distributed skeleton (init, asset barrier, seed partition,
     timing protocol, max-reduction, rank-0 JSON) over gloo without a GPU.  Never used by a real measurement."""
@@ -374,19 +412,25 @@ def run(argv=None):
                     'a step; any failure of capture or check falls back to plain launches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-lines', action='store_true')
+    ap.add_argument('--no-strong-line', action='store_true', help='skip the BASELINE configs[2] line (64 sequences split over the ranks) measured after the weak one')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo with --stub-model for the CPU test of the skeleton)')
     ap.add_argument('--stub-model', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--force-dist', action='store_true', help='create the process group also at --gpus 1 (a world of one rank): runs the init / barrier / reduction / '
                     'collective-latency code of the multi-GPU path on a single GPU (tests/test_e2e_gpu.py)')
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): spawn the N ranks ourselves, one process per GPU, exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` command line would; rank 0's JSON line is this process's
+        raise SystemExit(self_launch(args.gpus, list(sys.argv[1:] if argv is None else argv)))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+        raise SystemExit('--gpus %d inside a job of WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or plainly (no RANK in the '
+                         'environment) and bench.py spawns its own ranks' % (args.gpus, world, args.gpus))
     on_gpu = not args.stub_model
     if on_gpu:
         torch.cuda.set_device(local_rank)
@@ -500,11 +544,18 @@ def run(argv=None):
         model.pipeline_gate = None                                   # the single-stream measurements below run the plain step
     elapsed = parallel.max_over_ranks(elapsed, dev)
     n_total = parallel.sum_over_ranks(B, dev)                      # units all ranks processed per step
+    rccl_ranks = dist.get_world_size() if (use_dist and dist.get_backend() == 'nccl') else None
+    strong = None
+    if args.mode == 'weak' and not args.no_strong_line:
+        gate_keep, model.pipeline_gate = getattr(model, 'pipeline_gate', None), None
+        strong = strong_line(model, md, rank, world, dev, args.total, max(2, min(5, args.steps)), sync, use_dist)
+        model.pipeline_gate = gate_keep
     if args.stub_model:
         out = {'metric': 'sequences/sec (300-frame, 1-person) end-to-end global_recon', 'value': n_total * args.steps / elapsed, 'unit': 'sequences/sec',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
                'scaling': args.mode, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': {'workload': 'STUB (CPU test of the skeleton)', 'sequences_total': n_total,
-                                                                                                          'seeds_first_last': [int(seeds[0]), int(seeds[-1])]}}
+                                                                                                          'seeds_first_last': [int(seeds[0]), int(seeds[-1])]},
+               'rccl_ranks': rccl_ranks, 'process_group_ranks': dist.get_world_size() if use_dist else None, 'configs2_strong_64': strong}
         if rank == 0:
             print(json.dumps(out))
         if use_dist:
@@ -597,7 +648,9 @@ def run(argv=None):
             'metric': 'sequences/sec (300-frame, 1-person) end-to-end global_recon', 'value': n_total * args.steps / elapsed,
             'unit': 'sequences/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.mode, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'host_enqueue_ms_per_step': enqueue / args.steps * 1e3,
+            'dtype': 'f32 (optimiser, init_data) / fp16x2-split MFMA with f32 accumulation (priors, LBS: every f32 operand as hi + lo fp16 planes, hi*hi + hi*lo + lo*hi)',
+            'data': 'synthetic', 'host_enqueue_ms_per_step': enqueue / args.steps * 1e3,
+            'rccl_ranks': rccl_ranks, 'process_group_ranks': dist.get_world_size() if use_dist else None,
             'config': {'workload': ('BASELINE configs[1]: %d-frame 1-person dynamic-camera sequences, cfg %s (%d Adam iterations), batch of %d independent '
                                     'sequences per GPU, HybrIK arrays resident in HBM%s' % (NUM_FRAMES, CFG_ID, iters, B, '; the step is replayed as one captured HIP graph per stream (bit-checked against plain launches)' if step_graphs else '')) if args.mode == 'weak' else
                                    ('BASELINE configs[2]: %d independent %d-frame 1-person sequences (cfg %s, %d iterations) split over %d GPU(s): %d per GPU '
@@ -605,24 +658,28 @@ def run(argv=None):
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
                        'streams_per_gpu': len(streams), 'step_graph': bool(step_graphs), 'coscheduled_streams': bool(coschedule)},
             'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'latency/issue',
-                         'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration: neither HBM nor the matrix pipes limit it; the '
-                                       "contract's hbm line (achieved / peak / frac) is kept below and is NOTIONAL",
-                         'contract_bound': 'hbm',
+                         'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration: neither HBM nor the matrix pipes limit it. '
+                                       'achieved / peak / frac are SURVEY 8(d) K5\'s yardstick: microseconds per scene-iteration against the 1.45 us dependent-boundary floor '
+                                       "(frac = floor / achieved).  The contract's hbm line is kept under `contract_notional` and is NOTIONAL",
+                         'achieved': us_scene_iter, 'peak': DEPENDENT_BOUNDARY_US, 'unit': 'us per scene-iteration (lower is better; peak = dependent-boundary floor)',
+                         'frac': DEPENDENT_BOUNDARY_US / us_scene_iter if us_scene_iter > 0 else None,
                          'us_per_scene_iteration': us_scene_iter, 'dependent_boundary_floor_us': DEPENDENT_BOUNDARY_US,
                          'times_above_floor': us_scene_iter / DEPENDENT_BOUNDARY_US,
                          'issue_slot_utilisation': issue_util, 'traffic_over_compulsory': over_compulsory, 'traffic_bytes_per_scene_iteration': bytes_si,
                          'compulsory_bytes_per_scene_iteration': ALGO_BYTES_PER_PERSON_ITER / float(iters),
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'frac_is_notional': True,
+                         'contract_notional': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'contract_notional_frac': achieved / HBM_PEAK_GBS,
+                                               'note': '%d B per person-iteration (SURVEY.md 8d K5 live state) x %d scenes x %d iterations / launch time: bytes the '
+                                                       'kernel keeps in LDS and does not move' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'traffic_gbs': None if traffic is None or k_avg <= 0 else traffic / (k_avg * 1e-3) / 1e9,
+                         'traffic_frac_of_hbm_peak': None if traffic is None or k_avg <= 0 else traffic / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'avg_launch_ms': k_avg, 'scenes_per_launch': B, 'iterations_per_launch': iters, 'rounds_per_launch': rounds,
                          'launch_ms_each': [round(x, 2) for x in kms],
                          'launch_ms_in_timed_region': None if kms_timed is None else [round(x, 2) for x in kms_timed],
                          'measured': ('the launches of the timed region (one stream)' if kms is kms_timed else
                                       '2 single-stream plain steps right after the timed region: in the timed region the launches of the %d stream(s) '
                                       'share the CUs%s' % (len(streams), ' and are graph replays (one workspace per graph: no per-replay stamps)' if step_graphs else '')),
-                         'note': 'achieved / frac = %d B per person-iteration (SURVEY.md 8d K5 live state) x %d scenes x %d iterations / launch time: bytes the '
-                                 'kernel keeps in LDS and does not move -- notional.  traffic = memory-side bytes (PMC).' % (ALGO_BYTES_PER_PERSON_ITER, B, iters)},
+                         'note': 'traffic = memory-side bytes of one launch (rocprofv3 PMC passes on the shipped instance)'},
             'pipeline': None if not coschedule else {
                 'coscheduled_streams': True, 'stage_launch_ms_alone': k_avg, 'stage_launch_ms_beside_the_priors': beside,
                 'note': 'two streams, batches staggered by GlobalReconOptimizer.pipeline_gate: a batch starts when the previous one\'s priors are done, so its '
@@ -634,6 +691,8 @@ def run(argv=None):
             'host_inclusive_single_call_sequences_per_sec': B / host_single,
             'host_inclusive_stage_seconds': {k: round(v, 4) for k, v in tm.items()},
         }
+        if strong is not None:
+            out['configs2_strong_64'] = strong
         if sharded4 is not None:
             out['configs3_person_sharded'] = sharded4
         if coll_us is not None:

@@ -7,6 +7,8 @@ from ctypes import c_int, c_int32, c_int64, c_size_t, c_uint32, c_float, c_doubl
 _LIB = None
 LIB_PATH = os.environ.get('GLAMR_LIB_PATH') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libglamr_hip.so')      # (override: A/B runs of kernel variants, tools/README.md)
 NUM_LOSSES = 13
+LOSS_CAMERA_ONLY = (9, 13)    # [first, last) of the camera-only terms: CAM_INV_TRANS_RES_REG, CAM_INV_ROT_SMOOTHNESS, CAM_ORIGIN_SMOOTHNESS, CAM_UP_REG
+LOSS_KP_2D_DIST = 1          # index of the monitor-only keypoint distance in the loss record (GLAMR_LOSS_KP_2D_DIST, include/glamr_hip.h)
 
 
 class TensorDesc(Structure):

@@ -8,7 +8,14 @@ reference's own `run_pose_est_on_video` is called if it can be imported, as run_
 `<gt_dir>/<seq>.pkl` (preprocess/preprocess_3dpw.py; `--gt_dir` defaults to the dataset's `processed_v1/pose` directory, :27-38), and
 writes `<out_dir>/<seq>/grecon/<seq>_seed<k>.pkl` (:91-101, same dictionary).  Extensions: `--seqs` restricts / replaces the sequence
 list, `--seeds` also takes space-separated integers, and with ground truth present the metric line of `eval_dataset.py` is printed
-(returned by main()).  All sequences of one seed are optimised as ONE batch on the device."""
+(returned by main()).  All sequences of one seed are optimised as ONE batch on the device.
+
+`--gpus N` (extension; BASELINE configs[4]: the 3DPW test set on the 8 GPUs of a node): the sequence list is split into N contiguous
+balanced blocks (parallel.shard_range), one process per GPU reconstructs and evaluates its block -- sequences are independent, no
+data-path collective -- and the per-sequence metrics are gathered on rank 0 (parallel.gather_results over RCCL), which folds them in
+sequence order and prints the metric line.  Started plainly the command spawns its own ranks (parallel.self_launch); started under
+`torch.distributed.run --nproc-per-node N` it takes RANK / WORLD_SIZE from the environment.  The reference loops sequences serially on
+one GPU (run_dataset.py:67-105)."""
 import argparse
 import copy
 import glob
@@ -52,11 +59,53 @@ def build_parser():
     ap.add_argument('--cached', type=int, default=1)
     ap.add_argument('--seqs', nargs='+', default=None, help='extension: sequences to run (default: the test sequences of --dataset)')
     ap.add_argument('--gt_dir', default=None, help="extension: ground-truth directory (default: the dataset's gt_pose path when it exists)")
+    ap.add_argument('--gpus', type=int, default=1, help='extension: shard the sequences over N GPUs of this node, one process per GPU (rank r uses GPU r; --gpu is the single-process device)')
+    ap.add_argument('--backend', default=None, help='extension: torch.distributed backend of --gpus N (default nccl = RCCL)')
+    ap.add_argument('--stub-model', action='store_true', help=argparse.SUPPRESS)      # CPU stand-ins for the optimiser and the evaluator: tests of the sharding protocol over gloo
     return ap
+
+
+class _StubModel:
+    """CPU stand-in (tests/test_parallel_gloo.py): the result of a sequence is a function of its input alone, so the gathered metric line must
+    not depend on how the sequences were split."""
+    smpl = None
+
+    def optimize_batch(self, in_dicts):
+        return [dict(d, seq_len=len(next(iter(d['est'].values()))['bboxes_dict']['exist']), person_data={}) for d in in_dicts]
+
+
+class _StubEvaluator:
+    def __init__(self):
+        from glamr_amd.global_recon.utils.evaluator import AverageMeter
+        from collections import defaultdict
+        self.AverageMeter, self.totals, self.order = AverageMeter, defaultdict(AverageMeter), []
+
+    def compute_sequence_metrics(self, data, name=None, accumulate=False):
+        est = next(iter(data['est'].values()))
+        return {'seq_len': data['seq_len'], 'metrics': {'G-MPJPE': self.AverageMeter(float(np.abs(est['root_trans']).sum()) + sum(map(ord, name or "")) % 7, data['seq_len'])}}
+
+    def metrics_from_multiple_seeds(self, arr):
+        return {'seq_len': arr[0]['seq_len'], 'metrics': {'G-MPJPE': self.AverageMeter(float(np.mean([m['metrics']['G-MPJPE'].avg for m in arr])), arr[0]['metrics']['G-MPJPE'].count)}}
+
+    def update_accumulated_metrics(self, m, name=None):
+        self.order.append(name)
+        self.totals['G-MPJPE'].update(m['metrics']['G-MPJPE'].avg, m['metrics']['G-MPJPE'].count)
+
+    def print_metrics(self, prefix='', print_accum=False):
+        line = '%sstub --- G-MPJPE: %.6f sequences: %s' % (prefix, self.totals['G-MPJPE'].avg, ','.join(self.order))
+        print(line)
+        return line
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from glamr_amd import parallel
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        import sys
+        rc = parallel.self_launch(args.gpus, ['-m', 'glamr_amd.global_recon.run_dataset'], list(sys.argv[1:] if argv is None else argv))
+        if rc:
+            raise SystemExit(rc)
+        return None
     from glamr_amd.global_recon.configs import get_config
     from glamr_amd.global_recon.models import model_dict
     from glamr_amd.global_recon.utils.evaluator import Evaluator
@@ -70,11 +119,24 @@ def main(argv=None):
     if not seqs:
         raise SystemExit('no sequences: dataset %r has no built-in test list here, pass --seqs' % dataset)
     gt_dir = args.gt_dir if args.gt_dir is not None else (paths.get('gt_pose') if paths and os.path.isdir(paths['gt_pose']) else None)
-    device = torch.device('cuda', args.gpu)
-    torch.cuda.set_device(args.gpu)
+    rank, world, local_rank = parallel.env_rank_world()
+    if world != max(1, args.gpus):
+        raise SystemExit('--gpus %d inside a job of WORLD_SIZE=%d' % (args.gpus, world))
     cfg = get_config(args.cfg)
-    model = model_dict[cfg.get('grecon_model_name', 'global_recon_model')](cfg, device, None)
-    evaluator = Evaluator(algo=args.cfg, dataset=dataset, device=device, smpl=model.smpl) if gt_dir else None
+    if args.stub_model:
+        device = torch.device('cpu')
+        parallel.init_from_env(args.backend or 'gloo', device)
+        model, evaluator = _StubModel(), (_StubEvaluator() if gt_dir else None)
+    else:
+        gpu = local_rank if world > 1 else args.gpu
+        device = torch.device('cuda', gpu)
+        torch.cuda.set_device(gpu)
+        parallel.init_from_env(args.backend, device)
+        model = model_dict[cfg.get('grecon_model_name', 'global_recon_model')](cfg, device, None)
+        evaluator = Evaluator(algo=args.cfg, dataset=dataset, device=device, smpl=model.smpl) if gt_dir else None
+    all_seqs = list(seqs)
+    lo, hi = parallel.shard_range(len(all_seqs), rank, world)            # this rank's contiguous block of sequences
+    seqs = all_seqs[lo:hi]
     # (the name is handed on as typed, like eval_dataset.py:38 -- the evaluator's y-up branch tests for '3DPW', evaluator.py:250)
 
     in_dicts = []
@@ -83,7 +145,7 @@ def main(argv=None):
         if not os.path.exists(os.path.join(pose_dir, 'pose.pkl')):
             run_pose_est = _need('pose_est.run_pose_est_demo', 'run_pose_est_on_video', 'sequence %s without %s/pose.pkl' % (seq, pose_dir))
             run_pose_est(None, pose_dir, cfg['grecon_model_specs']['est_type'], image_dir=os.path.join(paths.get('image', ''), seq),
-                         bbox_file=os.path.join(paths.get('bbox', ''), seq + '.pkl'), cached_pose=int(args.cached), gpu_index=args.gpu)
+                         bbox_file=os.path.join(paths.get('bbox', ''), seq + '.pkl'), cached_pose=int(args.cached), gpu_index=(device.index or 0) if device.type == 'cuda' else args.gpu)
         with open(os.path.join(pose_dir, 'pose.pkl'), 'rb') as f:
             est = pickle.load(f)
         gt, meta = {}, {}
@@ -113,11 +175,21 @@ def main(argv=None):
                 # prepare_seq() trims and extends the dictionaries in place: the ground truth is shared with the next seed's input
                 work = dict(out, gt=copy.deepcopy(out['gt']), person_data=copy.deepcopy(out['person_data']))
                 per_seed[seq].append(evaluator.compute_sequence_metrics(work, '%s_seed%d' % (seq, seed), accumulate=False))
-    if evaluator is None:
-        return None
-    for seq in seqs:                               # eval_dataset.py: best / mean over seeds per sequence, then accumulate
-        evaluator.update_accumulated_metrics(evaluator.metrics_from_multiple_seeds(per_seed[seq]), seq)
-    return evaluator.print_metrics(prefix='%s %s: ' % (dataset, args.cfg), print_accum=False)
+    # every rank's (sequence, metrics over seeds) pairs -> rank 0, in global sequence order (blocks are contiguous and gathered by rank)
+    combined = [(seq, evaluator.metrics_from_multiple_seeds(per_seed[seq])) for seq in seqs] if evaluator is not None else [(seq, None) for seq in seqs]
+    gathered = parallel.gather_results(combined)
+    line = None
+    if gathered is not None:                       # rank 0 (or the only process)
+        assert [s for s, _ in gathered] == all_seqs, 'gathered sequences out of order'
+        if evaluator is not None:
+            for seq, m in gathered:                # eval_dataset.py: best / mean over seeds per sequence, then accumulate
+                evaluator.update_accumulated_metrics(m, seq)
+            line = evaluator.print_metrics(prefix='%s %s: ' % (dataset, args.cfg), print_accum=False)
+    if world > 1:
+        import torch.distributed as dist
+        parallel.barrier()
+        dist.destroy_process_group()
+    return line
 
 
 if __name__ == '__main__':

@@ -24,6 +24,44 @@ def weak_scaling_seeds(per_rank, rank):
     return list(range(rank * per_rank, (rank + 1) * per_rank))
 
 
+def self_launch(n, target, argv, keep_on_stdout=None):
+    """A command that was started plainly with `--gpus N` (no RANK in the environment) becomes N ranks: `target` (['script.py'] or
+    ['-m', 'package.module']) is re-executed under torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 at a free port.
+    The ranks' stdout passes through a filter: lines `keep_on_stdout(line)` accepts (default: all) stay on stdout, whatever else a backend
+    prints there (gloo's connection notes, RCCL's banner) goes to stderr.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    import sys
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # this pool's driver only supports dmabuf IPC (RCCL fails without it)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port)] + list(target) + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        (sys.stdout if (keep_on_stdout is None or keep_on_stdout(line)) else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def init_from_env(backend=None, device=None):
+    """Process group of a rank started by torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment): `nccl` (= RCCL) on a HIP
+    device, gloo otherwise.  Returns (rank, world, local_rank)."""
+    rank, world, local_rank = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = backend or ('nccl' if (device is not None and device.type == 'cuda') else 'gloo')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
@@ -193,17 +231,39 @@ class PersonShardedSchedule:
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
-        # every rank ends with the whole scene: own persons' variables and outputs to everybody
+        # every rank ends with the whole scene: own persons' variables and outputs to everybody -- including the BASE poses of the persons it
+        # did not own (during the loop those slots carried the peers' world poses: _all_gather_poses) and the loss values of the whole scene
         self._share_results(packed, own, block, person_cols)
+        self._reduce_losses(packed, own)
         packed.t['frozen'] = None
         packed.has_world_dheading = has_wd
         return packed
+
+    def _reduce_losses(self, packed, own):
+        """packed.t['losses'] after a sharded run: every rank's last evaluation reported ITS part -- the residuals of its own persons over the
+        GLOBAL normalisers -- so the scene's values are the sum over ranks.  Two exceptions: the camera-only terms (their VALUES are
+        reported by every rank, only their gradients are rank 0's: GLAMR_FLAG_NO_CAMERA_TERMS) count once, and the monitor-only keypoint
+        distance is a mean over the scored keypoints the rank saw: ranks are weighted by their own persons' visible frames."""
+        if not self.use_dist or self.world == 1:
+            return
+        from . import _lib
+        S, P, T = packed.S, packed.P, packed.T
+        losses = packed.t['losses']
+        vis = (packed.t['vis'].view(S, P, T) > 0).sum(dim=2).to(losses.dtype)              # visible frames per (scene, person)
+        w = vis[:, own].sum(dim=1)
+        part = losses.clone()
+        if self.rank != 0:
+            part[:, _lib.LOSS_CAMERA_ONLY[0]:_lib.LOSS_CAMERA_ONLY[1]] = 0.0
+        buf = torch.cat([part, (losses[:, _lib.LOSS_KP_2D_DIST] * w)[:, None], w[:, None]], dim=1).contiguous()
+        self._all_reduce(buf)
+        losses.copy_(buf[:, :losses.shape[1]])
+        losses[:, _lib.LOSS_KP_2D_DIST] = buf[:, -2] / buf[:, -1].clamp_min(1.0)
 
     def _share_results(self, packed, own, block, person_cols):
         if not self.use_dist:
             return
         S, P, T = packed.S, packed.P, packed.T
-        names = (('orient_world', 3), ('trans_world', 3), ('orient_cam_in_world', 3), ('kp_2d_pred', 52))
+        names = (('orient_world', 3), ('trans_world', 3), ('orient_cam_in_world', 3), ('kp_2d_pred', 52), ('base_orient', 3), ('base_trans', 3))
         width = sum(w for _, w in names)
         stride = person_cols[0].stop - person_cols[0].start
         mine = torch.zeros((block, S, T * width + stride), dtype=torch.float32, device=packed.device)

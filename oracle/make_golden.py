@@ -563,6 +563,63 @@ def gen_full_family():
     np.savez_compressed(os.path.join(GOLD, 'full_glamr_dynamic_T300_family.npz'), **out)
 
 
+FULL_SEEDS = (1, 2, 3, 4, 5, 6, 7, 8)          # BASELINE configs[1] WITH the detection gap, beyond seed 0 (gen_full): bench.py's workload is seeds 0 .. B-1
+FULL_SEEDS_FAMILY = (1, 2, 3)                 # seeds whose 1e-6 family (three members) is generated as well
+SEED_FAMILY = [('eps1e-6_seed%d' % sd, dict(eps=1e-6, seed=sd)) for sd in (0, 1, 2)]
+
+
+def seed_name(seed):
+    return 'full_glamr_dynamic_T300_s%d' % seed
+
+
+def gen_full_seeds(seeds=FULL_SEEDS, family_seeds=FULL_SEEDS_FAMILY):
+    """the full 500-iteration schedule of BASELINE configs[1] WITH the detection gap [100,160) on MORE THAN ONE seed --
+    the benchmark's workload is synth.make_in_dict(seed) for seeds 0 .. B-1, every one of them in the zero-camera regime of DESIGN.md 4.
+    One file per seed: the unmodified reference's final state, its initial cam_pose / projections (what the device init_data is compared
+    with), and for `family_seeds` the reference's own re-runs with the initial cam_pose x (1 + 1e-6 U(-1, 1)) (SEED_FAMILY), so that
+    "the device path ends on a member of the reference's family" is a statement about several seeds."""
+    import time
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    keys = ['kp_2d_pred', 'root_trans_world', 'smpl_orient_world', 'vis_frames']
+    for seed in seeds:
+        out = {}
+        members = [('', {})] + (list(SEED_FAMILY) if seed in family_seeds else [])
+        for name, opt in members:
+            model, cfg = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
+            in_dict = synth.make_in_dict(seed=seed, num_frames=300, num_persons=1, smpl_model=md)
+            keep = model.init_opt
+
+            def init_opt(data, opt_variables, opt_lr, keep=keep, opt=opt):
+                if opt.get('eps'):
+                    rng = np.random.RandomState(opt['seed'])
+                    cp = data['cam_pose']
+                    cp.mul_(torch.from_numpy((1 + opt['eps'] * rng.uniform(-1, 1, tuple(cp.shape))).astype(np.float32)))
+                return keep(data, opt_variables, opt_lr)
+            model.init_opt = init_opt
+            t0 = time.time()
+            data, init_state = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, seed))
+            dt = time.time() - t0
+            st = _flatten_state(data, keys, ['cam_pose'])
+            if not name:
+                out.update(st)
+                out['init_cam_pose'] = init_state['cam_pose']
+                out['init_p0_kp_2d_pred'] = init_state['p0_kp_2d_pred']
+                out['seed'] = np.array(seed)
+                out['ref_seconds'] = np.array(dt)
+                out['ref_threads'] = np.array(torch.get_num_threads())
+                print('seed %d: full reference optimize() %.1f s on %d threads; largest initial |projection| %.0f px'
+                      % (seed, dt, torch.get_num_threads(), float(np.abs(init_state['p0_kp_2d_pred'][st['p0_vis_frames']]).max())), flush=True)
+            else:
+                out['fam_%s_kp_2d_pred' % name] = st['p0_kp_2d_pred']
+                out['fam_%s_cam_pose' % name] = st['cam_pose']
+                out['fam_%s_root_trans_world' % name] = st['p0_root_trans_world']
+                d = np.abs(st['p0_kp_2d_pred'] - out['p0_kp_2d_pred'])[out['p0_vis_frames']].max(axis=(1, 2))
+                print('seed %d family member %-14s %.0f s: max %.3f px, frames > 1 px %d' % (seed, name, dt, d.max(), int((d > 1).sum())), flush=True)
+        np.savez_compressed(os.path.join(GOLD, seed_name(seed) + '.npz'), **out)
+
+
 FAMILY_CFG = [('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-6_seed0', dict(eps=1e-6, seed=0)), ('eps1e-6_seed1', dict(eps=1e-6, seed=1))]
 
 
@@ -662,7 +719,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

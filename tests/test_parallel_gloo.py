@@ -103,3 +103,69 @@ def test_bench_strong_scaling_split():
     """--mode strong: a fixed job (BASELINE configs[2]) split over the ranks in balanced contiguous blocks."""
     (r0, text0, out0), _ = _run_bench_skeleton('strong')
     assert out0['scaling'] == 'strong' and out0['config']['sequences_total'] == 7 and out0['config']['seeds_first_last'] == [0, 3]
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plain_env():
+    """A shell the driver would start a command from: no RANK / WORLD_SIZE / MASTER_* set."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE', 'GROUP_RANK')}
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    return env
+
+
+def test_bench_launched_plainly_spawns_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher and no rendezvous variables in the environment (what a SCALE driver that does not know about
+    torchrun would type): bench.py re-executes itself under torch.distributed.run with two ranks; rc 0, exactly ONE line on stdout -- rank 0's
+    JSON -- carrying the weak line AND the BASELINE configs[2] strong line of the same run."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub-model', '--backend', 'gloo', '--steps', '3', '--warmup', '1',
+                        '--batch', '6'], env=_plain_env(), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['process_group_ranks'] == 2 and out['config']['sequences_total'] == 12 and out['scaling'] == 'weak'
+    strong = out['configs2_strong_64']
+    assert strong['scaling'] == 'strong' and strong['sequences_total'] == 64 and '32 on rank 0' in strong['workload'] and strong['sequences_per_sec'] > 0
+    # inside a launcher with the wrong world size the message says what to do instead of a bare exit
+    env = dict(_plain_env(), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub-model', '--backend', 'gloo'], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr
+
+
+def test_run_dataset_sharded_over_two_ranks_prints_the_single_process_line(tmp_path):
+    """`python -m glamr_amd.global_recon.run_dataset --gpus 2` (BASELINE configs[4]'s driver) launched plainly: the sequence list is split in
+    contiguous blocks, every rank reconstructs and evaluates its own, rank 0 gathers the per-sequence metrics in sequence order and prints ONE
+    metric line -- equal to the line of the single-process run.  CPU stand-ins for the optimiser / evaluator (no GPU here); five sequences on
+    two ranks = blocks of 3 + 2; result pickles of BOTH ranks' sequences are on disk afterwards."""
+    import pickle
+    import subprocess
+    import sys
+    import numpy as np
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    out_dir, gt_dir = tmp_path / 'out', tmp_path / 'gt'
+    os.makedirs(gt_dir)
+    names = ['s%d' % i for i in range(5)]
+    for i, seq in enumerate(names):
+        d = synth.make_in_dict(seed=50 + i, num_frames=40 + 3 * i, num_persons=1, smpl_model=md, with_gt=True)
+        os.makedirs(out_dir / seq / 'pose_est')
+        pickle.dump(d['est'], open(out_dir / seq / 'pose_est' / 'pose.pkl', 'wb'))
+        pickle.dump({'person_data': d['gt'], 'meta': {}}, open(gt_dir / (seq + '.pkl'), 'wb'))
+    base = ['--cfg', 'glamr_static', '--dataset', '', '--seqs'] + names + ['--gt_dir', str(gt_dir), '--seeds', '1', '2', '--stub-model', '--cached', '0']
+    from glamr_amd.global_recon import run_dataset
+    single = run_dataset.main(base + ['--out_dir', str(out_dir)])
+    assert single is not None and 'sequences: s0,s1,s2,s3,s4' in single
+    for seq in names:
+        os.remove(out_dir / seq / 'grecon' / ('%s_seed1.pkl' % seq))
+    r = subprocess.run([sys.executable, '-m', 'glamr_amd.global_recon.run_dataset'] + base + ['--out_dir', str(out_dir), '--gpus', '2'],
+                       env=_plain_env(), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if 'G-MPJPE' in l]
+    assert lines == [single], (r.stdout, single)
+    for seq in names:                                   # written by rank 0 (s0..s2) and rank 1 (s3, s4)
+        assert os.path.exists(out_dir / seq / 'grecon' / ('%s_seed1.pkl' % seq))

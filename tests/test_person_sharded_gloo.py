@@ -44,7 +44,7 @@ def _scene(asset_root, cfg_id, T, P, gap=None):
     return cfg, packing.PackedScenes([data], [jl], torch.device('cpu'))
 
 
-KEYS = ('params', 'cam_pose', 'orient_world', 'trans_world', 'kp_2d_pred', 'orient_cam_in_world')
+KEYS = ('params', 'cam_pose', 'orient_world', 'trans_world', 'kp_2d_pred', 'orient_cam_in_world', 'base_orient', 'base_trans', 'losses')
 
 
 def _fused(asset_root, cfg_id, T, P, gap=None):
@@ -85,12 +85,16 @@ def _compare(ref, got, what, exact=False):
     errs = {'kp': gc.kp_err(got['kp_2d_pred'], ref['kp_2d_pred'])}
     for k in ('params', 'cam_pose', 'trans_world'):
         errs[k] = float(np.abs(got[k] - ref[k]).max())
-    for k in ('orient_world', 'orient_cam_in_world'):
+    for k in ('orient_world', 'orient_cam_in_world', 'base_orient'):
         errs[k] = gc._rot_err(got[k].reshape(-1, 3), ref[k].reshape(-1, 3))
+    # what collect() exports as smpl_orient_world_base / root_trans_world_base and model.last_losses: the base poses of persons
+    # a rank did NOT own are its peers' (not the world poses the frozen slots carried during the loop), the losses are the whole scene's
+    errs['base_trans'] = float(np.abs(got['base_trans'] - ref['base_trans']).max())
+    errs['losses'] = float((np.abs(got['losses'] - ref['losses']) / (np.abs(ref['losses']) + 1e-3)).max())
     print(what, {k: '%.2e' % v for k, v in errs.items()})
-    tol = dict(kp=2e-2, params=1e-3, cam_pose=1e-4, trans_world=1e-3, orient_world=1e-3, orient_cam_in_world=1e-3)
+    tol = dict(kp=2e-2, params=1e-3, cam_pose=1e-4, trans_world=1e-3, orient_world=1e-3, orient_cam_in_world=1e-3, base_orient=1e-3, base_trans=1e-3, losses=2e-3)
     for k, v in errs.items():
-        assert v < (1e-6 if exact else tol[k]), (what, k, v)
+        assert v < (1e-6 if exact else tol[k]), (what, k, v, got[k] if k == 'losses' else None, ref[k] if k == 'losses' else None)
 
 
 # (the per-frame-camera scene has no detection gaps: frames person 0 is not seen in start from ZERO cameras whose 1e9 gradients make the
