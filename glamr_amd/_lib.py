@@ -29,6 +29,10 @@ class SceneBatch(Structure):
                                         'kp_2d_pred', 'orient_cam_in_world', 'frozen', 'g_j_local')]
 
 
+class FilterOpts(Structure):
+    _fields_ = [('filter_pose', c_int32), ('make_invis_with_keypoint', c_int32), ('keypoint_min_score', c_float), ('keypoint_min_num', c_int32)]
+
+
 class RawBatch(Structure):
     _fields_ = [('n_slots', c_int32), ('max_len', c_int32)] + [(n, c_void_p) for n in ('seq_len', 'exist', 'rotmats', 'betas', 'root_trans', 'kp_2d')]
 
@@ -82,7 +86,7 @@ _SIGNATURES = {
     'glamr_traj_local_to_global': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'glamr_host_scatter': (c_int, [c_int, c_void_p, c_int, POINTER(HostStaging), c_void_p, c_void_p, c_int]),
     'glamr_init_workspace_bytes': (c_size_t, [c_int, c_int]),
-    'glamr_init_prepare': (c_int, [POINTER(RawBatch), POINTER(SceneBatch), POINTER(PersonArrays), c_int, c_void_p, c_void_p]),
+    'glamr_init_prepare': (c_int, [POINTER(RawBatch), POINTER(SceneBatch), POINTER(PersonArrays), POINTER(FilterOpts), c_void_p, c_void_p]),
     'glamr_check_inputs': (c_int, [POINTER(RawBatch), c_void_p, c_void_p, c_void_p]),
     'glamr_init_scenes': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays)] + [c_void_p] * 6),
     'glamr_init_cam_all_frames': (c_int, [POINTER(SceneBatch), c_void_p]),

@@ -92,7 +92,7 @@ struct PrepArgs {
   int T;                       // padded frames per slot
   const int32_t* seq_len;      // (slots) frames actually present
   const float* exist; const float* rotmats; const float* betas; const float* root_trans; const float* kp24;
-  int filter_pose;
+  int filter_pose; int kp_filter; float kp_min_score; int kp_min_num;
   // outputs
   float* visible_orig; float* visible; float* pose; float* beta; float* orient_cam; float* trans_cam;
   float* kp26; float* score; float* base_orient; float* base_trans; int32_t* fr_start; int32_t* fr_end;
@@ -194,6 +194,17 @@ __global__ __launch_bounds__(256) void prep_person_kernel(PrepArgs a) {
         }
       }
     __syncthreads();
+    // keypoint-count filter (:264-268): still-visible frames with too few confident keypoints
+    if (a.kp_filter) {
+      for (int t = threadIdx.x; t < n_fr; t += blockDim.x) {
+        if (vis[t] != 1.0f) continue;
+        const float* sc = a.score + (o1 + t) * NJ;
+        int n = 0;
+        for (int j = 0; j < NJ; ++j) n += sc[j] > a.kp_min_score ? 1 : 0;
+        if (n < a.kp_min_num) vis[t] = 0.f;
+      }
+      __syncthreads();
+    }
   }
   if (threadIdx.x == 0) { a.fr_start[slot] = first; a.fr_end[slot] = last + 1; }
   // inputs of the motion priors: existing frames shifted to row 0, pose zeroed outside them (all of [first, last] exists)
@@ -439,14 +450,15 @@ __global__ __launch_bounds__(256) void check_inputs_kernel(int n_slots, int T, c
   if (__any(nonfinite ? 1 : 0) && lane == 0) atomicOr(&verdict[n_slots + slot], 1);
 }
 
-extern "C" int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, int filter_pose,
+extern "C" int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, const glamr_filter_opts* filter,
                                   void* workspace, void* stream_) {
   GLAMR_REQUIRE(raw && batch && pa && workspace, "null argument");
   GLAMR_REQUIRE(raw->n_slots == batch->n_scenes * batch->max_persons && raw->max_len == batch->max_len, "raw batch and scene batch disagree on geometry");
   GLAMR_REQUIRE(raw->seq_len && raw->exist && raw->rotmats && raw->betas && raw->root_trans && raw->kp_2d, "a raw input array is NULL");
   GLAMR_REQUIRE(pa->visible_orig && pa->smpl_pose && pa->smpl_beta && pa->trans_cam && pa->nets_pose && pa->nets_vis, "a person array is NULL");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  PrepArgs a{raw->max_len, raw->seq_len, raw->exist, raw->rotmats, raw->betas, raw->root_trans, raw->kp_2d, filter_pose,
+  PrepArgs a{raw->max_len, raw->seq_len, raw->exist, raw->rotmats, raw->betas, raw->root_trans, raw->kp_2d,
+             filter ? filter->filter_pose : 0, filter ? filter->make_invis_with_keypoint : 0, filter ? filter->keypoint_min_score : 0.f, filter ? filter->keypoint_min_num : 0,
              pa->visible_orig, const_cast<float*>(batch->vis), pa->smpl_pose, pa->smpl_beta, const_cast<float*>(batch->orient_cam), pa->trans_cam,
              const_cast<float*>(batch->kp_2d), const_cast<float*>(batch->kp_score), const_cast<float*>(batch->base_orient),
              const_cast<float*>(batch->base_trans), const_cast<int32_t*>(batch->fr_start), const_cast<int32_t*>(batch->fr_end),

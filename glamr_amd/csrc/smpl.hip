@@ -8,7 +8,14 @@
 //                       in-register regression of the extra joints, picked-vertex capture, optional vertex write-out
 //                       through an LDS transpose (coalesced 384-B rows)
 //   smpl_finish_kernel  reduces the per-tile regression partials, assembles the mapped joints, re-anchors them
-//   smpl_anchor_kernel  (only if vertices are requested with root_trans) verts = (verts - pivot) * scale + trans
+// Calls that want VERTICES run the LBS kernel twice: first over the joints tileset (3 tiles: the picked vertices and the virtual vertices of
+// the extra-regressed joints) -> joints and the re-anchoring pivot (output joint 0, smpl.py:312: for body26fk a REGRESSED joint, i.e. a
+// function of every skinned vertex), then over the full mesh with the regression switched off and verts = (verts - pivot) * scale + trans
+// applied where a vertex tile leaves the accumulators (round 3 re-read and re-wrote all vertices in a separate pass for that, and wrote /
+// re-read 200 MB of per-tile regression partials at B = 19 200).
+// Operands of the fp16-plane instances that come from global memory (feature rows, joint transforms) are stored FRAGMENT-MAJOR by
+// smpl_prep_kernel: [frame tile][plane][k step][lane][8 halves], so a wave's B-operand fetch is one contiguous 1 KB read (row-major rows had
+// every lane of a load in its own cache line: 64 lines per instruction, and the loop waited on each of them) and is issued PF k steps ahead.
 //
 // MFMA tile orientation: rows (A operand) = vertices of the tile, cols (B operand) = frames.  With
 // v_mfma_f32_32x32x2_f32, lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; the reduction index k is
@@ -40,6 +47,21 @@ constexpr int KSH = 232;          // halves per LDS row of one fp16 plane of the
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// fragment-major addresses (in halves) of the fp16 planes the F16 LBS instances fetch from global memory.  Lane l = 32 half + col of a wave
+// working on frame tile ft supplies, at k step m, the 8 consecutive k values  112 half + 8 m ..  (feature rows; 14 steps)  resp.
+// 16 m + 8 half ..  (joint transforms, K = 24 padded to 32; 2 steps) of frame 32 ft + col.
+constexpr int FEAT_STEPS = 14;                        // KH / 8
+constexpr int FEAT_TILE_H = 2 * FEAT_STEPS * 64 * 8;  // halves per frame tile (= 32 frames x 2 planes x KTOT)
+constexpr int ASK_TILE_H = 12 * 2 * 2 * 64 * 8;       // halves per frame tile (= 32 frames x 12 entries x 2 planes x 32)
+__host__ __device__ __forceinline__ size_t feat_h_off(int b, int plane, int k) {
+  const int ft = b >> 5, col = b & 31, half = k / 112, kk = k - half * 112;
+  return (size_t)ft * FEAT_TILE_H + (size_t)(((plane * FEAT_STEPS + (kk >> 3)) * 2 + half) * 32 + col) * 8 + (kk & 7);
+}
+__host__ __device__ __forceinline__ size_t askin_h_off(int b, int e, int plane, int k) {
+  const int ft = b >> 5, col = b & 31;
+  return (size_t)ft * ASK_TILE_H + (size_t)(((((e * 2 + plane) * 2 + (k >> 4)) * 2 + ((k >> 3) & 1)) * 32) + col) * 8 + (k & 7);
+}
 
 }  // namespace glamr
 
@@ -125,7 +147,7 @@ __device__ __forceinline__ void rodrigues_smplx_bwd(const float r[3], const floa
 constexpr int PREP_FRAMES = 8;   // 8 * 24 = 192 active threads of 256
 
 struct PrepArgs {
-  int B, num_betas, n_levels, use_shape;
+  int B, Bpad, num_betas, n_levels, use_shape;      // frames [B, Bpad) are the padding of the last 32-frame tile: their operand rows are written as zeros
   const float* pose;        // (B,72)
   const float* betas;       // (B,num_betas) or null
   const float* j_template;  // (24,3)
@@ -133,9 +155,9 @@ struct PrepArgs {
   const int32_t* parents;
   const int32_t* level;
   float* feat;              // (Bpad, KTOT) or null
-  unsigned short* feat_h;   // (Bpad, 2 planes, KTOT) the same rows as two fp16 planes, or null
+  unsigned short* feat_h;   // the same rows as two fp16 planes, fragment-major (feat_h_off), or null
   float* askin;             // (Bpad, 12, 24) or null
-  unsigned short* askin_h;  // (Bpad, 12, 2 planes, 32) the same transforms as two fp16 planes, K padded to 32 with zeros, or null
+  unsigned short* askin_h;  // the same transforms as two fp16 planes, K padded to 32 with zeros, fragment-major (askin_h_off), or null
   float* chain_joints;      // (B, 24, 3)
 };
 
@@ -147,29 +169,33 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
   const int fl = tid / NJ, j = tid % NJ;
   const int b = blockIdx.x * PREP_FRAMES + fl;
   const bool active = (fl < PREP_FRAMES) && (b < a.B);
+  const bool padding = (fl < PREP_FRAMES) && !active && (b < a.Bpad);      // rows the padded MFMA tiles read: zeros
   float R[9];
   float Jr[3] = {0.f, 0.f, 0.f};
-  if (active) {
-    float r[3] = {a.pose[(size_t)b * 72 + j * 3 + 0], a.pose[(size_t)b * 72 + j * 3 + 1], a.pose[(size_t)b * 72 + j * 3 + 2]};
-    rodrigues_smplx(r, R);
-    for (int c = 0; c < 3; ++c) {
-      float v = a.j_template[j * 3 + c];
-      if (a.use_shape)
-        for (int l = 0; l < a.num_betas; ++l) v = fmaf(a.j_shapedirs[(j * 3 + c) * a.num_betas + l], a.betas[(size_t)b * a.num_betas + l], v);
-      Jr[c] = v;
-      sJ[fl][j][c] = v;
+  if (active || padding) {
+    if (active) {
+      float r[3] = {a.pose[(size_t)b * 72 + j * 3 + 0], a.pose[(size_t)b * 72 + j * 3 + 1], a.pose[(size_t)b * 72 + j * 3 + 2]};
+      rodrigues_smplx(r, R);
+      for (int c = 0; c < 3; ++c) {
+        float v = a.j_template[j * 3 + c];
+        if (a.use_shape)
+          for (int l = 0; l < a.num_betas; ++l) v = fmaf(a.j_shapedirs[(j * 3 + c) * a.num_betas + l], a.betas[(size_t)b * a.num_betas + l], v);
+        Jr[c] = v;
+        sJ[fl][j][c] = v;
+      }
     }
     if (a.feat) {
       float* f = a.feat + (size_t)b * KTOT;
-      _Float16* fh = a.feat_h ? reinterpret_cast<_Float16*>(a.feat_h) + (size_t)b * 2 * KTOT : nullptr;
+      _Float16* fh = reinterpret_cast<_Float16*>(a.feat_h);
       auto put = [&](int k, float v) {
+        if (padding) v = 0.0f;
         f[k] = v;
-        if (fh) { const _Float16 hi = (_Float16)v; fh[k] = hi; fh[KTOT + k] = (_Float16)(v - (float)hi); }
+        if (fh) { const _Float16 hi = (_Float16)v; fh[feat_h_off(b, 0, k)] = hi; fh[feat_h_off(b, 1, k)] = (_Float16)(v - (float)hi); }
       };
       if (j > 0) {
-        for (int e = 0; e < 9; ++e) put(10 + (j - 1) * 9 + e, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
+        for (int e = 0; e < 9; ++e) put(10 + (j - 1) * 9 + e, padding ? 0.0f : R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
       } else {
-        for (int l = 0; l < 10; ++l) put(l, (l < a.num_betas) ? a.betas[(size_t)b * a.num_betas + l] : 0.0f);
+        for (int l = 0; l < 10; ++l) put(l, (!padding && l < a.num_betas) ? a.betas[(size_t)b * a.num_betas + l] : 0.0f);
         put(K_ONE, 1.0f);
         for (int k = K_ONE + 1; k < KTOT; ++k) put(k, 0.0f);
       }
@@ -197,25 +223,26 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
     }
     __syncthreads();
   }
-  if (active) {
+  if (active || padding) {
     const float* G = sG[fl][j];
-    for (int c = 0; c < 3; ++c) a.chain_joints[((size_t)b * NJ + j) * 3 + c] = G[c * 4 + 3];
+    if (active) for (int c = 0; c < 3; ++c) a.chain_joints[((size_t)b * NJ + j) * 3 + c] = G[c * 4 + 3];
     if (a.askin) {
       // relative transform: A = [G_R | G_t - G_R J]
       float* A = a.askin + (size_t)b * 12 * NJ;
-      _Float16* Ah = a.askin_h ? reinterpret_cast<_Float16*>(a.askin_h) + (size_t)b * 12 * 2 * 32 : nullptr;
+      _Float16* Ah = reinterpret_cast<_Float16*>(a.askin_h);
       auto put = [&](int e, float v) {
+        if (padding) v = 0.0f;
         A[e * NJ + j] = v;
         if (Ah) {
           const _Float16 hi = (_Float16)v;
-          Ah[(e * 2 + 0) * 32 + j] = hi;
-          Ah[(e * 2 + 1) * 32 + j] = (_Float16)(v - (float)hi);
-          if (j < 8) { Ah[(e * 2 + 0) * 32 + 24 + j] = (_Float16)0.f; Ah[(e * 2 + 1) * 32 + 24 + j] = (_Float16)0.f; }      // K padding
+          Ah[askin_h_off(b, e, 0, j)] = hi;
+          Ah[askin_h_off(b, e, 1, j)] = (_Float16)(v - (float)hi);
+          if (j < 8) { Ah[askin_h_off(b, e, 0, 24 + j)] = (_Float16)0.f; Ah[askin_h_off(b, e, 1, 24 + j)] = (_Float16)0.f; }      // K padding
         }
       };
       for (int r0 = 0; r0 < 3; ++r0) {
-        for (int c = 0; c < 3; ++c) put(r0 * 4 + c, G[r0 * 4 + c]);
-        put(r0 * 4 + 3, G[r0 * 4 + 3] - (G[r0 * 4 + 0] * Jr[0] + G[r0 * 4 + 1] * Jr[1] + G[r0 * 4 + 2] * Jr[2]));
+        for (int c = 0; c < 3; ++c) put(r0 * 4 + c, padding ? 0.0f : G[r0 * 4 + c]);
+        put(r0 * 4 + 3, padding ? 0.0f : G[r0 * 4 + 3] - (G[r0 * 4 + 0] * Jr[0] + G[r0 * 4 + 1] * Jr[1] + G[r0 * 4 + 2] * Jr[2]));
       }
     }
   }
@@ -241,6 +268,11 @@ struct LbsArgs {
   float* picked;            // (B, n_picked, 3)
   float* partial;           // (n_tiles, Bpad, n_extra_used, 3)
   int Bpad;
+  // re-anchoring of the vertices where they leave the accumulators (smpl.py:309-315): v = (v - pivot) * scale + trans; pivot null = none
+  const float* pivot;       // (B,3) un-anchored output joint 0, from the joints pass
+  const float* root_trans;  // (B,3)
+  const float* root_scale;  // (B) or null
+  int skip_picks;           // the joints pass already captured the picked vertices
 };
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -316,29 +348,44 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
     const float* frow = a.feat + (size_t)b * KTOT + half * KH;
     f32x16 px = {0}, py = {0}, pz = {0};
     if (F16) {
-      // lane half h supplies k = 112 h + 8 m .. + 7 to k step m, on both operands alike
+      // lane half h supplies k = 112 h + 8 m .. + 7 to k step m, on both operands alike.  The feature planes are fragment-major: the
+      // fetch of (plane, step) is ONE contiguous 1 KB read per wave, requested PF steps before its MFMAs
       const unsigned short* myH = reinterpret_cast<const unsigned short*>(sDirs) + (size_t)col * KSH + half * KH;
-      const unsigned short* fh = a.feat_h + (size_t)b * 2 * KTOT + half * KH;
-#pragma unroll 2
-      for (int m = 0; m < KH / 8; ++m) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(fh + 8 * m));
-        const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(fh + KTOT + 8 * m));
-        f16x8 ah[3], al[3];
+      const uint4* fq = reinterpret_cast<const uint4*>(a.feat_h) + (size_t)ft * (FEAT_TILE_H / 8) + lane;
+      constexpr int PF = 3, RING = PF + 1;
+      uint4 qh[RING], ql[RING];
+      uint4 ah[2][3], al[2][3];          // direction fragments (LDS), one k step ahead as well
+      auto lds_frag = [&](int m, int buf) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          ah[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(myH + (size_t)(c * 2 + 0) * TILE_V * KSH + 8 * m));
-          al[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(myH + (size_t)(c * 2 + 1) * TILE_V * KSH + 8 * m));
+          ah[buf][c] = *reinterpret_cast<const uint4*>(myH + (size_t)(c * 2 + 0) * TILE_V * KSH + 8 * m);
+          al[buf][c] = *reinterpret_cast<const uint4*>(myH + (size_t)(c * 2 + 1) * TILE_V * KSH + 8 * m);
         }
+      };
+#pragma unroll
+      for (int m = 0; m < PF; ++m) { qh[m] = fq[(0 * FEAT_STEPS + m) * 64]; ql[m] = fq[(1 * FEAT_STEPS + m) * 64]; }
+      lds_frag(0, 0);
+#pragma unroll
+      for (int m = 0; m < FEAT_STEPS; ++m) {
+        if (m + PF < FEAT_STEPS) {
+          qh[(m + PF) % RING] = fq[(0 * FEAT_STEPS + m + PF) * 64];
+          ql[(m + PF) % RING] = fq[(1 * FEAT_STEPS + m + PF) * 64];
+        }
+        if (m + 1 < FEAT_STEPS) lds_frag(m + 1, (m + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);            // (left alone the scheduler sinks the loads to just before their use)
+        const f16x8 bh = __builtin_bit_cast(f16x8, qh[m % RING]);
+        const f16x8 bl = __builtin_bit_cast(f16x8, ql[m % RING]);
+        const int cur = m & 1;
         // small products first; consecutive MFMAs go to different accumulators
-        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh, px, 0, 0, 0);
-        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh, py, 0, 0, 0);
-        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[2], bh, pz, 0, 0, 0);
-        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl, px, 0, 0, 0);
-        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl, py, 0, 0, 0);
-        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2], bl, pz, 0, 0, 0);
-        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh, px, 0, 0, 0);
-        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh, py, 0, 0, 0);
-        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2], bh, pz, 0, 0, 0);
+        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[cur][0]), bh, px, 0, 0, 0);
+        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[cur][1]), bh, py, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[cur][2]), bh, pz, 0, 0, 0);
+        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[cur][0]), bl, px, 0, 0, 0);
+        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[cur][1]), bl, py, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[cur][2]), bl, pz, 0, 0, 0);
+        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[cur][0]), bh, px, 0, 0, 0);
+        py = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[cur][1]), bh, py, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[cur][2]), bh, pz, 0, 0, 0);
       }
     } else
 #pragma unroll 2
@@ -361,23 +408,27 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
     for (int r = 0; r < 3; ++r) {
       f32x16 T[4];
       if (F16) {
-        const unsigned short* ah = a.askin_h + (size_t)b * 12 * 2 * 32 + 8 * half;
+        // joint transforms, fragment-major: entry e = 4 r + c, (plane, k step m) -> one contiguous 1 KB read per wave; all 16 fetches of
+        // this output row are requested before its first MFMA
+        const uint4* aq = reinterpret_cast<const uint4*>(a.askin_h) + (size_t)ft * (ASK_TILE_H / 8) + lane;
+        uint4 qa[4][2][2];      // [c][plane][m]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) qa[c][pl][m] = aq[((((r * 4 + c) * 2 + pl) * 2 + m)) * 64];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) T[c] = (f32x16){0};
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          f16x8 bh[4], bl[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            bh[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ah + ((r * 4 + c) * 2 + 0) * 32 + 16 * m));
-            bl[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ah + ((r * 4 + c) * 2 + 1) * 32 + 16 * m));
-          }
+          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[m], __builtin_bit_cast(f16x8, qa[c][0][m]), T[c], 0, 0, 0);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[m], bh[c], T[c], 0, 0, 0);
+          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[c][1][m]), T[c], 0, 0, 0);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], bl[c], T[c], 0, 0, 0);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], bh[c], T[c], 0, 0, 0);
+          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[c][0][m]), T[c], 0, 0, 0);
         }
       } else
 #pragma unroll
@@ -396,6 +447,15 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
       out[r] = T[0] * px + T[1] * py + T[2] * pz + T[3];
     }
     const bool frame_ok = b < a.B;
+    if (a.pivot && frame_ok) {      // re-anchor on output joint 0 (lane = frame: three pivots, three translations, one scale per lane)
+      const float sc = a.root_scale ? a.root_scale[b] : 1.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float pv = a.pivot[(size_t)b * 3 + r], tr = a.root_trans[(size_t)b * 3 + r];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[r][q] = (out[r][q] - pv) * sc + tr;
+      }
+    }
     // extra-joint regression partial sums: sum over this tile's 32 vertices (16 rows here + 16 in the other half)
     if (NE > 0) {
 #pragma unroll
@@ -411,7 +471,8 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
       }
     }
     // picked vertices of this tile (rare: 21 picks over 216 tiles)
-    for (int p = a.tile_pick_start[tile]; p < a.tile_pick_start[tile + 1]; ++p) {
+    const int pick0 = a.skip_picks ? 0 : a.tile_pick_start[tile], pick1 = a.skip_picks ? 0 : a.tile_pick_start[tile + 1];
+    for (int p = pick0; p < pick1; ++p) {
       const int slot = a.tile_pick_ids[p];
       const int row = a.pick_row[slot];
       if (frame_ok) {
@@ -1014,7 +1075,8 @@ SmplWs smpl_ws_layout(const glamr_smpl* h, int B, char* base) {
   w.askin_h = take((size_t)w.Bpad * 12 * 32);     // two fp16 planes, K padded to 32
   w.chain = take((size_t)w.Bpad * NJ * 3);
   w.picked = take((size_t)w.Bpad * std::max(1, h->n_picked) * 3);
-  w.partial = take((size_t)h->full.n_tiles * w.Bpad * std::max(1, h->n_extra_used) * 3);
+  // regression partials of the pass that produces the joints: the 3-tile joints tileset when it exists, else the full mesh
+  w.partial = take((size_t)(h->joints.n_tiles > 0 ? h->joints.n_tiles : h->full.n_tiles) * w.Bpad * std::max(1, h->n_extra_used) * 3);
   w.pivot = take((size_t)w.Bpad * 3);
   w.total = off;
   return w;
@@ -1032,58 +1094,63 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   GLAMR_REQUIRE(B > 0, "B must be positive");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SmplWs w = smpl_ws_layout(h, B, static_cast<char*>(workspace));
-  // rows [B, Bpad) of feat/askin are read by the padded MFMA tiles: keep them finite
-  if (w.Bpad > B) {
-    GLAMR_HIP_CHECK(hipMemsetAsync(w.feat + (size_t)B * KTOT, 0, (size_t)(w.Bpad - B) * KTOT * sizeof(float), stream));
-    GLAMR_HIP_CHECK(hipMemsetAsync(w.feat_h + (size_t)B * KTOT, 0, (size_t)(w.Bpad - B) * KTOT * sizeof(float), stream));
-    GLAMR_HIP_CHECK(hipMemsetAsync(w.askin + (size_t)B * 12 * NJ, 0, (size_t)(w.Bpad - B) * 12 * NJ * sizeof(float), stream));
-    GLAMR_HIP_CHECK(hipMemsetAsync(w.askin_h + (size_t)B * 12 * 32, 0, (size_t)(w.Bpad - B) * 12 * 32 * sizeof(float), stream));
-  }
   const bool orig = (flags & GLAMR_SMPL_ORIG_JOINTS) != 0;
-  const glamr_tileset& ts = (!verts && h->joints.n_tiles > 0) ? h->joints : h->full;
   // blend shapes and skinning transforms on the fp16 matrix cores (two-plane operands: fp32-grade products); GLAMR_SMPL_FP32_BLEND=1
   // selects the fp32-MFMA instances (and then the planes of the feature rows / joint transforms are not written)
-  const bool planes = std::getenv("GLAMR_SMPL_FP32_BLEND") == nullptr && ts.dirs_h != nullptr;
-  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat,
+  const bool planes = std::getenv("GLAMR_SMPL_FP32_BLEND") == nullptr && h->full.dirs_h != nullptr && (h->joints.n_tiles == 0 || h->joints.dirs_h != nullptr);
+  // (rows [B, Bpad) of the operand arrays, read by the padded MFMA tiles, are written as zeros by the prep kernel)
+  PrepArgs pa{B, w.Bpad, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat,
               planes ? reinterpret_cast<unsigned short*>(w.feat_h) : nullptr, w.askin, planes ? reinterpret_cast<unsigned short*>(w.askin_h) : nullptr, w.chain};
-  hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((w.Bpad + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   const int n_ftiles = w.Bpad / TILE_F;
-  LbsArgs la{B, h->V, ts.n_tiles, n_ftiles, h->n_extra_used, h->n_picked, ts.dirs_tiled, ts.w_tiled, ts.jx_used,
-             ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, ts.dirs_h, reinterpret_cast<const unsigned short*>(w.feat_h), reinterpret_cast<const unsigned short*>(w.askin_h), w.askin, verts,
-             w.picked, w.partial, w.Bpad};
   const bool f16 = planes;
-  const size_t dirs_bytes = f16 ? (size_t)3 * 2 * TILE_V * KSH * sizeof(unsigned short) : (size_t)3 * TILE_V * KSTRIDE * sizeof(float);
   const int nw = f16 ? 8 : 4;
-  const size_t lds = dirs_bytes + (verts ? (size_t)nw * (f16 ? TILE_F / 2 : TILE_F) * OUT_STRIDE * sizeof(float) : 0);
-  // frame tiles are split over gridDim.y so that a launch has ~4 workgroups per CU even with few vertex tiles; every workgroup
-  // re-stages its 87 KB direction tile, so a chunk keeps >= 8 frame tiles per wave
-  int gy = std::max(1, std::min((1024 + ts.n_tiles - 1) / ts.n_tiles, n_ftiles / 32));
-  auto launch = [&](auto kern) -> int {
-    {      // once per instance and process: the largest arena an instance can ask for (direction tile + eight half-tile transposes)
-      static std::mutex amu;
-      static std::set<const void*> raised;
-      std::lock_guard<std::mutex> lock(amu);
-      if (raised.insert(reinterpret_cast<const void*>(kern)).second)
-        GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  const size_t dirs_bytes = f16 ? (size_t)3 * 2 * TILE_V * KSH * sizeof(unsigned short) : (size_t)3 * TILE_V * KSTRIDE * sizeof(float);
+  // one pass of the LBS kernel over a tileset: `ne` regressed joints accumulated (0: none), vertices written when `vout`, re-anchored when `pivot`
+  auto lbs_pass = [&](const glamr_tileset& ts, int ne, float* vout, const float* pivot, bool skip_picks) -> int {
+    LbsArgs la{B, h->V, ts.n_tiles, n_ftiles, ne, h->n_picked, ts.dirs_tiled, ts.w_tiled, ts.jx_used,
+               ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, ts.dirs_h, reinterpret_cast<const unsigned short*>(w.feat_h),
+               reinterpret_cast<const unsigned short*>(w.askin_h), w.askin, vout, w.picked, w.partial, w.Bpad,
+               pivot, root_trans, root_scale, skip_picks ? 1 : 0};
+    const size_t lds = dirs_bytes + (vout ? (size_t)nw * (f16 ? TILE_F / 2 : TILE_F) * OUT_STRIDE * sizeof(float) : 0);
+    // frame tiles are split over gridDim.y so that a launch has ~4 workgroups per CU even with few vertex tiles; every workgroup
+    // re-stages its 87 KB direction tile, so a chunk keeps >= 8 frame tiles per wave
+    const int gy = std::max(1, std::min((1024 + ts.n_tiles - 1) / ts.n_tiles, n_ftiles / 32));
+    auto launch = [&](auto kern) -> int {
+      {      // once per instance and process: the largest arena an instance can ask for (direction tile + eight half-tile transposes)
+        static std::mutex amu;
+        static std::set<const void*> raised;
+        std::lock_guard<std::mutex> lock(amu);
+        if (raised.insert(reinterpret_cast<const void*>(kern)).second)
+          GLAMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      }
+      hipLaunchKernelGGL(kern, dim3(ts.n_tiles, gy), dim3(nw * 64), lds, stream, la);
+      return GLAMR_OK;
+    };
+    switch (ne) {
+      case 0: return f16 ? launch(smpl_lbs_kernel<0, true>) : launch(smpl_lbs_kernel<0>);
+      case 1: return f16 ? launch(smpl_lbs_kernel<1, true>) : launch(smpl_lbs_kernel<1>);
+      case 2: return f16 ? launch(smpl_lbs_kernel<2, true>) : launch(smpl_lbs_kernel<2>);
+      case 3: return f16 ? launch(smpl_lbs_kernel<3, true>) : launch(smpl_lbs_kernel<3>);
+      case 4: return f16 ? launch(smpl_lbs_kernel<4, true>) : launch(smpl_lbs_kernel<4>);
+      default: return fail(GLAMR_E_UNSUPPORTED, "joint_map references %d extra-regressed joints (max 4 supported)", ne);
     }
-    hipLaunchKernelGGL(kern, dim3(ts.n_tiles, gy), dim3(nw * 64), lds, stream, la);
-    return GLAMR_OK;
   };
   int rc = GLAMR_OK;
-  if (verts || !orig) switch (h->n_extra_used) {
-    case 0: rc = f16 ? launch(smpl_lbs_kernel<0, true>) : launch(smpl_lbs_kernel<0>); break;
-    case 1: rc = f16 ? launch(smpl_lbs_kernel<1, true>) : launch(smpl_lbs_kernel<1>); break;
-    case 2: rc = f16 ? launch(smpl_lbs_kernel<2, true>) : launch(smpl_lbs_kernel<2>); break;
-    case 3: rc = f16 ? launch(smpl_lbs_kernel<3, true>) : launch(smpl_lbs_kernel<3>); break;
-    case 4: rc = f16 ? launch(smpl_lbs_kernel<4, true>) : launch(smpl_lbs_kernel<4>); break;
-    default: return fail(GLAMR_E_UNSUPPORTED, "joint_map references %d extra-regressed joints (max 4 supported)", h->n_extra_used);
-  }
-  if (rc) return rc;
-  FinishArgs fa{B, w.Bpad, (verts || !orig) ? ts.n_tiles : 0, h->n_extra_used, h->n_picked, h->n_out, orig ? 1 : 0,
+  // joints: the picked vertices and the virtual vertices of the regressed joints (3 tiles) when that tileset exists, else the full mesh
+  const bool two_pass = verts && h->joints.n_tiles > 0;
+  const glamr_tileset& jts = h->joints.n_tiles > 0 ? h->joints : h->full;
+  const bool need_tiles = !orig || (verts && !two_pass);      // (orig_joints: chain joints only, nothing to regress or pick)
+  if (need_tiles && (rc = lbs_pass(jts, h->n_extra_used, two_pass ? nullptr : verts, nullptr, false))) return rc;
+  FinishArgs fa{B, w.Bpad, (need_tiles && !orig) ? jts.n_tiles : 0, h->n_extra_used, h->n_picked, h->n_out, orig ? 1 : 0,
                 w.chain, w.picked, w.partial, h->joint_map, h->extra_slot, root_trans, root_scale, joints, w.pivot};
   hipLaunchKernelGGL(smpl_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, fa);
-  if (verts && root_trans)
+  if (two_pass) {
+    // the full mesh: no regression, no picks, vertices re-anchored on the pivot the finish kernel just wrote
+    if ((rc = lbs_pass(h->full, 0, verts, root_trans ? w.pivot : nullptr, true))) return rc;
+  } else if (verts && root_trans) {
     hipLaunchKernelGGL(smpl_anchor_kernel, dim3(8, B), dim3(256), 0, stream, B, h->V, w.pivot, root_trans, root_scale, verts);
+  }
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }
@@ -1093,7 +1160,7 @@ extern "C" int glamr_smpl_fk(glamr_smpl* h, int B, const float* pose, const floa
   GLAMR_REQUIRE(h && pose && joints, "null argument");
   GLAMR_REQUIRE(B > 0, "B must be positive");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  PrepArgs pa{B, h->num_betas, h->n_levels, 0, pose, nullptr, h->j_template, h->j_shapedirs, h->parents, h->level, nullptr, nullptr, nullptr, nullptr, joints};
+  PrepArgs pa{B, B, h->num_betas, h->n_levels, 0, pose, nullptr, h->j_template, h->j_shapedirs, h->parents, h->level, nullptr, nullptr, nullptr, nullptr, joints};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   if (root_trans) hipLaunchKernelGGL(smpl_fk_anchor_kernel, dim3(B), dim3(NJ), 0, stream, B, root_trans, root_scale, joints);
   GLAMR_HIP_CHECK(hipGetLastError());
@@ -1152,7 +1219,7 @@ extern "C" int glamr_smpl_backward(glamr_smpl* h, int B, const float* pose, cons
   const int with_verts = g_verts != nullptr;
   SmplBwdWs w = smpl_bwd_ws_layout(h, B, with_verts, static_cast<char*>(workspace));
   const glamr_tileset& ts = (!with_verts && h->joints.n_tiles > 0) ? h->joints : h->full;
-  PrepArgs pa{B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, nullptr, w.askin, nullptr, w.chain};
+  PrepArgs pa{B, B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, nullptr, w.askin, nullptr, w.chain};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   BwdGenArgs a{B, w.Bpad, h->V, ts.Vpad, ts.n_tiles, h->n_extra_used, h->n_picked, h->n_out, orig ? 1 : 0, h->num_betas,
                pose, betas, root_trans, root_scale, verts, joints, g_verts, g_joints, h->joint_map, h->extra_slot, h->parents,

@@ -201,7 +201,7 @@ class GlobalReconOptimizer:
             raise NotImplementedError('only est_type=hybrik with motion infilling + trajectory prediction + trajectory optimisation '
                                       '(every shipped config) is supported')
         for flag in ('flag_opt_vis_local_rot', 'flag_opt_person2cam_rot',
-                     'flag_opt_person2cam_trans', 'flag_make_invis_with_keypoint', 'flag_traj_from_cam', 'flag_use_pen_loss', 'absolute_heading'):
+                     'flag_opt_person2cam_trans', 'flag_traj_from_cam', 'flag_use_pen_loss', 'absolute_heading'):
             if g(flag, False):
                 raise NotImplementedError('%s is not supported by the MI355X path' % flag)
         if g('heading_type', 'scalar') != 'scalar' or not g('flag_cam_inv_trans_res_all', True) or not g('flag_opt_cam', True):
@@ -210,6 +210,11 @@ class GlobalReconOptimizer:
         self.flag_opt_motion_latent = bool(g('flag_opt_motion_latent', False))
         self.flag_opt_traj_latent = bool(g('flag_opt_traj_latent', False))
         self.flag_filter_pose = g('flag_filter_pose', True)
+        # keypoint-count filter inside filter_pose (:50-52,264-268); with HybrIK's binary scores (14 scored joints per detected frame) it is all or
+        # nothing: the reference's default minimum of 15 removes every frame, 14 or less none
+        self.flag_make_invis_with_keypoint = bool(g('flag_make_invis_with_keypoint', False))
+        self.make_invis_keypoint_min_score = float(g('make_invis_keypoint_min_score', 0.6))
+        self.make_invis_keypoint_min_num = int(g('make_invis_keypoint_min_num', 15))
         self.flag_init_cam_all_frames = g('flag_init_cam_all_frames', False)
         self.cam_fix_frames = [tuple(x) for x in g('cam_fix_frames', [[0, None]])]
         self.smpl = smpl if smpl is not None else SMPL(SMPL_MODEL_DIR, pose_type='body26fk', create_transl=False).to(self.device)
@@ -258,6 +263,10 @@ class GlobalReconOptimizer:
             d[key] = np.ascontiguousarray(d[key], dtype=np.float32)
         if self.flag_filter_pose:
             self._filter_pose(d)
+            if getattr(self, 'flag_make_invis_with_keypoint', False):                    # :264-268
+                vis_ind = np.where(d['visible'] == 1.0)[0]
+                num_valid = (d['kp_2d_score'][vis_ind] > self.make_invis_keypoint_min_score).sum(axis=1)
+                d['visible'][vis_ind[num_valid < self.make_invis_keypoint_min_num]] = 0.0
         d['vis_frames'] = d['visible'] == 1
         d['invis_frames'] = d['visible'] == 0
         # identity initial camera: world := camera frame (:141-144)
@@ -269,7 +278,7 @@ class GlobalReconOptimizer:
 
     @staticmethod
     def _filter_pose(d):
-        """:250-271 -- sequential and data dependent, stays on the host."""
+        """:250-262, the numpy twin of the loop in csrc/init.hip prep_person_kernel (sequential and data dependent: one thread there)."""
         visible = d['visible']
         quat = nt.aa_to_quat(d['smpl_orient_cam'])
         jump = nt.quat_angle_between(quat[1:], quat[:-1])
@@ -580,6 +589,39 @@ class GlobalReconOptimizer:
                 si, pi = divmod(int(bad[0]), rin.P)
                 raise wire.WireFormatError('sequence %d (%s), person %r: %s' % (si, rin.meta[si]['seq_name'], rin.ids[si][pi] if pi < len(rin.ids[si]) else pi, msg))
 
+    def _init_prepare(self, rin, packed, pa_t):
+        """glamr_init_prepare on the staged batch: visibility bookkeeping, rotation matrices -> axis-angle, interpolation over detection gaps,
+        filter_pose (:88-148,250-271).  Returns the structures the following launches share."""
+        import ctypes
+        L, g, n_slots, T = _lib.lib(), rin.g, rin.S * rin.P, rin.T
+        raw = _lib.RawBatch()
+        raw.n_slots, raw.max_len = n_slots, T
+        for name, ten in (('seq_len', rin.seq_len_slot), ('exist', g['exist']), ('rotmats', g['rot']), ('betas', g['betas']), ('root_trans', g['trans']), ('kp_2d', g['kp'])):
+            setattr(raw, name, ctypes.c_void_p(ten.data_ptr()))
+        pa = _lib.PersonArrays()
+        for name, ten in pa_t.items():
+            setattr(pa, name, ctypes.c_void_p(ten.data_ptr()))
+        sb = packed.struct()
+        ws = torch.empty(L.glamr_init_workspace_bytes(n_slots, T), dtype=torch.uint8, device=self.device)
+        st = _lib.current_stream()
+        fo = _lib.FilterOpts(int(bool(self.flag_filter_pose)), int(self.flag_make_invis_with_keypoint), self.make_invis_keypoint_min_score, self.make_invis_keypoint_min_num)
+        _lib.check(L.glamr_init_prepare(ctypes.byref(raw), ctypes.byref(sb), ctypes.byref(pa), ctypes.byref(fo), _lib.ptr(ws), st))
+        return pa, sb, ws, st
+
+    def prepare_only(self, in_dicts):
+        """The per-person preparation alone (no priors, no scene): `visible` after filter_pose, (person slots, frames) float32 on the host.
+        For inspecting what the filters of :250-271 do to a batch (a batch they leave without a visible frame cannot be reconstructed)."""
+        rin = self.stage_inputs(in_dicts)
+        n_slots, T, dev = rin.S * rin.P, rin.T, self.device
+        packed = packing.PackedScenes.empty(rin.S, rin.P, T, dev)
+        packed.t['cam_K'], packed.t['n_persons'], packed.t['seq_len'] = rin.g['K'], rin.n_persons, rin.seq_len
+        packed.t['j_local'] = torch.zeros(1, dtype=torch.float32, device=dev)
+        pa_t = packing.carve_zeros([('visible_orig', torch.float32, (n_slots, T)), ('smpl_pose', torch.float32, (n_slots, T, 69)), ('smpl_beta', torch.float32, (n_slots, T, 10)),
+                                    ('trans_cam', torch.float32, (n_slots, T, 3)), ('nets_pose', torch.float32, (n_slots, T, 69)), ('nets_vis', torch.float32, (n_slots, T))], dev)
+        self._init_prepare(rin, packed, pa_t)
+        torch.cuda.synchronize(dev)
+        return packed.t['vis'].view(n_slots, T).cpu().numpy()
+
     def init_resident(self, rin, init_forward=True):
         """init_data (:76-248) on device-resident inputs: per-person preparation, motion priors, scene assembly, cached joints and
         the 'init' forward pass -- kernel launches only, nothing crosses PCIe.  Returns (datas, packed): `datas` are light
@@ -609,17 +651,7 @@ class GlobalReconOptimizer:
         pa_t['nets_vis'] = rs['nets_vis'] if rs else f32(n_slots, T)
         # the cached joints are produced in place by the skinning kernel: keep a placeholder until then
         packed.t['j_local'] = f32(1)
-        raw = _lib.RawBatch()
-        raw.n_slots, raw.max_len = n_slots, T
-        for name, ten in (('seq_len', rin.seq_len_slot), ('exist', g['exist']), ('rotmats', g['rot']), ('betas', g['betas']), ('root_trans', g['trans']), ('kp_2d', g['kp'])):
-            setattr(raw, name, ctypes.c_void_p(ten.data_ptr()))
-        pa = _lib.PersonArrays()
-        for name, ten in pa_t.items():
-            setattr(pa, name, ctypes.c_void_p(ten.data_ptr()))
-        sb = packed.struct()
-        ws = torch.empty(L.glamr_init_workspace_bytes(n_slots, T), dtype=torch.uint8, device=dev)
-        st = _lib.current_stream()
-        _lib.check(L.glamr_init_prepare(ctypes.byref(raw), ctypes.byref(sb), ctypes.byref(pa), int(self.flag_filter_pose), _lib.ptr(ws), st))
+        pa, sb, ws, st = self._init_prepare(rin, packed, pa_t)
         # motion priors on every person of every sequence in one call
         if rs:
             meps, teps = rs['meps'], rs['teps']

@@ -287,3 +287,35 @@ def make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=None, dynamic
         }
     return {'est': est, 'gt': gt, 'gt_meta': dict(),
             'seq_name': seq_name or 'synth_s%d_T%d_P%d' % (seed, T, num_persons)}
+
+
+def inject_orient_jumps(in_dict, idx, events):
+    """Root-orientation discontinuities in person `idx`'s HybrIK rotations -- what `filter_pose` (global_recon_model.py:250-262) exists for
+    (a pose estimator flipping a person by ~180 degrees for a few frames).  `events`, applied in order, frames are VIDEO frames that must be
+    detected:
+      ('spike', frame, angle, n)   frames [frame, frame + n) are turned by `angle` about the body's own up axis (right-multiplied): two
+                                   discontinuities, at `frame` and at `frame + n`;
+      ('step', frame, angle)       the root rotation of `frame` becomes EXACTLY that of `frame - 1` (the previous DETECTED frame's) turned by
+                                   `angle` about a fixed oblique axis, and every later frame carries the same left factor along (no second
+                                   discontinuity): the quaternion angle between the two frames is `angle` to float32 rounding -- for
+                                   thresholds at pi / 3 +- 1e-4."""
+    src = in_dict['est'][idx]
+    rot = src['smpl_pose_quat_wroot'].reshape(src['smpl_pose_quat_wroot'].shape[0], -1, 3, 3).astype(np.float64)
+    f2i = src['frame2ind']
+    for ev in events:
+        if ev[0] == 'spike':
+            _, frame, angle, n = ev
+            D = _rodrigues(np.array([[0.0, angle, 0.0]]))[0]
+            for f in range(frame, frame + n):
+                rot[f2i[f], 0] = rot[f2i[f], 0] @ D
+        elif ev[0] == 'step':
+            _, frame, angle = ev
+            i = f2i[frame]
+            axis = np.array([0.36, 0.8, 0.48])
+            target = rot[i - 1, 0] @ _rodrigues((axis * angle)[None])[0]
+            L = target @ rot[i, 0].T
+            rot[i:, 0] = L[None] @ rot[i:, 0]
+        else:
+            raise KeyError(ev[0])
+    src['smpl_pose_quat_wroot'] = rot.reshape(rot.shape[0], -1, 4).astype(np.float32)
+    return in_dict

@@ -382,7 +382,17 @@ size_t glamr_init_workspace_bytes(int n_slots, int max_len);
  * 3 x 3 matrices, demo.py:320).  One pass over the arrays.  dev out: verdict (2, n_slots) int32: [0][slot] != 0 = a matrix that is no
  * rotation, [1][slot] != 0 = a non-finite value.  cam_K: dev (n_slots, max_len, 9). */
 int glamr_check_inputs(const glamr_raw_batch* raw, const float* cam_K, int32_t* verdict, void* stream);
-int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, int filter_pose,
+/* `filter`: filter_pose (global_recon_model.py:250-271).  filter_pose != 0: a visible frame whose root orientation jumps by more than pi/3
+ * from its predecessor makes itself or the predecessor invisible (the look-ahead rule :256-262, sequential); make_invis_with_keypoint != 0
+ * (flag_make_invis_with_keypoint :264-268, applied inside filter_pose like the reference): a still-visible frame with fewer than
+ * keypoint_min_num scores above keypoint_min_score becomes invisible (defaults of the reference: 0.6 / 15).  NULL = no filtering. */
+typedef struct glamr_filter_opts {
+  int32_t filter_pose;
+  int32_t make_invis_with_keypoint;
+  float keypoint_min_score;
+  int32_t keypoint_min_num;
+} glamr_filter_opts;
+int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batch, const glamr_person_arrays* pa, const glamr_filter_opts* filter,
                        void* workspace, void* stream);
 /* After glamr_nets_infer: scatters its outputs, fills traj_local_pred, person2cam, rel_transform_cam, cam_pose of `batch`. */
 int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,

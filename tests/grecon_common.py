@@ -184,11 +184,20 @@ KSTEP_TOL = {   # achieved (MI355X / CPU runtime):           kp px            ro
 
 def full_schedule_errors(out_persons, cam_pose, g, P, prefix=''):
     """Differences between a finished optimisation and a full-schedule reference fixture (oracle/make_golden.py gen_full_cfg), over the
-    frames each person is seen in: (projected keypoints px, root-in-camera m, world root m, world orientation as a rotation, camera)."""
+    frames each person is seen in: projected keypoints px, root-in-camera m, world root m, world orientation as a rotation, and the camera --
+    `cam_rot` / `cam_trans` value by value (world -> camera matrices of the frames the first person is seen in) and, free of the world frame's
+    gauge, `orient_cam`: the person's orientation SEEN FROM the camera, R_cam R(smpl_orient_world), as a rotation."""
+    from oracle.port import transforms as tf
+    def seen_from_cam(cam, aa):
+        R = tf.aa_to_rotmat(torch.as_tensor(np.asarray(aa), dtype=torch.float32)).numpy()
+        return np.einsum('tij,tjk->tik', np.asarray(cam)[:, :3, :3], R)
     def root_cam(cam, trans):
         return np.einsum('tij,tj->ti', cam[:, :3, :3], trans) + cam[:, :3, 3]
     cam_ref = g[prefix + 'cam_pose']
-    worst = dict(kp=0.0, root_cam=0.0, root_world=0.0, orient=0.0, frames_over_1px=0)
+    worst = dict(kp=0.0, root_cam=0.0, root_world=0.0, orient=0.0, frames_over_1px=0, orient_cam=0.0, cam_rot=0.0, cam_trans=0.0)
+    seen0 = g['%sp0_vis_frames' % prefix]
+    worst['cam_rot'] = float(np.abs(np.asarray(cam_pose)[seen0][:, :3, :3] - cam_ref[seen0][:, :3, :3]).max())
+    worst['cam_trans'] = float(np.abs(np.asarray(cam_pose)[seen0][:, :3, 3] - cam_ref[seen0][:, :3, 3]).max())
     for pi in range(P):
         pd = out_persons[pi]
         vis = g['%sp%d_vis_frames' % (prefix, pi)]
@@ -201,6 +210,9 @@ def full_schedule_errors(out_persons, cam_pose, g, P, prefix=''):
         worst['root_world'] = max(worst['root_world'], float(np.abs(tr - tr_ref)[vis].max()))
         worst['root_cam'] = max(worst['root_cam'], float(np.abs(root_cam(np.asarray(cam_pose), tr) - root_cam(cam_ref, tr_ref))[vis].max()))
         worst['orient'] = max(worst['orient'], _rot_err(np.asarray(pd['smpl_orient_world'])[vis], g['%sp%d_smpl_orient_world' % (prefix, pi)][vis]))
+        both = vis & seen0 if cam_ref.shape[0] == vis.shape[0] else vis
+        oc = seen_from_cam(cam_pose, pd['smpl_orient_world']) - seen_from_cam(cam_ref, g['%sp%d_smpl_orient_world' % (prefix, pi)])
+        worst['orient_cam'] = max(worst['orient_cam'], float(np.abs(oc[both]).max()))
     return worst
 
 

@@ -99,8 +99,12 @@ def _full_schedule(make_model, golden, tag, gap, host_init=False):
     obs = in_dict['est'][0]['kp_2d'][:, :24, :2]
     def reproj(kp):
         return float(np.linalg.norm(kp[vis][:, :24] - obs, axis=-1).mean())
-    print('full schedule%s: kp max %.3f px (median over frames %.3f), root-in-camera %.2e m, reprojection %.3f vs reference %.3f px'
-          % (tag, d_kp.max(), np.median(d_kp), e_root, reproj(pd['kp_2d_pred']), reproj(g['p0_kp_2d_pred'])))
+    from tests.grecon_common import full_schedule_errors
+    w = full_schedule_errors(out['person_data'], out['cam_pose'], g, 1)
+    print('full schedule%s: kp max %.3f px (median over frames %.3f), root-in-camera %.2e m, world root %.2e m, orientation %.2e, seen from the camera %.2e, '
+          'cam_pose rotation %.2e translation %.2e m, reprojection %.3f vs reference %.3f px'
+          % (tag, d_kp.max(), np.median(d_kp), e_root, w['root_world'], w['orient'], w['orient_cam'], w['cam_rot'], w['cam_trans'], reproj(pd['kp_2d_pred']), reproj(g['p0_kp_2d_pred'])))
+    _full_schedule.last = w
     return d_kp, e_root, reproj(pd['kp_2d_pred']), reproj(g['p0_kp_2d_pred'])
 
 
@@ -109,6 +113,8 @@ def test_full_schedule_300_frames_all_detected(make_model, golden):
     every frame: the problem is well conditioned and the result is compared with the reference VALUE BY VALUE."""
     d_kp, e_root, _, _ = _full_schedule(make_model, golden, '_nogap', (0, 0))
     assert d_kp.max() < 0.1 and e_root < 2e-3          # achieved on the MI355X: 0.015 px, 2.3e-4 m
+    w = _full_schedule.last                            # smpl_orient_world, root_trans_world, cam_pose (SURVEY 8c: <= 1e-3 after the full schedule)
+    assert w['root_world'] < 1e-3 and w['orient'] < 1e-3 and w['orient_cam'] < 1e-3 and w['cam_rot'] < 1e-3 and w['cam_trans'] < 1e-3
 
 
 def _family_envelope(golden):
@@ -132,6 +138,8 @@ def test_full_schedule_300_frames_detection_gap_host_init(make_model, golden):
     thread-count changes, so a start that is equal to the last bit must stay in its solution: VALUE BY VALUE, 0.1 px."""
     d_kp, e_root, ours, ref = _full_schedule(make_model, golden, '', None, host_init=True)
     assert d_kp.max() < 0.1 and e_root < 5e-3
+    w = _full_schedule.last
+    assert w['root_world'] < 5e-3 and w['orient'] < 5e-3 and w['orient_cam'] < 5e-3 and w['cam_rot'] < 5e-3 and w['cam_trans'] < 5e-3
 
 
 def test_full_schedule_300_frames_detection_gap(make_model, golden):
@@ -458,14 +466,18 @@ FULL_CFG_CASES = [(c, T, P, gap) for (c, T, P, _seed) in mg.FULL_CASES for gap i
 # unmodified reference re-run with 3 threads moves by 34.5 px, with cam_pose x (1 + 1e-7 U) by 28.2 px (zero cameras); glamr_h36m (per-frame
 # camera optimised at lr 1e-2 under 1e4-weighted smoothness terms): 3.7 px / 8.0 px -- there is no single reference answer to match.
 FULL_FAMILY = {('glamr_dynamic_multi', True): True, ('glamr_h36m', False): False, ('glamr_h36m', True): False}
-FULL_TOL_GPU = {                                                              # achieved on the MI355X (round 3)
-    ('glamr_3dpw', 1, False): (0.1, 1e-3),                                    # 0.030 px   2.5e-4 m
-    ('glamr_3dpw', 1, True): (0.1, 1e-3),                                     # 0.027 px   3.4e-4 m
-    ('glamr_dynamic_multi', 2, False): (0.01, 5e-5),                          # 0.0016 px  8.6e-6 m
-    ('glamr_static_multi', 4, True): (0.05, 2e-4),                            # 0.0147 px  5.4e-5 m   BASELINE configs[3]
-    ('glamr_static_multi', 4, False): (0.03, 2e-4),                           # 0.0073 px  5.2e-5 m
-    ('glamr_static', 1, False): (0.01, 2e-5),                                 # 0.0027 px  2.9e-6 m
-    ('glamr_static', 1, True): (0.1, 6e-5),                                   # 0.0347 px  1.8e-5 m
+# (keypoints px, root in the camera frame m, world root m, world orientation as a rotation, orientation seen from the camera, camera rotation,
+#  camera translation m): ~3 x the values achieved on the MI355X (in the comments).  None = not comparable: glamr_3dpw DERIVES the camera from
+# the person's world pose (flag_opt_cam_from_person_pose), so person and camera share a free world-frame gauge along the optical axis -- the
+# world root wanders by decimetres between two runs while everything SEEN FROM the camera (root_cam, orient_cam, the projections) agrees.
+FULL_TOL_GPU = {                                                              # achieved on the MI355X (round 3; orient_cam / cam: round 4)
+    ('glamr_3dpw', 1, False): (0.1, 1e-3, None, 5e-3, 5e-3, None, None),      # 0.030 px   2.5e-4 m   (1.5e-1 m)  1.4e-3
+    ('glamr_3dpw', 1, True): (0.1, 1e-3, None, 1e-2, 1e-2, None, None),       # 0.027 px   3.4e-4 m   (3.5e-1 m)  3.0e-3
+    ('glamr_dynamic_multi', 2, False): (0.01, 5e-5, 3e-5, 5e-5, 5e-5, 5e-5, 5e-5),      # 0.0016 px  8.6e-6 m   6.7e-6 m   1.4e-5
+    ('glamr_static_multi', 4, True): (0.05, 2e-4, 2e-4, 5e-4, 5e-4, 5e-4, 5e-4),        # 0.0147 px  5.4e-5 m   5.0e-5 m   1.5e-4   BASELINE configs[3]
+    ('glamr_static_multi', 4, False): (0.03, 2e-4, 2e-4, 5e-5, 1e-4, 1e-4, 2e-4),       # 0.0073 px  5.2e-5 m   4.7e-5 m   1.2e-5
+    ('glamr_static', 1, False): (0.01, 2e-5, 2e-5, 3e-4, 3e-4, 3e-4, 3e-4),             # 0.0027 px  2.9e-6 m   3.3e-6 m   8.1e-5
+    ('glamr_static', 1, True): (0.1, 6e-5, 2e-4, 6e-4, 6e-4, 6e-4, 6e-4),               # 0.0347 px  1.8e-5 m   6.1e-5 m   1.7e-4
 }
 
 
@@ -493,8 +505,9 @@ def test_full_schedule_of_every_config_matches_the_reference(make_model, golden,
             tot, n = tot + float(d[d < 1e3].sum()), n + int((d < 1e3).sum())
         return tot / max(n, 1)
     ours, ref = reproj(lambda pi: out['person_data'][pi]['kp_2d_pred']), reproj(lambda pi: g['p%d_kp_2d_pred' % pi])
-    print('full schedule %s T=%d P=%d gap=%s: kp %.4f px (%d frames > 1 px), root in camera %.2e m, world root %.2e m, orientation %.2e; reprojection %.3f vs reference %.3f px'
-          % (cfg_id, T, P, gap, w['kp'], w['frames_over_1px'], w['root_cam'], w['root_world'], w['orient'], ours, ref))
+    print('full schedule %s T=%d P=%d gap=%s: kp %.4f px (%d frames > 1 px), root in camera %.2e m, world root %.2e m, orientation %.2e, orientation seen from the camera %.2e, '
+          'cam_pose rotation %.2e translation %.2e m; reprojection %.3f vs reference %.3f px'
+          % (cfg_id, T, P, gap, w['kp'], w['frames_over_1px'], w['root_cam'], w['root_world'], w['orient'], w['orient_cam'], w['cam_rot'], w['cam_trans'], ours, ref))
     assert abs(ours - ref) < 0.02 * max(ref, 1.0)
     if (cfg_id, gap) in FULL_FAMILY:
         # the reference's own spread on this case (oracle/make_golden.py gen_full_family_cfg: another thread count, cam_pose x (1 + 1e-7 .. 1e-6 U))
@@ -509,8 +522,11 @@ def test_full_schedule_of_every_config_matches_the_reference(make_model, golden,
         print('  reference family: %s' % {k: '%.2f px' % v for k, v in spread.items()})
         assert w['kp'] < 1.5 * max(spread.values()) + 0.5
     if (cfg_id, P, gap) in FULL_TOL_GPU:
-        tol_kp, tol_root = FULL_TOL_GPU[(cfg_id, P, gap)]
+        tol_kp, tol_root, tol_world, tol_orient, tol_orient_cam, tol_cam_rot, tol_cam_trans = FULL_TOL_GPU[(cfg_id, P, gap)]
         assert w['kp'] < tol_kp and w['root_cam'] < tol_root and w['frames_over_1px'] == 0
+        # what north_star names: smpl_orient_world, root_trans_world, cam_pose after the full schedule (SURVEY 8c asks for <= 1e-3)
+        for name, tol in (('root_world', tol_world), ('orient', tol_orient), ('orient_cam', tol_orient_cam), ('cam_rot', tol_cam_rot), ('cam_trans', tol_cam_trans)):
+            assert tol is None or w[name] < tol, '%s: %.3e >= %.1e' % (name, w[name], tol)
 
 
 def test_captured_resident_step_follows_new_inputs(make_model):

@@ -175,3 +175,36 @@ def test_carved_batch_arrays_are_independent_zero_views():
         v.zero_()
     sb = p.struct()
     assert sb.params == t['params'].data_ptr() and sb.cam_pose == t['cam_pose'].data_ptr()
+
+
+@pytest.mark.parametrize('case', mg.FILTER_CASES, ids=[c[0] for c in mg.FILTER_CASES])
+def test_filter_pose_twin_on_injected_jumps(golden, case):
+    """The numpy twin of filter_pose (what init_data_batch_host runs) on sequences with injected root-orientation jumps -- isolated, adjacent
+    and persistent ones, at the first / last frame, next to a detection gap, within 1e-4 of the pi / 3 threshold -- against the visibility
+    bookkeeping the UNMODIFIED reference's init_data leaves (oracle/make_golden.py gen_filter).  The device twin: tests/test_filter_pose_gpu.py."""
+    from glamr_amd.global_recon.models.global_recon_model import GlobalReconOptimizer
+    g = golden('filter_pose')
+    name, T, gap, events, attrs = case
+    in_dict, seed = mg.filter_inputs(case)
+    opt = GlobalReconOptimizer.__new__(GlobalReconOptimizer)
+    opt.flag_filter_pose = True
+    opt.flag_make_invis_with_keypoint = bool(attrs.get('flag_make_invis_with_keypoint', False))
+    opt.make_invis_keypoint_min_score, opt.make_invis_keypoint_min_num = 0.6, attrs.get('make_invis_keypoint_min_num', 15)
+    d = opt._person_arrays(in_dict['est'][0])
+    for key in ('visible', 'visible_orig', 'exist_frames', 'vis_frames', 'invis_frames'):
+        assert np.array_equal(np.asarray(d[key]), g['%s_%s' % (name, key)]), key
+    assert int(d['fr_start']) == int(g[name + '_fr_start']) and int(d['fr_end']) == int(g[name + '_fr_end'])
+    assert (d['visible'] != d['visible_orig']).sum() == (g[name + '_visible'] != g[name + '_visible_orig']).sum()
+
+
+def test_keypoint_count_filter_with_the_reference_default_removes_every_frame(golden):
+    """flag_make_invis_with_keypoint (:264-268) with the reference's default minimum of 15 confident keypoints: HybrIK scores 14 joints
+    per detected frame, so every frame becomes invisible -- as the reference's own filter_pose does on the same arrays."""
+    from glamr_amd.global_recon.models.global_recon_model import GlobalReconOptimizer
+    g = golden('filter_pose')
+    in_dict, seed = mg.filter_inputs(mg.FILTER_CASES[0])
+    opt = GlobalReconOptimizer.__new__(GlobalReconOptimizer)
+    opt.flag_filter_pose, opt.flag_make_invis_with_keypoint = True, True
+    opt.make_invis_keypoint_min_score, opt.make_invis_keypoint_min_num = 0.6, 15
+    d = opt._person_arrays(in_dict['est'][0])
+    assert np.array_equal(d['visible'], g['kp_default_visible']) and np.array_equal(d['vis_frames'], g['kp_default_vis_frames']) and not d['vis_frames'].any()
