@@ -34,6 +34,9 @@
 #define GLAMR_MARK_END(rt)
 #endif
 
+#ifndef GLAMR_HOIST_FRAME_CONSTS
+#define GLAMR_HOIST_FRAME_CONSTS 0
+#endif
 namespace glamr {
 namespace grecon {
 
@@ -256,6 +259,23 @@ GLAMR_HD LocalRow local_row(const PersonView& c, const glamr_param_layout& l, in
     L.dx = pr[0] + P[l.local_dxy + e * 2 + 0];
     L.dy = pr[1] + P[l.local_dxy + e * 2 + 1];
     L.h = c.h_prior[e] + (c.dheading_mask ? P[l.local_dheading + e] * c.dheading_mask[e] : 0.0f);
+  }
+  L.z = pr[2] + P[l.local_z + e];
+  for (int k = 0; k < 6; ++k) L.r6[k] = pr[3 + k] + P[l.local_rot + e * 6 + k];
+  return L;
+}
+
+// the same row from values the thread keeps in registers for the whole launch (FrameRegs): same operations in the same order
+GLAMR_HD LocalRow local_row_regs(const float (&pr)[9], float h_prior, float dmask, bool has_dmask, const float* P, const glamr_param_layout& l, int e) {
+  LocalRow L;
+  if (e == 0) {
+    L.dx = pr[0] + P[l.local_xy + 0];
+    L.dy = pr[1] + P[l.local_xy + 1];
+    L.h = h_prior + P[l.local_heading];
+  } else {
+    L.dx = pr[0] + P[l.local_dxy + e * 2 + 0];
+    L.dy = pr[1] + P[l.local_dxy + e * 2 + 1];
+    L.h = h_prior + (has_dmask ? P[l.local_dheading + e] * dmask : 0.0f);
   }
   L.z = pr[2] + P[l.local_z + e];
   for (int k = 0; k < 6; ++k) L.r6[k] = pr[3 + k] + P[l.local_rot + e * 6 + k];
@@ -816,6 +836,28 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   }
   rt.sync();
 
+  // Per-frame constants of the iteration kept in REGISTERS for the whole launch (constant-layout instances: one frame per thread, one
+  // person): the intrinsics, the camera-frame orientation target, the prior row, visibility.  The loop used to fetch these 110 B per
+  // frame from their workspace copies every iteration -- a quarter of the 122 KB a scene re-reads per iteration, and what pushed the 32
+  // scenes resident on an XCD past its 4 MB of L2 (29 KB per scene-iteration fetched from beyond it: profiles/r03_pmc_stage_kernel.json).
+  constexpr bool HOIST = GLAMR_HOIST_FRAME_CONSTS && TMC > 0 && RT::one_thread_per_frame;
+  struct FrameRegs { float K[9], tgt[6], prior[9], h_prior, dmask, vis; int rank; } fr;
+  if (HOIST) {
+    const int t = rt.tid();
+    if (frame_in(t, T)) {
+      const PersonView c = pv(0);
+      for (int k = 0; k < 9; ++k) fr.K[k] = c.cam_K[(size_t)t * 9 + k];
+      for (int k = 0; k < 6; ++k) fr.tgt[k] = c.oc6[t * 6 + k];
+      fr.vis = c.vis[t];
+      fr.rank = c.vis_rank[t];
+      const int e = t - c.fr_start;
+      const bool ex = t >= c.fr_start && t < c.fr_end;
+      for (int k = 0; k < 9; ++k) fr.prior[k] = ex ? c.prior[(size_t)e * 11 + k] : 0.f;
+      fr.h_prior = ex ? c.h_prior[e] : 0.f;
+      fr.dmask = (ex && c.dheading_mask) ? c.dheading_mask[e] : 0.f;
+    }
+  }
+
   const int niters = st.niters;
   double b1p = 1.0, b2p = 1.0;
   int n_done = 0;
@@ -849,7 +891,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         const PersonView c = pv(p);
         float v = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
-          const LocalRow L = local_row(c, lo, t - c.fr_start);
+          const LocalRow L = HOIST ? local_row_regs(fr.prior, fr.h_prior, fr.dmask, c.dheading_mask != nullptr, c.p, lo, t - c.fr_start)
+                                   : local_row(c, lo, t - c.fr_start);
           store_row(pv(p).Lc, sh.TM, t, L);
           // atan2(sin h, cos h) of the reference (:401-405) only wraps h into (-pi, pi]: done arithmetically
           v = L.h - 6.28318530717958647692f * rintf(L.h * 0.15915494309189533577f);
@@ -1022,10 +1065,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         }
         const float* tw = s.tw + t * 3;
         float K[9], tgt[6];
-        for (int k = 0; k < 9; ++k) K[k] = c.cam_K[(size_t)t * 9 + k];
-        for (int k = 0; k < 6; ++k) tgt[k] = s.oc6[t * 6 + k];
-        const float vis_t = c.vis[t];
-        const int rank_t = c.vis_rank[t];
+        for (int k = 0; k < 9; ++k) K[k] = HOIST ? fr.K[k] : c.cam_K[(size_t)t * 9 + k];
+        for (int k = 0; k < 6; ++k) tgt[k] = HOIST ? fr.tgt[k] : s.oc6[t * 6 + k];
+        const float vis_t = HOIST ? fr.vis : c.vis[t];
+        const int rank_t = HOIST ? fr.rank : c.vis_rank[t];
         float g_tw[3] = {0, 0, 0};
         float gRk[9];
         for (int k = 0; k < 9; ++k) gRk[k] = 0.f;

@@ -40,7 +40,8 @@ constexpr int TILE_V = 32;
 constexpr int TILE_F = 32;
 constexpr int MAX_EXTRA = 9;
 constexpr int MAX_PICKED = 32;
-constexpr int OUT_STRIDE = 97;    // LDS transpose row stride (floats) for the vertex write-out
+constexpr int OUT_STRIDE = 100;   // LDS transpose row stride (floats) for the vertex write-out: 400-B rows keep the 48-B runs of a lane 16-B aligned,
+                                  // and 100 mod 64 = 36 spreads the 16 frames of a pass over all banks (conflict-free ds_write_b128)
 constexpr int K_ONE = 217;        // feature index that carries the constant 1 (multiplies v_template)
 constexpr int KSH = 232;          // halves per LDS row of one fp16 plane of the direction matrix (224 + 8: 16-byte rows, conflict-free b128 reads)
 
@@ -161,15 +162,25 @@ struct PrepArgs {
   float* chain_joints;      // (B, 24, 3)
 };
 
+// The fp16 planes leave through LDS: a block's 8 frames are 8 consecutive columns of one 32-frame tile, so for every (plane, k step, lane
+// half) -- and (entry, plane, k step, lane half) of the joint transforms -- they form ONE 128-byte run of the fragment-major arrays; written
+// straight from the (frame, joint) threads these were 2-byte stores 16 bytes apart.
+constexpr int PREP_FEAT_SEGS = 2 * FEAT_STEPS * 2;          // (plane, step, half)
+constexpr int PREP_ASK_SEGS = 12 * 2 * 2 * 2;               // (entry, plane, step, half)
+
 __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
   GLAMR_CRITICAL_PATH_PRIO();
   __shared__ float sG[PREP_FRAMES][NJ][12];   // global transform of each joint: 3x3 rotation | translation
   __shared__ float sJ[PREP_FRAMES][NJ][3];    // rest joints
+  __shared__ __attribute__((aligned(16))) _Float16 sFeatH[PREP_FEAT_SEGS][PREP_FRAMES * 8];
+  __shared__ __attribute__((aligned(16))) _Float16 sAskH[PREP_ASK_SEGS][PREP_FRAMES * 8];
   const int tid = threadIdx.x;
   const int fl = tid / NJ, j = tid % NJ;
   const int b = blockIdx.x * PREP_FRAMES + fl;
   const bool active = (fl < PREP_FRAMES) && (b < a.B);
   const bool padding = (fl < PREP_FRAMES) && !active && (b < a.Bpad);      // rows the padded MFMA tiles read: zeros
+  const bool want_feat = a.feat != nullptr || a.feat_h != nullptr;
+  const bool want_askin = a.askin != nullptr || a.askin_h != nullptr;
   float R[9];
   float Jr[3] = {0.f, 0.f, 0.f};
   if (active || padding) {
@@ -184,13 +195,17 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
         sJ[fl][j][c] = v;
       }
     }
-    if (a.feat) {
-      float* f = a.feat + (size_t)b * KTOT;
-      _Float16* fh = reinterpret_cast<_Float16*>(a.feat_h);
+    if (want_feat) {
+      float* f = a.feat ? a.feat + (size_t)b * KTOT : nullptr;
       auto put = [&](int k, float v) {
         if (padding) v = 0.0f;
-        f[k] = v;
-        if (fh) { const _Float16 hi = (_Float16)v; fh[feat_h_off(b, 0, k)] = hi; fh[feat_h_off(b, 1, k)] = (_Float16)(v - (float)hi); }
+        if (f) f[k] = v;
+        if (a.feat_h) {
+          const int half = k / 112, kk = k - half * 112, m = kk >> 3, i = kk & 7;
+          const _Float16 hi = (_Float16)v;
+          sFeatH[(0 * FEAT_STEPS + m) * 2 + half][fl * 8 + i] = hi;
+          sFeatH[(1 * FEAT_STEPS + m) * 2 + half][fl * 8 + i] = (_Float16)(v - (float)hi);
+        }
       };
       if (j > 0) {
         for (int e = 0; e < 9; ++e) put(10 + (j - 1) * 9 + e, padding ? 0.0f : R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
@@ -226,23 +241,41 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
   if (active || padding) {
     const float* G = sG[fl][j];
     if (active) for (int c = 0; c < 3; ++c) a.chain_joints[((size_t)b * NJ + j) * 3 + c] = G[c * 4 + 3];
-    if (a.askin) {
+    if (want_askin) {
       // relative transform: A = [G_R | G_t - G_R J]
-      float* A = a.askin + (size_t)b * 12 * NJ;
-      _Float16* Ah = reinterpret_cast<_Float16*>(a.askin_h);
+      float* A = a.askin ? a.askin + (size_t)b * 12 * NJ : nullptr;
       auto put = [&](int e, float v) {
         if (padding) v = 0.0f;
-        A[e * NJ + j] = v;
-        if (Ah) {
+        if (A) A[e * NJ + j] = v;
+        if (a.askin_h) {
           const _Float16 hi = (_Float16)v;
-          Ah[askin_h_off(b, e, 0, j)] = hi;
-          Ah[askin_h_off(b, e, 1, j)] = (_Float16)(v - (float)hi);
-          if (j < 8) { Ah[askin_h_off(b, e, 0, 24 + j)] = (_Float16)0.f; Ah[askin_h_off(b, e, 1, 24 + j)] = (_Float16)0.f; }      // K padding
+          const int m = j >> 4, half = (j >> 3) & 1, i = j & 7;
+          sAskH[(((e * 2 + 0) * 2 + m) * 2) + half][fl * 8 + i] = hi;
+          sAskH[(((e * 2 + 1) * 2 + m) * 2) + half][fl * 8 + i] = (_Float16)(v - (float)hi);
+          if (j < 8) { sAskH[(((e * 2 + 0) * 2 + 1) * 2) + 1][fl * 8 + j] = (_Float16)0.f; sAskH[(((e * 2 + 1) * 2 + 1) * 2) + 1][fl * 8 + j] = (_Float16)0.f; }      // K padding: k = 24 + j
         }
       };
       for (int r0 = 0; r0 < 3; ++r0) {
         for (int c = 0; c < 3; ++c) put(r0 * 4 + c, padding ? 0.0f : G[r0 * 4 + c]);
         put(r0 * 4 + 3, padding ? 0.0f : G[r0 * 4 + 3] - (G[r0 * 4 + 0] * Jr[0] + G[r0 * 4 + 1] * Jr[1] + G[r0 * 4 + 2] * Jr[2]));
+      }
+    }
+  }
+  if (a.feat_h || a.askin_h) {
+    // (frames beyond Bpad of the last block: their columns belong to no tile -- Bpad is a multiple of 32 and of PREP_FRAMES, so a block is
+    // either entirely inside the padded range or not launched)
+    __syncthreads();
+    const int b0 = blockIdx.x * PREP_FRAMES, ft = b0 >> 5, c0 = b0 & 31;
+    const int nfeat = a.feat_h ? PREP_FEAT_SEGS * 8 : 0, nask = a.askin_h ? PREP_ASK_SEGS * 8 : 0;
+    for (int i = tid; i < nfeat + nask; i += 256) {
+      if (i < nfeat) {
+        const int seg = i >> 3, piece = i & 7;
+        uint4* dst = reinterpret_cast<uint4*>(a.feat_h + (size_t)ft * FEAT_TILE_H + (size_t)seg * 256 + c0 * 8) + piece;
+        *dst = reinterpret_cast<const uint4*>(&sFeatH[seg][0])[piece];
+      } else {
+        const int q = i - nfeat, seg = q >> 3, piece = q & 7;
+        uint4* dst = reinterpret_cast<uint4*>(a.askin_h + (size_t)ft * ASK_TILE_H + (size_t)seg * 256 + c0 * 8) + piece;
+        *dst = reinterpret_cast<const uint4*>(&sAskH[seg][0])[piece];
       }
     }
   }
@@ -273,7 +306,15 @@ struct LbsArgs {
   const float* root_trans;  // (B,3)
   const float* root_scale;  // (B) or null
   int skip_picks;           // the joints pass already captured the picked vertices
+#ifdef GLAMR_SMPL_EXPERIMENT
+  int exp;                  // development builds: ablation switches (tools/smpl_ablate.py)
+#endif
 };
+#ifdef GLAMR_SMPL_EXPERIMENT
+#define GLAMR_SMPL_EXP(a, bit) (((a).exp & (bit)) != 0)
+#else
+#define GLAMR_SMPL_EXP(a, bit) false
+#endif
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -299,7 +340,17 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
   if (F16) {
     const uint4* src = reinterpret_cast<const uint4*>(a.dirs_h + (size_t)tile * 3 * 2 * TILE_V * KSH);
     uint4* dst = reinterpret_cast<uint4*>(sDirs);
-    for (int i = tid; i < 3 * 2 * TILE_V * KSH / 8; i += NT) dst[i] = src[i];
+    // 5568 sixteen-byte pieces over 512 threads: all eleven loads of a thread in flight before its first LDS write (one memory round trip
+    // per workgroup instead of eleven -- nothing else runs on the CU while its only workgroup stages)
+    constexpr int NPIECE = 3 * 2 * TILE_V * KSH / 8, NFULL = NPIECE / NT;
+    uint4 st[NFULL], tail = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NFULL; ++k) st[k] = src[tid + k * NT];
+    const bool has_tail = tid + NFULL * NT < NPIECE;
+    if (has_tail) tail = src[tid + NFULL * NT];
+#pragma unroll
+    for (int k = 0; k < NFULL; ++k) dst[tid + k * NT] = st[k];
+    if (has_tail) dst[tid + NFULL * NT] = tail;
   } else {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.dirs_tiled + (size_t)tile * 3 * TILE_V * KSTRIDE);
     f32x4* dst = reinterpret_cast<f32x4*>(sDirs);
@@ -351,7 +402,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
       // lane half h supplies k = 112 h + 8 m .. + 7 to k step m, on both operands alike.  The feature planes are fragment-major: the
       // fetch of (plane, step) is ONE contiguous 1 KB read per wave, requested PF steps before its MFMAs
       const unsigned short* myH = reinterpret_cast<const unsigned short*>(sDirs) + (size_t)col * KSH + half * KH;
-      const uint4* fq = reinterpret_cast<const uint4*>(a.feat_h) + (size_t)ft * (FEAT_TILE_H / 8) + lane;
+      const uint4* fq = reinterpret_cast<const uint4*>(a.feat_h) + (GLAMR_SMPL_EXP(a, 8) ? (size_t)wave : (size_t)ft) * (FEAT_TILE_H / 8) + lane;
       constexpr int PF = 3, RING = PF + 1;
       uint4 qh[RING], ql[RING];
       uint4 ah[2][3], al[2][3];          // direction fragments (LDS), one k step ahead as well
@@ -404,47 +455,56 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
     // skinning: out_r = T_r0 px + T_r1 py + T_r2 pz + T_r3,  T_e[v, b] = sum_j W[v, j] A_e[b, j]
     const float* arow = a.askin + (size_t)b * 12 * NJ + half * 12;
     f32x16 out[3];
+    if (F16) {
+      // joint transforms, fragment-major: entry e = 4 r + c, (plane, k step m) -> one contiguous 1 KB read per wave.  Twelve phases
+      // (r, m, pair of c) of four fetches and six MFMAs each; the fetches of a phase are requested before the MFMAs of the one before it
+      // (a ring of three sets, two phases ahead, costs 16 more registers: the epilogue then spills addresses, and a scratch reload waits on
+      // vmcnt(0) -- on every vertex store still in flight; the ablations say the operand fetches are 0.2 of 1.5 ms, the epilogue 0.75)
+      const uint4* aq = reinterpret_cast<const uint4*>(a.askin_h) + (GLAMR_SMPL_EXP(a, 4) ? (size_t)wave : (size_t)ft) * (ASK_TILE_H / 8) + lane;
+      uint4 qa[2][2][2];      // [ring][c of the pair][plane]
+      auto fetch = [&](int ph, int buf) {
+        const int r = ph >> 2, m = (ph >> 1) & 1, cp = ph & 1;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) qa[buf][ci][pl] = aq[((((r * 4 + 2 * cp + ci) * 2 + pl) * 2 + m)) * 64];
+      };
+      fetch(0, 0);
       f32x16 T[4];
-      if (F16) {
-        // joint transforms, fragment-major: entry e = 4 r + c, (plane, k step m) -> one contiguous 1 KB read per wave; all 16 fetches of
-        // this output row are requested before its first MFMA
-        const uint4* aq = reinterpret_cast<const uint4*>(a.askin_h) + (size_t)ft * (ASK_TILE_H / 8) + lane;
-        uint4 qa[4][2][2];      // [c][plane][m]
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) qa[c][pl][m] = aq[((((r * 4 + c) * 2 + pl) * 2 + m)) * 64];
+      for (int ph = 0; ph < 12; ++ph) {
+        const int r = ph >> 2, m = (ph >> 1) & 1, cp = ph & 1, buf = ph & 1;
+        if (ph + 1 < 12) fetch(ph + 1, (ph + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) T[c] = (f32x16){0};
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[m], __builtin_bit_cast(f16x8, qa[c][0][m]), T[c], 0, 0, 0);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[c][1][m]), T[c], 0, 0, 0);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) T[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[c][0][m]), T[c], 0, 0, 0);
-        }
-      } else
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        T[c] = (f32x16){0};
-        const float* ae = arow + (r * 4 + c) * NJ;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ae), a1 = *reinterpret_cast<const f32x4*>(ae + 4),
-                    a2 = *reinterpret_cast<const f32x4*>(ae + 8);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[m], a0[m], T[c], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 + m], a1[m], T[c], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[8 + m], a2[m], T[c], 0, 0, 0);
+        const int c0 = 2 * cp, c1 = 2 * cp + 1;
+        if (m == 0) { T[c0] = (f32x16){0}; T[c1] = (f32x16){0}; }
+        T[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[m], __builtin_bit_cast(f16x8, qa[buf][0][0]), T[c0], 0, 0, 0);
+        T[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[m], __builtin_bit_cast(f16x8, qa[buf][1][0]), T[c1], 0, 0, 0);
+        T[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[buf][0][1]), T[c0], 0, 0, 0);
+        T[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[buf][1][1]), T[c1], 0, 0, 0);
+        T[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[buf][0][0]), T[c0], 0, 0, 0);
+        T[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[m], __builtin_bit_cast(f16x8, qa[buf][1][0]), T[c1], 0, 0, 0);
+        if (m == 1 && cp == 1) out[r] = T[0] * px + T[1] * py + T[2] * pz + T[3];
       }
-      out[r] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        f32x16 T[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          T[c] = (f32x16){0};
+          const float* ae = arow + (r * 4 + c) * NJ;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(ae), a1 = *reinterpret_cast<const f32x4*>(ae + 4),
+                      a2 = *reinterpret_cast<const f32x4*>(ae + 8);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[m], a0[m], T[c], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 + m], a1[m], T[c], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) T[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[8 + m], a2[m], T[c], 0, 0, 0);
+        }
+        out[r] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+      }
     }
     const bool frame_ok = b < a.B;
     if (a.pivot && frame_ok) {      // re-anchor on output joint 0 (lane = frame: three pivots, three translations, one scale per lane)
@@ -486,28 +546,59 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
           }
       }
     }
-    // vertex write-out through an LDS transpose: [frame][vertex row][xyz] so each frame's 96 floats are contiguous
-    if (a.verts) {
+    // vertex write-out through an LDS transpose: [frame][vertex row][xyz] so each frame's 96 floats are contiguous.  A lane's 16 accumulator
+    // rows are four runs of four consecutive vertices = 12 consecutive floats each: three ds_write_b128 per run; the rows leave as 16-byte
+    // pieces, two frame rows per store instruction
+    if (a.verts && !GLAMR_SMPL_EXP(a, 2)) {
       float* so = sOut + (size_t)wave * OF * OUT_STRIDE;
-      const int nvalid = min(TILE_V, a.V - v0) * 3;
+      const int nvalid = GLAMR_SMPL_EXP(a, 1) ? 0 : min(TILE_V, a.V - v0) * 3;
+      const bool wide = (a.V & 1) == 0;
 #pragma unroll
       for (int pass = 0; pass < TILE_F / OF; ++pass) {
         if (col / OF == pass) {
           const int fc = col - pass * OF;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int row = acc_row(q, half);
-            so[fc * OUT_STRIDE + row * 3 + 0] = out[0][q];
-            so[fc * OUT_STRIDE + row * 3 + 1] = out[1][q];
-            so[fc * OUT_STRIDE + row * 3 + 2] = out[2][q];
+          for (int g = 0; g < 4; ++g) {
+            f32x4* dst = reinterpret_cast<f32x4*>(so + fc * OUT_STRIDE + (8 * g + 4 * half) * 3);
+            dst[0] = (f32x4){out[0][4 * g + 0], out[1][4 * g + 0], out[2][4 * g + 0], out[0][4 * g + 1]};
+            dst[1] = (f32x4){out[1][4 * g + 1], out[2][4 * g + 1], out[0][4 * g + 2], out[1][4 * g + 2]};
+            dst[2] = (f32x4){out[2][4 * g + 2], out[0][4 * g + 3], out[1][4 * g + 3], out[2][4 * g + 3]};
           }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int idx = lane; idx < OF * 96; idx += 64) {
-          const int f = idx / 96, c = idx - f * 96;
-          const int bb = ft * TILE_F + pass * OF + f;
-          if (bb < a.B && c < nvalid) a.verts[((size_t)bb * a.V + v0) * 3 + c] = so[f * OUT_STRIDE + c];
+        if (wide) {
+          // TWO frame rows (24 sixteen-byte pieces each) per step: lanes 0 .. 23 the even row, lanes 32 .. 55 the odd one.  The LDS address is
+          // one register + an immediate, the global address advances by two frame strides -- no per-piece index arithmetic for the compiler to
+          // hoist out of the frame loop and spill (a scratch reload waits on vmcnt(0), i.e. on every vertex store still in flight).  A row starts
+          // on an 8-byte boundary (V even), so every other row's pieces are 8-byte aligned only: global memory takes unaligned dwordx4.
+          const int sub = lane >> 5, pc = lane & 31;
+          const bool mine = pc < 24 && 4 * pc < nvalid;
+          const int nhere = nvalid - 4 * pc;                       // floats of this piece inside the tile's valid range (>= 4: whole piece)
+          const float* src = so + sub * OUT_STRIDE + 4 * (pc < 24 ? pc : 0);
+          const int bb0 = ft * TILE_F + pass * OF + sub;
+          float* dst = a.verts + ((size_t)bb0 * a.V + v0) * 3 + 4 * (pc < 24 ? pc : 0);
+          const size_t fstride2 = (size_t)a.V * 6;
+#pragma unroll
+          for (int h = 0; h < OF / 2; h += 4) {
+            f32x4 piece[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) piece[k] = *reinterpret_cast<const f32x4*>(src + 2 * (h + k) * OUT_STRIDE);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float* d = dst + (size_t)(h + k) * fstride2;
+              if (mine && bb0 + 2 * (h + k) < a.B) {
+                if (nhere >= 4) *reinterpret_cast<f32x4*>(d) = piece[k];
+                else { d[0] = piece[k][0]; if (nhere > 1) d[1] = piece[k][1]; if (nhere > 2) d[2] = piece[k][2]; }
+              }
+            }
+          }
+        } else {
+          for (int idx = lane; idx < OF * 96; idx += 64) {
+            const int f = idx / 96, c = idx - f * 96;
+            const int bb = ft * TILE_F + pass * OF + f;
+            if (bb < a.B && c < nvalid) a.verts[((size_t)bb * a.V + v0) * 3 + c] = so[f * OUT_STRIDE + c];
+          }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1083,6 +1174,23 @@ SmplWs smpl_ws_layout(const glamr_smpl* h, int B, char* base) {
 }
 }  // namespace
 
+// Frame tiles are split over gridDim.y.  The split decides two things: how evenly the frame tiles fall on the (waves x chunks) wave slots of a
+// vertex tile, and how full the last round of workgroups leaves the 256 CUs (one workgroup per CU: the direction tile fills its LDS).
+// 216 vertex tiles x 5 chunks = 1080 workgroups were 4.2 rounds -- a fifth round at 22 % occupancy; 15 chunks = 12.7 rounds (97 %) with the
+// 600 frame tiles of B = 19 200 still 5 per wave.  Every workgroup re-stages its 87 KB direction tile, so a wave keeps >= 3 frame tiles.
+static int lbs_frame_chunks(int n_tiles, int n_ftiles, int nw) {
+  const int cus = 256;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int gy = 1; gy <= std::max(1, n_ftiles / (3 * nw)); ++gy) {
+    const int wgs = n_tiles * gy, rounds = (wgs + cus - 1) / cus;
+    const int per_wave = (n_ftiles + nw * gy - 1) / (nw * gy);
+    const double eff = ((double)wgs / (rounds * cus)) * ((double)n_ftiles / ((double)per_wave * nw * gy));
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = gy; }
+  }
+  return best;
+}
+
 extern "C" size_t glamr_smpl_workspace_bytes(const glamr_smpl* h, int B) {
   if (!h || B <= 0) return 0;
   return smpl_ws_layout(h, B, nullptr).total;
@@ -1099,8 +1207,9 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   // selects the fp32-MFMA instances (and then the planes of the feature rows / joint transforms are not written)
   const bool planes = std::getenv("GLAMR_SMPL_FP32_BLEND") == nullptr && h->full.dirs_h != nullptr && (h->joints.n_tiles == 0 || h->joints.dirs_h != nullptr);
   // (rows [B, Bpad) of the operand arrays, read by the padded MFMA tiles, are written as zeros by the prep kernel)
-  PrepArgs pa{B, w.Bpad, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat,
-              planes ? reinterpret_cast<unsigned short*>(w.feat_h) : nullptr, w.askin, planes ? reinterpret_cast<unsigned short*>(w.askin_h) : nullptr, w.chain};
+  // (the fp16-plane instances read nothing but the planes: the fp32 rows are only written for the fp32-MFMA instances)
+  PrepArgs pa{B, w.Bpad, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, planes ? nullptr : w.feat,
+              planes ? reinterpret_cast<unsigned short*>(w.feat_h) : nullptr, planes ? nullptr : w.askin, planes ? reinterpret_cast<unsigned short*>(w.askin_h) : nullptr, w.chain};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((w.Bpad + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   const int n_ftiles = w.Bpad / TILE_F;
   const bool f16 = planes;
@@ -1111,11 +1220,15 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
     LbsArgs la{B, h->V, ts.n_tiles, n_ftiles, ne, h->n_picked, ts.dirs_tiled, ts.w_tiled, ts.jx_used,
                ts.tile_pick_start, ts.tile_pick_ids, ts.pick_row, w.feat, ts.dirs_h, reinterpret_cast<const unsigned short*>(w.feat_h),
                reinterpret_cast<const unsigned short*>(w.askin_h), w.askin, vout, w.picked, w.partial, w.Bpad,
-               pivot, root_trans, root_scale, skip_picks ? 1 : 0};
+               pivot, root_trans, root_scale, skip_picks ? 1 : 0
+#ifdef GLAMR_SMPL_EXPERIMENT
+               , std::getenv("GLAMR_SMPL_EXP") ? std::atoi(std::getenv("GLAMR_SMPL_EXP")) : 0
+#endif
+    };
     const size_t lds = dirs_bytes + (vout ? (size_t)nw * (f16 ? TILE_F / 2 : TILE_F) * OUT_STRIDE * sizeof(float) : 0);
     // frame tiles are split over gridDim.y so that a launch has ~4 workgroups per CU even with few vertex tiles; every workgroup
     // re-stages its 87 KB direction tile, so a chunk keeps >= 8 frame tiles per wave
-    const int gy = std::max(1, std::min((1024 + ts.n_tiles - 1) / ts.n_tiles, n_ftiles / 32));
+    const int gy = lbs_frame_chunks(ts.n_tiles, n_ftiles, nw);
     auto launch = [&](auto kern) -> int {
       {      // once per instance and process: the largest arena an instance can ask for (direction tile + eight half-tile transposes)
         static std::mutex amu;

@@ -564,8 +564,12 @@ def gen_full_family():
 
 
 FULL_SEEDS = (1, 2, 3, 4, 5, 6, 7, 8)          # BASELINE configs[1] WITH the detection gap, beyond seed 0 (gen_full): bench.py's workload is seeds 0 .. B-1
-FULL_SEEDS_FAMILY = (1, 2, 3)                 # seeds whose 1e-6 family (three members) is generated as well
+FULL_SEEDS_FAMILY = (1, 2, 3, 4, 6)           # seeds whose family of re-runs is generated as well: 1-3 by choice, 4 and 6 because the kernel
+#                                               algorithm on the CPU runtime, started from the reference's OWN initial state, ends 9 / 45 px from
+#                                               the reference there (tools/seeds_hostsim.py) -- the question is then what the reference itself does
 SEED_FAMILY = [('eps1e-6_seed%d' % sd, dict(eps=1e-6, seed=sd)) for sd in (0, 1, 2)]
+SEED_FAMILY_WIDE = [('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-7_seed1', dict(eps=1e-7, seed=1))] + SEED_FAMILY
+WIDE_FAMILY_SEEDS = (4, 6)
 
 
 def seed_name(seed):
@@ -585,8 +589,10 @@ def gen_full_seeds(seeds=FULL_SEEDS, family_seeds=FULL_SEEDS_FAMILY):
     keys = ['kp_2d_pred', 'root_trans_world', 'smpl_orient_world', 'vis_frames']
     for seed in seeds:
         out = {}
-        members = [('', {})] + (list(SEED_FAMILY) if seed in family_seeds else [])
+        members = [('', {})] + (list(SEED_FAMILY_WIDE if seed in WIDE_FAMILY_SEEDS else SEED_FAMILY) if seed in family_seeds else [])
+        keep_threads = torch.get_num_threads()
         for name, opt in members:
+            torch.set_num_threads(opt.get('threads', keep_threads))
             model, cfg = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
             in_dict = synth.make_in_dict(seed=seed, num_frames=300, num_persons=1, smpl_model=md)
             keep = model.init_opt
@@ -795,7 +801,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

@@ -167,6 +167,84 @@ def test_full_schedule_300_frames_detection_gap(make_model, golden):
     assert best[0] < 0.25
 
 
+MULTI_SEEDS = (0,) + tuple(mg.FULL_SEEDS)
+_MULTI = {}
+
+
+def _seed_fixture(golden, seed):
+    """(reference result, {member: projections}) of BASELINE configs[1] WITH the detection gap for one seed: seed 0 is the round-1 fixture and
+    its family file, seeds 1.. come from oracle/make_golden.py gen_full_seeds (the 1e-6 family inside the same file for FULL_SEEDS_FAMILY)."""
+    if seed == 0:
+        g, fam = golden('full_glamr_dynamic_T300'), golden('full_glamr_dynamic_T300_family')
+        members = {k[:-len('_kp_2d_pred')]: v for k, v in fam.items() if k.endswith('_kp_2d_pred')}
+    else:
+        g = golden(mg.seed_name(seed))
+        members = {k[4:-len('_kp_2d_pred')]: v for k, v in g.items() if k.startswith('fam_') and k.endswith('_kp_2d_pred')}
+    return g, members
+
+
+@pytest.mark.parametrize('seed', MULTI_SEEDS)
+def test_full_schedule_detection_gap_multi_seed(make_model, golden, seed):
+    """bench.py's workload is synth.make_in_dict(seed) for seeds 0 .. B-1 with person 0 undetected in [100, 160): the zero-camera regime of
+    DESIGN.md 4, where the unmodified reference itself has neighbouring solutions within 1e-6 of its own start.  NINE seeds, each through
+    (a) the numpy init_data (the reference's own initial state): the 500-iteration result VALUE BY VALUE against the reference's, and
+    (b) the default path (init_data on the device, a few 1e-6 from the reference's start): on the reference's result or on a member of its
+    1e-6 family where one was generated, inside the family's envelope otherwise, and with the reference's reprojection quality."""
+    g, members = _seed_fixture(golden, seed)
+    md = synth.make_smpl_model()
+    in_dict = synth.make_in_dict(seed=seed, num_frames=300, num_persons=1, smpl_model=md)
+    lat = mg.latents_for(in_dict, seed)
+    vis = g['p0_vis_frames']
+    ref = g['p0_kp_2d_pred']
+    obs = in_dict['est'][0]['kp_2d'][:, :24, :2]
+    reproj = lambda kp: float(np.linalg.norm(kp[vis][:, :24] - obs, axis=-1).mean())
+    per_frame = lambda kp, other: np.abs(kp - other)[vis].max(axis=(1, 2))
+    res = {}
+    for leg in ('host', 'device'):
+        model = make_model('glamr_dynamic')
+        if leg == 'host':
+            model.init_data_batch = model.init_data_batch_host
+        out = model.optimize(in_dict, latents=lat)
+        kp = out['person_data'][0]['kp_2d_pred']
+        d = per_frame(kp, ref)
+        near = min([(float(per_frame(kp, v).max()), k) for k, v in members.items()] + [(float(d.max()), 'golden')])
+        from tests.grecon_common import full_schedule_errors
+        w = full_schedule_errors(out['person_data'], out['cam_pose'], g, 1)
+        res[leg] = dict(kp=float(d.max()), over1=int((d > 1).sum()), nearest=near, reproj=reproj(kp), w=w)
+        print('seed %d, %s init: %.3f px from the reference (%d frames > 1 px), nearest member %s at %.3f px; world root %.1e m, orientation %.1e, cam_pose %.1e / %.1e m; '
+              'reprojection %.3f vs reference %.3f px' % (seed, leg, d.max(), int((d > 1).sum()), near[1], near[0], w['root_world'], w['orient'], w['cam_rot'], w['cam_trans'],
+                                                          reproj(kp), reproj(ref)))
+    spread = [(float(per_frame(v, ref).max()), int((per_frame(v, ref) > 1).sum())) for v in members.values()]
+    res['family'] = spread
+    _MULTI[seed] = res
+    ref_q = reproj(ref)
+    for leg in ('host', 'device'):
+        assert abs(res[leg]['reproj'] - ref_q) < 0.02 * max(ref_q, 1.0), leg          # the reference's quality, whatever the basin
+    # (a) the reference's own start: its own solution, value by value
+    assert res['host']['kp'] < 0.1, 'host init: %.3f px' % res['host']['kp']
+    # (b) the device start
+    if members:
+        env_px, env_n = max(s[0] for s in spread), max(s[1] for s in spread)
+        on_member = res['device']['nearest'][0] < 0.25
+        inside = res['device']['kp'] <= 1.5 * env_px + 0.5 and res['device']['over1'] <= env_n + 10
+        assert on_member or inside, 'device init: %.3f px, %d frames > 1 px; family envelope %.3f px, %d frames' % (res['device']['kp'], res['device']['over1'], env_px, env_n)
+
+
+def test_multi_seed_summary():
+    """How many of the nine seeds land where: printed for DESIGN.md 4 (needs the parametrised test above to have run in this process)."""
+    if len(_MULTI) < len(MULTI_SEEDS):
+        pytest.skip('the per-seed cases did not all run')
+    host_on = [s for s, r in _MULTI.items() if r['host']['kp'] < 0.1]
+    dev_on_golden = [s for s, r in _MULTI.items() if r['device']['kp'] < 0.25]
+    dev_on_member = [s for s, r in _MULTI.items() if r['device']['kp'] >= 0.25 and r['device']['nearest'][0] < 0.25]
+    dev_else = [s for s in _MULTI if s not in dev_on_golden and s not in dev_on_member]
+    print('multi-seed full schedules (configs[1] with the detection gap), %d seeds: host init on the reference result (< 0.1 px): %s; device init on the reference result '
+          '(< 0.25 px): %s, on a member of its 1e-6 family: %s, elsewhere: %s' % (len(_MULTI), host_on, dev_on_golden, dev_on_member,
+                                                                                 {s: '%.2f px' % _MULTI[s]['device']['kp'] for s in dev_else}))
+    print('reference families (max px, frames > 1 px per member): %s' % {s: r['family'] for s, r in _MULTI.items() if r['family']})
+    assert len(host_on) == len(_MULTI)
+
+
 def test_run_demo_entry_point(asset_root, tmp_path, monkeypatch):
     """pose.pkl in -> grecon/<seq>_seed<k>.pkl out, with the reference's working-directory conventions (run_demo.py:44-82)."""
     import pickle
@@ -467,18 +545,19 @@ FULL_CFG_CASES = [(c, T, P, gap) for (c, T, P, _seed) in mg.FULL_CASES for gap i
 # camera optimised at lr 1e-2 under 1e4-weighted smoothness terms): 3.7 px / 8.0 px -- there is no single reference answer to match.
 FULL_FAMILY = {('glamr_dynamic_multi', True): True, ('glamr_h36m', False): False, ('glamr_h36m', True): False}
 # (keypoints px, root in the camera frame m, world root m, world orientation as a rotation, orientation seen from the camera, camera rotation,
-#  camera translation m): ~3 x the values achieved on the MI355X (in the comments).  None = not comparable: glamr_3dpw DERIVES the camera from
-# the person's world pose (flag_opt_cam_from_person_pose), so person and camera share a free world-frame gauge along the optical axis -- the
-# world root wanders by decimetres between two runs while everything SEEN FROM the camera (root_cam, orient_cam, the projections) agrees.
-FULL_TOL_GPU = {                                                              # achieved on the MI355X (round 3; orient_cam / cam: round 4)
-    ('glamr_3dpw', 1, False): (0.1, 1e-3, None, 5e-3, 5e-3, None, None),      # 0.030 px   2.5e-4 m   (1.5e-1 m)  1.4e-3
-    ('glamr_3dpw', 1, True): (0.1, 1e-3, None, 1e-2, 1e-2, None, None),       # 0.027 px   3.4e-4 m   (3.5e-1 m)  3.0e-3
-    ('glamr_dynamic_multi', 2, False): (0.01, 5e-5, 3e-5, 5e-5, 5e-5, 5e-5, 5e-5),      # 0.0016 px  8.6e-6 m   6.7e-6 m   1.4e-5
-    ('glamr_static_multi', 4, True): (0.05, 2e-4, 2e-4, 5e-4, 5e-4, 5e-4, 5e-4),        # 0.0147 px  5.4e-5 m   5.0e-5 m   1.5e-4   BASELINE configs[3]
-    ('glamr_static_multi', 4, False): (0.03, 2e-4, 2e-4, 5e-5, 1e-4, 1e-4, 2e-4),       # 0.0073 px  5.2e-5 m   4.7e-5 m   1.2e-5
-    ('glamr_static', 1, False): (0.01, 2e-5, 2e-5, 3e-4, 3e-4, 3e-4, 3e-4),             # 0.0027 px  2.9e-6 m   3.3e-6 m   8.1e-5
-    ('glamr_static', 1, True): (0.1, 6e-5, 2e-4, 6e-4, 6e-4, 6e-4, 6e-4),               # 0.0347 px  1.8e-5 m   6.1e-5 m   1.7e-4
+#  camera translation m): ~3 x the values achieved on the MI355X (in the comments).  None = not comparable (gauge, see below the table).
+FULL_TOL_GPU = {          # achieved on the MI355X (round 4):  kp px   root_cam m  root_world m  orient   orient_cam  cam_rot  cam_trans m
+    ('glamr_3dpw', 1, False): (0.1, 1e-3, None, None, 1e-4, None, None),                  # 0.030  2.5e-4  (1.6e-1)  (1.0e-2)  1.0e-6  (7.2e-3)  (1.4e-1)
+    ('glamr_3dpw', 1, True): (0.1, 1e-3, None, None, 1e-4, None, None),                   # 0.026  2.3e-4  (2.3e-1)  (4.5e-5)  1.0e-6  (4.5e-5)  (2.4e-1)
+    ('glamr_dynamic_multi', 2, False): (0.01, 5e-5, 3e-5, 5e-5, 5e-5, 1e-5, 5e-5),        # 0.0011 7.3e-6  6.7e-6  1.2e-5  1.2e-5  1.5e-6  1.4e-5
+    ('glamr_static_multi', 4, True): (0.06, 2e-4, 2e-4, 5e-4, 5e-4, 5e-6, 5e-6),          # 0.0195 5.4e-5  5.0e-5  1.3e-4  1.1e-4  1.8e-7  7.2e-7   BASELINE configs[3]
+    ('glamr_static_multi', 4, False): (0.03, 2e-4, 2e-4, 5e-5, 5e-5, 5e-6, 5e-6),         # 0.0072 5.3e-5  4.7e-5  7.1e-6  7.0e-6  1.8e-7  6.0e-7
+    ('glamr_static', 1, False): (0.01, 2e-5, 2e-5, 1e-4, 1e-4, 5e-6, 5e-6),               # 0.0008 3.8e-6  3.3e-6  1.9e-5  1.9e-5  2.4e-7  4.8e-7
+    ('glamr_static', 1, True): (0.1, 6e-5, 2e-4, 6e-4, 6e-4, 5e-5, 5e-6),                 # 0.0140 1.6e-5  4.8e-5  1.4e-4  1.3e-4  8.5e-6  2.1e-7
 }
+# glamr_3dpw DERIVES the camera from the person's world pose (flag_opt_cam_from_person_pose): person and camera share the world frame's gauge
+# (a rigid motion of both changes no residual but the weak regularisers), so between two runs the WORLD root / orientation / camera wander
+# by decimetres / 1e-2 (values in brackets) while everything seen FROM the camera -- root_cam, orient_cam, the projections -- agrees to 1e-6.
 
 
 @pytest.mark.parametrize('cfg_id,T,P,gap', FULL_CFG_CASES)
