@@ -95,6 +95,12 @@ _SIGNATURES = {
     'glamr_grecon_run_stage': (c_int, [POINTER(SceneBatch), POINTER(StageDesc), c_void_p, c_void_p, c_void_p]),
     'glamr_grecon_last_launch_ns': (c_int, [c_void_p, POINTER(ctypes.c_double)]),
     'glamr_adam_step': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
+    'glamr_adam_coef_table': (c_int, [c_double, c_int, c_void_p]),
+    'glamr_adam_step_indexed': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'glamr_counter_add': (c_int, [c_void_p, c_int, c_void_p]),
+    'glamr_eval_regress_joints': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'glamr_eval_procrustes': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'glamr_eval_heading_align': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 

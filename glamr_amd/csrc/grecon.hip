@@ -86,10 +86,13 @@ extern "C" int glamr_grecon_param_layout(int max_persons, int max_len, glamr_par
 constexpr size_t GLAMR_GRECON_WS_HEADER = 256;
 
 namespace {
-// stream of the last stage launch per workspace: glamr_grecon_last_launch_ns reads the stamps ON that stream (it waits for that stream's
-// work only, not for the device)
+// completion event of the last stage launch per workspace: glamr_grecon_last_launch_ns waits for THAT launch only, not for the device
 std::mutex g_ws_mu;
-std::map<const void*, hipStream_t> g_ws_stream;
+std::map<const void*, hipEvent_t> g_ws_event;      // (an EVENT, not the stream handle: the caller may destroy its stream; an event outlives it)
+void forget_workspaces_locked() {
+  for (auto& kv : g_ws_event) (void)hipEventDestroy(kv.second);
+  g_ws_event.clear();
+}
 int current_device() {
   int dev = 0;
   return hipGetDevice(&dev) == hipSuccess ? dev : 0;
@@ -232,9 +235,24 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   if (rc) return rc;
   GLAMR_HIP_CHECK(hipGetLastError());
   {
+    // completion event of this launch, per workspace (not under stream capture: a captured launch has no completion of its own, and
+    // glamr_grecon_last_launch_ns then falls back to a device-wide wait)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
     std::lock_guard<std::mutex> lock(g_ws_mu);
-    if (g_ws_stream.size() > 4096) g_ws_stream.clear();      // callers that never ask for the stamps
-    g_ws_stream[workspace] = stream;
+    if (cap == hipStreamCaptureStatusNone) {
+      if (g_ws_event.size() > 4096) forget_workspaces_locked();      // callers that never ask for the stamps
+      auto it = g_ws_event.find(workspace);
+      if (it == g_ws_event.end()) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) it = g_ws_event.emplace(workspace, ev).first;
+        else (void)hipGetLastError();
+      }
+      if (it != g_ws_event.end() && hipEventRecord(it->second, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(it->second); g_ws_event.erase(it); }
+    } else {
+      auto it = g_ws_event.find(workspace);
+      if (it != g_ws_event.end()) { (void)hipEventDestroy(it->second); g_ws_event.erase(it); }
+    }
   }
   return GLAMR_OK;
 }
@@ -257,6 +275,37 @@ extern "C" int glamr_adam_step(int n, float* params, float* exp_avg, float* exp_
   return GLAMR_OK;
 }
 
+// The same step with its number ON THE DEVICE: loops that are replayed as HIP graphs (the latent-optimisation mode's iteration) cannot carry
+// a per-iteration scalar in a kernel argument.  `coef` holds two floats per step, made on the host (Python's arithmetic: libm pow in double).
+__global__ void adam_step_indexed_kernel(int n, float* p, float* m, float* v, const float* g, const float* coef, const int32_t* step_index) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = *step_index;
+  const glamr::grecon::AdamCoef c{coef[2 * k], coef[2 * k + 1]};
+  if (i < n) glamr::grecon::adam(p[i], m[i], v[i], g[i], c);
+}
+__global__ void counter_add_kernel(int32_t* c, int value) { *c += value; }
+
+extern "C" int glamr_adam_coef_table(double lr, int n_steps, float* out_host) {
+  GLAMR_REQUIRE(out_host && n_steps > 0 && lr > 0.0, "bad argument");
+  for (int k = 0; k < n_steps; ++k) adam_coef_host(lr, k + 1, out_host + 2 * k);
+  return GLAMR_OK;
+}
+extern "C" int glamr_adam_step_indexed(int n, float* params, float* exp_avg, float* exp_avg_sq, const float* grad, const float* coef_table,
+                                       const int32_t* step_index, void* stream_) {
+  GLAMR_REQUIRE(n >= 0 && (n == 0 || (params && exp_avg && exp_avg_sq && grad)) && coef_table && step_index, "null argument");
+  if (n == 0) return GLAMR_OK;
+  hipLaunchKernelGGL(adam_step_indexed_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), n, params, exp_avg, exp_avg_sq, grad,
+                     coef_table, step_index);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+extern "C" int glamr_counter_add(int32_t* counter, int value, void* stream_) {
+  GLAMR_REQUIRE(counter, "null argument");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_), counter, value);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
 #ifdef GLAMR_PHASE_TIMING
 // development builds only: per-phase time of workgroup 0 in the last stage launch, in 10 ns ticks
 extern "C" int glamr_debug_phase_ticks(unsigned long long* out16) {
@@ -271,20 +320,18 @@ extern "C" int glamr_grecon_last_launch_ns(const void* workspace, double* ns) {
   unsigned long long st[2];
   // the stamps are read on the stream the launch ran on: this waits for the work of THAT stream, not for the device (a pipelined caller
   // keeps its other streams running).  A workspace this library has not seen a launch on falls back to a device-wide wait.
-  hipStream_t stream = nullptr;
-  bool known = false;
+  hipEvent_t ev = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_ws_mu);
-    auto it = g_ws_stream.find(workspace);
-    if (it != g_ws_stream.end()) { stream = it->second; known = true; }
+    auto it = g_ws_event.find(workspace);
+    if (it != g_ws_event.end()) ev = it->second;
   }
-  if (known && hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
-    // done
-  } else {
-    (void)hipGetLastError();                       // e.g. the stream has been destroyed since
+  // the launch's own completion event: waits for that launch, not for the device (a pipelined caller keeps its other streams running)
+  if (!(ev && hipEventSynchronize(ev) == hipSuccess)) {
+    (void)hipGetLastError();
     GLAMR_HIP_CHECK(hipDeviceSynchronize());
-    GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));
   }
+  GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));
   GLAMR_REQUIRE(st[0] != ~0ull, "no stage launch has completed on this workspace");
   *ns = st[1] > st[0] ? (double)(st[1] - st[0]) * 10.0 : 0.0;
   return GLAMR_OK;

@@ -1313,7 +1313,22 @@ extern "C" int glamr_nets_infill_taped(glamr_nets* h, int B, int max_len, const 
   tl_fp32 = h->fp32_only ? 1 : 0;
   tl_free = 0;
   Tape t = tape_layout(B, max_len, static_cast<char*>(tape_));
-  GLAMR_HIP_CHECK(hipMemcpyAsync(t.lens, lens_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  // (a caller capturing this stream -- the latent-optimisation mode replays its iteration as a HIP graph -- gets the lengths uploaded from
+  // the handle's pinned table, as glamr_nets_infer does: a copy node must not read pageable memory that is gone at replay)
+  const int32_t* lens_src = lens_host;
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) {
+      std::lock_guard<std::mutex> lock(h->graph_mu);
+      GLAMR_REQUIRE(h->capture_lens && h->capture_lens_used + (size_t)B <= CAPTURE_LENS_INTS,
+                    "the handle's table for calls recorded into caller graphs is full (%zu lengths); destroy and re-create the handle", CAPTURE_LENS_INTS);
+      int32_t* pinned = h->capture_lens + h->capture_lens_used;
+      h->capture_lens_used += (size_t)B;
+      std::memcpy(pinned, lens_host, (size_t)B * sizeof(int32_t));
+      lens_src = pinned;
+    }
+  }
+  GLAMR_HIP_CHECK(hipMemcpyAsync(t.lens, lens_src, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(pose_in_kernel, dim3(B, t.Tpad), dim3(64), 0, st, body_pose, max_len, t.Tpad, t.pose);
   for (int i = 0; i < n_win; ++i) {
     WinTape& w = t.win[i];

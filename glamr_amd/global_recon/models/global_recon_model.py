@@ -967,57 +967,108 @@ class GlobalReconOptimizer:
         lens = np.ascontiguousarray(rin.lens, dtype=np.int32)
         fr_start = packed.t['fr_start'].cpu().numpy()
         occupied = rin.seq_len_slot.cpu().numpy() > 0                    # (person slots a scene with fewer persons leaves empty are skipped)
-        rows = [(k, int(fr_start[k]), int(lens[k])) for k in range(n_slots) if occupied[k]]
+        # frame rows of the priors' outputs (row e of slot k = video frame fr_start[k] + e) <-> the per-slot video-frame arrays: ONE gather /
+        # scatter index for the whole batch instead of a python loop over the slots, twice per iteration
+        src, dst = [], []
+        for k in range(n_slots):
+            if occupied[k]:
+                nk, fs = int(lens[k]), int(fr_start[k])
+                src.append(k * T + np.arange(nk))
+                dst.append(k * T + fs + np.arange(nk))
+        src = torch.as_tensor(np.concatenate(src) if src else np.zeros(0, np.int64), device=dev)
+        dst = torch.as_tensor(np.concatenate(dst) if dst else np.zeros(0, np.int64), device=dev)
         smpl_h = self.smpl._handle(dev)
         zeros3 = torch.zeros((n_slots * T, 3), device=dev)
         packed.t['g_j_local'] = torch.zeros((n_slots, T, packing.NJ, 3), device=dev)
         params = packed.t['params']
-        m_lat, v_lat, lat_step = torch.zeros_like(meps), torch.zeros_like(meps), 0
+        m_lat, v_lat = torch.zeros_like(meps), torch.zeros_like(meps)
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        step_idx = torch.zeros(2, dtype=torch.int32, device=dev)         # [0] scene parameters, [1] latents: 0-based row of the coefficient table
         has_wd = False
+        use_graph = os.environ.get('GLAMR_LATENT_GRAPH', '1') != '0'
+        self.latent_graph_replays = 0
+
+        def iteration(spec, with_priors, first, coef):
+            """One Adam iteration (:547-570 in latent mode), launches only -- nothing here reads a value back or depends on the iteration
+            number except through `step_idx` on the device, so the same launch sequence is captured ONCE per stage and replayed."""
+            tape = None
+            if with_priors:
+                # infer_motion_traj with the current latents (:352-392)
+                pose_out, tape = h.infill_taped(pa['nets_pose'], pa['nets_vis'], lens, meps)
+                tr = h.infer(pose_out, None, lens, traj_eps=teps, infill=False, traj=True)
+                pa['smpl_pose'].view(-1, 69).index_copy_(0, dst, pose_out.view(-1, 69).index_select(0, src))
+                packed.t['traj_local_pred'].view(-1, 11).index_copy_(0, src, tr['local_traj'].view(-1, 11).index_select(0, src))
+                with torch.no_grad():
+                    jl = self.smpl(global_orient=zeros3, body_pose=pa['smpl_pose'].view(-1, 69), betas=pa['smpl_beta'].view(-1, 10), root_trans=zeros3,
+                                   return_verts=False).joints
+                if packed.t['j_local'].shape == (n_slots, T, packing.NJ, 3):
+                    packed.t['j_local'].copy_(jl.view(n_slots, T, packing.NJ, 3))          # (a fixed address: the gradient launch below is captured with it)
+                else:
+                    packed.t['j_local'] = jl.view(n_slots, T, packing.NJ, 3).clone()
+            sd = packing.stage_desc(spec, self.specs, has_wd, niters=1)
+            sd.lr = 0.0
+            if not first:
+                sd.flags |= packing.FLAG_KEEP_CAM_PARAMS
+            grads = parallel._device_run_stage(packed, sd, True)
+            g_lat = None
+            if tape is not None and self.flag_opt_motion_latent:
+                # dL/d j_local -> body pose (skinning, blend shapes, chain, re-anchoring in reverse) -> latents (all windows)
+                pose72 = torch.cat([zeros3, pa['smpl_pose'].view(-1, 69)], dim=1).contiguous()
+                g_pose = torch.empty((n_slots * T, 72), device=dev)
+                ws = torch.empty(L.glamr_smpl_backward_workspace_bytes(smpl_h, n_slots * T, 0), dtype=torch.uint8, device=dev)
+                _lib.check(L.glamr_smpl_backward(smpl_h, n_slots * T, _lib.ptr(pose72), _lib.ptr(pa['smpl_beta'].view(-1, 10)), _lib.ptr(zeros3), None, None, None,
+                                                 None, _lib.ptr(packed.t['g_j_local']), _lib.ptr(g_pose), None, None, None, 0, _lib.ptr(ws), _lib.current_stream()))
+                g_out = torch.zeros((n_slots * T, 69), device=dev)
+                g_out.index_copy_(0, src, g_pose[:, 3:].index_select(0, dst))
+                g_lat = h.infill_backward(tape, g_out.view(n_slots, T, 69))
+                # (a parameter's step count advances only when it has a gradient: the latents have their own index)
+                _lib.check(L.glamr_adam_step_indexed(meps.numel(), _lib.ptr(meps), _lib.ptr(m_lat), _lib.ptr(v_lat), _lib.ptr(g_lat), _lib.ptr(coef), _lib.ptr(step_idx[1:]),
+                                                     _lib.current_stream()))
+                _lib.check(L.glamr_counter_add(_lib.ptr(step_idx[1:]), 1, _lib.current_stream()))
+            _lib.check(L.glamr_adam_step_indexed(params.numel(), _lib.ptr(params), _lib.ptr(m), _lib.ptr(v), _lib.ptr(grads), _lib.ptr(coef), _lib.ptr(step_idx),
+                                                 _lib.current_stream()))
+            _lib.check(L.glamr_counter_add(_lib.ptr(step_idx), 1, _lib.current_stream()))
+            return g_lat
+
         for stage, spec in self.opt_stage_specs.items():
             n = spec['opt_niters'] if max_iters is None else min(max_iters, spec['opt_niters'])
             start = spec.get('opt_latent_start_iter', 0)                 # optimize() :581
-            m, v = torch.zeros_like(params), torch.zeros_like(params)
-            m_lat.zero_(); v_lat.zero_(); lat_step = 0                   # init_opt creates a fresh optimiser per stage (:635-644)
+            # init_opt creates a fresh optimiser per stage (:635-644): zero moments, step counts back to the first row of the stage's table
+            m.zero_(); v.zero_(); m_lat.zero_(); v_lat.zero_(); step_idx.zero_()
+            tab = np.empty(2 * max(n, 1), np.float32)
+            _lib.check(L.glamr_adam_coef_table(float(spec['opt_lr']), max(n, 1), tab.ctypes.data_as(ctypes.c_void_p)))
+            coef = torch.as_tensor(tab, device=dev)
+            graph = None
             for it in range(n):
-                tape = None
-                if it >= start:
-                    # infer_motion_traj with the current latents (:352-392)
-                    pose_out, tape = h.infill_taped(pa['nets_pose'], pa['nets_vis'], lens, meps)
-                    tr = h.infer(pose_out, None, lens, traj_eps=teps, infill=False, traj=True)
-                    for k, fs, nk in rows:
-                        pa['smpl_pose'][k, fs:fs + nk] = pose_out[k, :nk]
-                        packed.t['traj_local_pred'][k, :nk] = tr['local_traj'][k, :nk]
-                    with torch.no_grad():
-                        jl = self.smpl(global_orient=zeros3, body_pose=pa['smpl_pose'].view(-1, 69), betas=pa['smpl_beta'].view(-1, 10), root_trans=zeros3,
-                                       return_verts=False).joints
-                    packed.t['j_local'] = jl.view(n_slots, T, packing.NJ, 3)
-                sd = packing.stage_desc(spec, self.specs, has_wd, niters=1)
-                sd.lr = 0.0
-                if it > 0:
-                    sd.flags |= packing.FLAG_KEEP_CAM_PARAMS
-                grads = parallel._device_run_stage(packed, sd, True)
-                if tape is not None and self.flag_opt_motion_latent:
-                    # dL/d j_local -> body pose (skinning, blend shapes, chain, re-anchoring in reverse) -> latents (all windows)
-                    pose72 = torch.cat([zeros3, pa['smpl_pose'].view(-1, 69)], dim=1).contiguous()
-                    g_pose = torch.empty((n_slots * T, 72), device=dev)
-                    ws = torch.empty(L.glamr_smpl_backward_workspace_bytes(smpl_h, n_slots * T, 0), dtype=torch.uint8, device=dev)
-                    _lib.check(L.glamr_smpl_backward(smpl_h, n_slots * T, _lib.ptr(pose72), _lib.ptr(pa['smpl_beta'].view(-1, 10)), _lib.ptr(zeros3), None, None, None,
-                                                     None, _lib.ptr(packed.t['g_j_local']), _lib.ptr(g_pose), None, None, None, 0, _lib.ptr(ws), _lib.current_stream()))
-                    g_body = g_pose.view(n_slots, T, 72)[:, :, 3:]
-                    g_out = torch.zeros((n_slots, T, 69), device=dev)
-                    for k, fs, nk in rows:
-                        g_out[k, :nk] = g_body[k, fs:fs + nk]
-                    g_lat = h.infill_backward(tape, g_out)
-                    if getattr(self, 'latent_trace', None) is not None and not self.latent_trace:      # first gradient of the run, for the parity tests
-                        self.latent_trace.update(g_motion_latent=g_lat.detach().cpu().numpy(), losses=packed.t['losses'].detach().cpu().numpy(),
-                                                 smpl_pose=pa['smpl_pose'].detach().cpu().numpy(), traj_local_pred=packed.t['traj_local_pred'].detach().cpu().numpy())
-                    lat_step += 1
-                    parallel._device_adam_step(meps.view(-1), m_lat.view(-1), v_lat.view(-1), g_lat.view(-1), spec['opt_lr'], lat_step)
-                parallel._device_adam_step(params.view(-1), m.view(-1), v.view(-1), grads.view(-1), spec['opt_lr'], it + 1)
+                with_priors = it >= start
+                if graph is not None:
+                    graph.replay()
+                    self.latent_graph_replays += 1
+                    continue
+                g_lat = iteration(spec, with_priors, it == 0, coef)
+                if g_lat is not None and getattr(self, 'latent_trace', None) is not None and not self.latent_trace:      # first gradient of the run, for the parity tests
+                    self.latent_trace.update(g_motion_latent=g_lat.detach().cpu().numpy(), losses=packed.t['losses'].detach().cpu().numpy(),
+                                             smpl_pose=pa['smpl_pose'].detach().cpu().numpy(), traj_local_pred=packed.t['traj_local_pred'].detach().cpu().numpy())
+                # from here on every iteration of the stage is the same launch sequence: capture it once, replay it n - it - 2 times
+                if use_graph and with_priors and it >= 1 and n - it - 1 >= 2 and not torch.cuda.is_current_stream_capturing():
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        cur = torch.cuda.current_stream(dev)
+                        side = self.__dict__.setdefault('_latent_capture_stream', torch.cuda.Stream(device=dev))
+                        side.wait_stream(cur)
+                        with torch.cuda.graph(g, stream=side):
+                            iteration(spec, True, False, coef)
+                        cur.wait_stream(side)
+                        graph = g
+                    except Exception as e:      # noqa: BLE001 -- the plain launches are always available
+                        import sys
+                        sys.stderr.write('latent-optimisation mode: iteration graph not used (%s); plain launches\n' % e)
+                        torch.cuda.synchronize(dev)
+                        graph, use_graph = None, False
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
+            del graph
         packed.has_world_dheading = has_wd
         packed.stage_ws = []
         packed.latents = (meps, teps)

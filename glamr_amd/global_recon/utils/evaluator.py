@@ -2,17 +2,21 @@
 the per-frame sample metric -- the reference's `global_recon/utils/evaluator.py` with the same class, method and metric names
 (SURVEY.md 8f rank 1).
 
-What runs where: the four SMPL evaluations per person (ground truth and estimate, each in world coordinates and with the
-trajectory re-aligned to its heading every `align_freq` frames, evaluator.py:202-327) go through the HIP skinning kernel with
-vertices; the 17-joint H36M regression from the vertices is one library GEMM on the device; the per-chunk heading alignment
-(`convert_traj_world2heading`, traj_pred/utils/traj_utils.py:97-107), the Procrustes alignment (3x3 SVDs,
-lib/utils/torch_transform.py:282-345) and the metric reductions are a few hundred floats per frame and stay on the host.
+What runs where: everything per frame runs on the device through libglamr_hip.so -- the four SMPL evaluations per person (ground truth
+and estimate, each in world coordinates and with the trajectory re-aligned to its heading every `align_freq` frames,
+evaluator.py:202-327) on the HIP skinning kernel with vertices, the 17-joint H36M regression from the vertices
+(glamr_eval_regress_joints), the per-chunk heading alignment (glamr_eval_heading_align: `convert_traj_world2heading`,
+traj_pred/utils/traj_utils.py:97-107) and the Procrustes alignment (glamr_eval_procrustes: one 3x3 SVD per frame,
+lib/utils/torch_transform.py:282-345).  The host keeps the dictionaries and the final reductions of a few numbers per frame
+(means over frames, the min / mean over seeds).  The numpy twins (`convert_traj_world2heading`, `batch_compute_similarity_transform`)
+are kept as cross-checks for the tests.
 """
 from collections import defaultdict
 
 import numpy as np
 import torch
 
+from glamr_amd import _lib
 from glamr_amd.lib.models.smpl import SMPL, SMPL_MODEL_DIR
 from glamr_amd.lib.utils import np_transform as nt
 
@@ -198,25 +202,35 @@ class Evaluator:
         with torch.no_grad():
             out = self.smpl(global_orient=t(orient), body_pose=t(body_pose), betas=t(betas), root_trans=t(trans),
                             root_scale=None if scale is None else t(scale), return_full_pose=True)
-            j17 = torch.matmul(self.J_regressor, out.vertices)
-            return out.vertices.cpu().numpy(), j17[:, H36M_TO_J15].cpu().numpy(), out.joints.cpu().numpy()
+            verts = out.vertices.contiguous()
+            B, V = verts.shape[:2]
+            j17 = torch.empty((B, self.J_regressor.shape[0], 3), dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().glamr_eval_regress_joints(B, V, self.J_regressor.shape[0], _lib.ptr(verts), _lib.ptr(self.J_regressor), _lib.ptr(j17),
+                                                            _lib.current_stream()))
+            return verts.cpu().numpy(), j17[:, H36M_TO_J15].cpu().numpy(), out.joints.cpu().numpy()
 
-    # -- host part ------------------------------------------------------------------------------------------------------------------
+    # -- alignment (device kernels) + host bookkeeping ------------------------------------------------------------------------------------------------------------------
     def get_aligned_orient_trans(self, pose_dict):
         """evaluator.py:202-216: heading alignment in chunks of `align_freq` frames that overlap by one frame."""
-        orient_q = nt.aa_to_quat(_np(pose_dict['smpl_orient_world']).astype(np.float32))
-        trans = _np(pose_dict['root_trans_world']).astype(np.float32)
-        qs, ts = [], []
-        n = orient_q.shape[0]
-        for i in range(int(np.ceil(n / self.align_freq))):
-            sind = i * self.align_freq - int(i > 0)
-            eind = min((i + 1) * self.align_freq, n)
-            q, tr = convert_traj_world2heading(orient_q[sind:eind], trans[sind:eind], apply_base_orient_after=True)
-            qs.append(q[int(i > 0):])
-            ts.append(tr[int(i > 0):])
-        pose_dict['aligned_orient_q'] = np.concatenate(qs)
-        pose_dict['aligned_orient'] = nt.quat_to_aa(pose_dict['aligned_orient_q']).astype(np.float32)
-        pose_dict['aligned_trans'] = np.concatenate(ts)
+        dev = self.device
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(_np(a), dtype=np.float32), device=dev)
+        orient, trans = t(pose_dict['smpl_orient_world']), t(pose_dict['root_trans_world'])
+        n = orient.shape[0]
+        o_aa, o_tr, o_q = (torch.empty((n, k), dtype=torch.float32, device=dev) for k in (3, 3, 4))
+        _lib.check(_lib.lib().glamr_eval_heading_align(n, int(self.align_freq), _lib.ptr(orient), _lib.ptr(trans), _lib.ptr(o_aa), _lib.ptr(o_tr), _lib.ptr(o_q),
+                                                       _lib.current_stream()))
+        pose_dict['aligned_orient_q'] = o_q.cpu().numpy()
+        pose_dict['aligned_orient'] = o_aa.cpu().numpy()
+        pose_dict['aligned_trans'] = o_tr.cpu().numpy()
+
+    def procrustes(self, S1, S2):
+        """batch_compute_similarity_transform_torch (lib/utils/torch_transform.py:282-345) on the device: (N, J, 3) onto (N, J, 3)."""
+        dev = self.device
+        a = torch.as_tensor(np.ascontiguousarray(S1, dtype=np.float32), device=dev)
+        b = torch.as_tensor(np.ascontiguousarray(S2, dtype=np.float32), device=dev)
+        out = torch.empty_like(a)
+        _lib.check(_lib.lib().glamr_eval_procrustes(a.shape[0], a.shape[1], _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.current_stream()))
+        return out.cpu().numpy()
 
     def prepare_seq(self, data):
         use_keys = ['pose', 'pose_cam', 'root_trans', 'root_trans_cam', 'smpl_orient_cam', 'smpl_orient_world', 'smpl_pose', 'smpl_beta',
@@ -263,7 +277,7 @@ class Evaluator:
             pelvis = (j15[:, [3]] + j15[:, [4]]) * 0.5
             pd['eval_joints_world'], pd['eval_verts_world'] = j15[:, 1:] - pelvis, verts - pelvis
             self.get_aligned_orient_trans(pd)
-            pd['eval_joints_world_PA'] = batch_compute_similarity_transform(pd['eval_joints_world'], data['gt'][idx]['eval_joints_world'])
+            pd['eval_joints_world_PA'] = self.procrustes(pd['eval_joints_world'], data['gt'][idx]['eval_joints_world'])
             verts, j15, _ = self._smpl_eval(pd['aligned_orient'], args[0], args[1], pd['aligned_trans'], scale)
             pd['aligned_eval_joints_world'], pd['aligned_eval_verts_world'] = j15[:, 1:], verts
 

@@ -325,6 +325,15 @@ int glamr_grecon_last_launch_ns(const void* workspace, double* ns);
  * as Python does.  `step` is 1-based.  All arrays dev, n floats; params / exp_avg / exp_avg_sq are updated in place.  The parity
  * tests compare it bit for bit with torch.optim.Adam. */
 int glamr_adam_step(int n, float* params, float* exp_avg, float* exp_avg_sq, const float* grad, double lr, int step, void* stream);
+/* The same step with its number ON THE DEVICE, for loops replayed as HIP graphs (a captured launch cannot carry a per-iteration scalar):
+ * glamr_adam_coef_table fills, on the HOST, two floats per step 1 .. n_steps (-lr / (1 - 0.9^step), sqrt(1 - 0.999^step), formed in double
+ * with libm pow as Python does -- what glamr_adam_step computes per call); the caller uploads it.  glamr_adam_step_indexed takes the step
+ * `*step_index` (dev int32, 0-based row of the table: 0 = the first step) and leaves the index alone; glamr_counter_add advances it on the
+ * stream.  Replaces the per-iteration `optimizer.step()` of global_recon_model.py:561-565 inside a captured iteration. */
+int glamr_adam_coef_table(double lr, int n_steps, float* out_host);
+int glamr_adam_step_indexed(int n, float* params, float* exp_avg, float* exp_avg_sq, const float* grad, const float* coef_table,
+                            const int32_t* step_index, void* stream);
+int glamr_counter_add(int32_t* counter, int value, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------------------
@@ -399,6 +408,19 @@ int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_person_arrays*
                       const float* nets_local_traj, const float* nets_trans, const float* nets_orient, void* workspace, void* stream);
 /* init_cam_pose(all_frames=True) (:243-244) from the orient_world / trans_world of the last forward pass. */
 int glamr_init_cam_all_frames(const glamr_scene_batch* batch, void* stream);
+
+/* ---- evaluator pieces (global_recon/utils/evaluator.py:202-327).  All arrays dev, fp32. ----------------------------
+ * glamr_eval_regress_joints: joints (B, n_joints, 3) = regressor (n_joints, V) . verts (B, V, 3) -- `torch.matmul(self.J_regressor, vertices)` of
+ *   evaluator.py:262-263 with JOINT_REGRESSOR_H36M (lib/models/smpl.py:29); n_joints <= 32.
+ * glamr_eval_procrustes: every frame of S1 (n, n_joints, 3) aligned onto S2 by the least-squares similarity transform (scale, rotation,
+ *   translation; 3 x 3 SVD per frame, in double) -- batch_compute_similarity_transform_torch, lib/utils/torch_transform.py:282-345.
+ * glamr_eval_heading_align: get_aligned_orient_trans (evaluator.py:202-216): the trajectory (axis-angle orientation, translation; n frames) cut
+ *   in chunks of `align_freq` frames that overlap by one frame, each expressed in the heading frame of its first frame with that frame's xy as
+ *   origin (convert_traj_world2heading with apply_base_orient_after, traj_pred/utils/traj_utils.py:97-107).  aligned_orient_q (n, 4) may be NULL. */
+int glamr_eval_regress_joints(int B, int V, int n_joints, const float* verts, const float* regressor, float* joints, void* stream);
+int glamr_eval_procrustes(int n, int n_joints, const float* S1, const float* S2, float* S1_aligned, void* stream);
+int glamr_eval_heading_align(int n, int align_freq, const float* orient_aa, const float* trans, float* aligned_orient_aa, float* aligned_trans,
+                             float* aligned_orient_q, void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,43 +36,76 @@ def make_model(asset_root):
 @pytest.mark.parametrize('cfg_id,T,P,K', mg.LATENT_CASES)
 def test_latent_optimisation_matches_the_reference(make_model, golden, cfg_id, T, P, K):
     g = golden('grecon_latent_%s_T%d_P%d' % (cfg_id, T, P))
-    in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model())
+    in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model(), gap=mg.LATENT_GAP.get((cfg_id, T, P)))
     lat = mg.latents_for(in_dict, 3)
     model = make_model(cfg_id, flag_opt_motion_latent=True, flag_opt_traj_latent=True)
     model.latent_trace = {}
     out = model.optimize(in_dict, latents=lat, max_iters=K)
     tr = model.latent_trace
     stage = next(iter(model.opt_stage_specs))
-    # first iteration: what the re-run priors produce, and the gradient that reaches the motion latent
-    n = int(g['init_p0_exist_len'])
-    assert np.abs(tr['smpl_pose'][0, :T] - g['%s_fwd_p0_smpl_pose' % stage]).max() < 1e-4
-    assert np.abs(tr['traj_local_pred'][0, :n] - g['%s_fwd_p0_traj_local_pred' % stage]).max() < 1e-4
-    ref = g['%s_grad_p0_motion_latent' % stage]
-    got = tr['g_motion_latent'][0, :ref.shape[0]]
-    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
-    print('%s T=%d: d loss / d motion_latent, first iteration: relative error %.2e (largest %.3g); traj_latent: gradient None in the reference = %s'
-          % (cfg_id, T, err, np.abs(ref).max(), bool(g['%s_gradnone_p0_traj_latent' % stage])))
-    assert err < 1e-3
-    assert bool(g['%s_gradnone_p0_traj_latent' % stage])
-    # after K iterations of every stage
-    pd = out['person_data'][0]
-    vis = g['init_p0_vis_frames']
-    e_lat = np.abs(pd['motion_latent'] - g['opt_p0_motion_latent']).max()
-    e_pose = np.abs(pd['smpl_pose'] - g['opt_p0_smpl_pose']).max()
-    e_kp = kp_err(pd['kp_2d_pred'], g['opt_p0_kp_2d_pred'], vis)
-    e_tr = np.abs(pd['root_trans_world'] - g['opt_p0_root_trans_world']).max()
-    print('after %d iterations per stage: motion_latent %.2e (moved %.2e), smpl_pose %.2e, kp_2d_pred %.3f px, root_trans_world %.2e'
-          % (K, e_lat, np.abs(g['opt_p0_motion_latent'] - lat[0]['motion']).max(), e_pose, e_kp, e_tr))
-    assert np.array_equal(pd['traj_latent'], lat[0]['traj'])                      # never updated: its gradient is None, Adam skips it
-    assert np.abs(g['opt_p0_traj_latent'] - lat[0]['traj']).max() == 0.0           # ... in the reference too
-    assert np.abs(g['opt_p0_motion_latent'] - lat[0]['motion']).max() > 1e-3       # the motion latent did move
     tol = LATENT_TOL[(cfg_id, T)]
-    assert e_lat < tol[0] and e_pose < tol[1] and e_kp < tol[2] and e_tr < tol[3]
+    for pi in range(P):
+        # first iteration: what the re-run priors produce, and the gradient that reaches the motion latent (in glamr_dynamic_multi's first
+        # stage it is EXACTLY zero in the reference: the only active term there is the first visible frame's reprojection, frame 0 is one of
+        # the ten context frames the infiller copies through -- and zero it must be here)
+        n = int(g['init_p%d_exist_len' % pi])
+        fs = int(g['init_p%d_fr_start' % pi])
+        assert np.abs(tr['smpl_pose'][pi, :T] - g['%s_fwd_p%d_smpl_pose' % (stage, pi)]).max() < 1e-4
+        assert np.abs(tr['traj_local_pred'][pi, :n] - g['%s_fwd_p%d_traj_local_pred' % (stage, pi)]).max() < 1e-4
+        ref = g['%s_grad_p%d_motion_latent' % (stage, pi)]
+        got = tr['g_motion_latent'][pi, :ref.shape[0]]
+        err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        print('%s T=%d person %d (frames %d..%d): d loss / d motion_latent, first iteration: relative error %.2e (largest %.3g); traj_latent: gradient None in the reference = %s'
+              % (cfg_id, T, pi, fs, fs + n, err, np.abs(ref).max(), bool(g['%s_gradnone_p%d_traj_latent' % (stage, pi)])))
+        assert err < 1e-3
+        assert bool(g['%s_gradnone_p%d_traj_latent' % (stage, pi)])
+        # after K iterations of every stage
+        pd = out['person_data'][pi]
+        vis = g['init_p%d_vis_frames' % pi]
+        e_lat = np.abs(pd['motion_latent'] - g['opt_p%d_motion_latent' % pi]).max()
+        e_pose = np.abs(pd['smpl_pose'] - g['opt_p%d_smpl_pose' % pi]).max()
+        e_kp = kp_err(pd['kp_2d_pred'], g['opt_p%d_kp_2d_pred' % pi], vis)
+        e_tr = np.abs(pd['root_trans_world'] - g['opt_p%d_root_trans_world' % pi]).max()
+        moved = np.abs(g['opt_p%d_motion_latent' % pi] - lat[pi]['motion']).max()
+        print('after %d iterations per stage: motion_latent %.2e (moved %.2e), smpl_pose %.2e, kp_2d_pred %.3f px, root_trans_world %.2e'
+              % (K, e_lat, moved, e_pose, e_kp, e_tr))
+        assert np.array_equal(pd['traj_latent'], lat[pi]['traj'])                      # never updated: its gradient is None, Adam skips it
+        assert np.abs(g['opt_p%d_traj_latent' % pi] - lat[pi]['traj']).max() == 0.0     # ... in the reference too
+        assert moved > tol[4]                                                          # the motion latent did move
+        assert e_lat < tol[0] and e_pose < tol[1] and e_kp < tol[2] and e_tr < tol[3]
 
 
 # (motion_latent, smpl_pose rad, projected keypoints px, root_trans_world m) after K iterations per stage
-LATENT_TOL = {('glamr_dynamic', 100): (1e-4, 1e-5, 0.1, 1e-4),       # achieved 3.4e-6 (moved 1.2e-2), 6.2e-8, 0.013 px, 2.4e-7
-              ('glamr_static', 130): (1e-4, 1e-5, 0.1, 1e-4)}        #          1.4e-6 (moved 8.1e-3), 5.7e-8, 0.012 px, 4.2e-6
+# + how far the latent must have moved in the reference (a case whose latent stays put would test nothing)
+LATENT_TOL = {('glamr_dynamic', 100): (1e-4, 1e-5, 0.1, 1e-4, 1e-3),       # achieved 3.4e-6 (moved 1.2e-2), 6.2e-8, 0.013 px, 2.4e-7
+              ('glamr_static', 130): (1e-4, 1e-5, 0.1, 1e-4, 1e-3),        #          1.4e-6 (moved 8.1e-3), 5.7e-8, 0.012 px, 4.2e-6
+              ('glamr_dynamic_multi', 90): (1e-4, 1e-5, 0.1, 1e-4, 2e-4)}  # two persons, 5 iterations per stage (main stage lr 1e-4)
+
+
+def test_iteration_graph_equals_plain_launches(make_model, monkeypatch):
+    """From the second iteration of a stage on, the mode replays ONE captured HIP graph per iteration (taped infiller, trajectory predictor,
+    skinning, gradient launch, SMPL backward, infiller backward, two Adam steps with their step numbers on the device).  Same launches, same
+    buffers: the result must equal the plain launch-by-launch schedule (GLAMR_LATENT_GRAPH=0) to the bit -- with two persons whose existence
+    ranges differ (ragged fr_start: the gather / scatter between the priors' rows and the video-frame arrays), and the graph must have been used."""
+    from tests.test_e2e_gpu import _trim_person
+    md = synth.make_smpl_model()
+    in_dict = _trim_person(synth.make_in_dict(seed=12, num_frames=100, num_persons=2, smpl_model=md), 1, 13, 91)
+    lat = mg.latents_for(in_dict, 12)
+    K = 7
+    model = make_model('glamr_dynamic_multi', flag_opt_motion_latent=True, flag_opt_traj_latent=True)
+    out_g = model.optimize(in_dict, latents=lat, max_iters=K)
+    n_stages = len(model.opt_stage_specs)
+    assert model.latent_graph_replays == n_stages * (K - 2), model.latent_graph_replays      # iterations 0 and 1 of every stage are plain launches
+    monkeypatch.setenv('GLAMR_LATENT_GRAPH', '0')
+    model_p = make_model('glamr_dynamic_multi', flag_opt_motion_latent=True, flag_opt_traj_latent=True)
+    out_p = model_p.optimize(in_dict, latents=lat, max_iters=K)
+    assert model_p.latent_graph_replays == 0
+    for idx in (0, 1):
+        a, b = out_g['person_data'][idx], out_p['person_data'][idx]
+        for key in ('motion_latent', 'smpl_pose', 'kp_2d_pred', 'root_trans_world', 'smpl_orient_world', 'traj_local_pred'):
+            assert np.array_equal(a[key], b[key]), (idx, key)
+        assert np.abs(a['motion_latent'] - lat[idx]['motion']).max() > 1e-4          # the latents did move
+    assert np.array_equal(out_g['cam_pose'], out_p['cam_pose'])
 
 
 def test_shipped_configs_are_unaffected_and_flags_are_read(make_model):

@@ -76,7 +76,7 @@ def _inputs(kind, rng, n=400):
 def test_forward_and_backward_match_autograd(name):
     lib = hostsim.build('rotmath_shim')
     nin, nout, fn, kind = CASES[name]
-    rng = np.random.default_rng(hash(name) % 1000)
+    rng = np.random.default_rng(sum(map(ord, name)) % 1000)          # (not hash(name): Python randomises string hashes per process -- one run in a few dozen drew an ill-conditioned input)
     x = _inputs(kind, rng)
     gout = rng.normal(size=(x.shape[0], nout)).astype(np.float32)
     out, gx = _call(lib, name, x, gout, nout)

@@ -13,6 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+DATA_SEED = int(os.environ.get('GLAMR_TRACE_DATA_SEED', '0'))      # seed of the synthetic sequence (and of its latent draws)
+
 
 def reference_init(which):
     from oracle import ref_harness as rh
@@ -20,9 +22,9 @@ def reference_init(which):
     from glamr_amd.utils import synth
     rh.setup()
     model, cfg = rh.reference_optimizer('glamr_dynamic', log=rh.QuietLog())
-    in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=synth.make_smpl_model(), gap=None if which == 'gap' else (0, 0))
+    in_dict = synth.make_in_dict(seed=DATA_SEED, num_frames=300, num_persons=1, smpl_model=synth.make_smpl_model(), gap=None if which == 'gap' else (0, 0))
     specs = {}          # no stage: init_data only
-    data, _ = mg.run_reference(model, specs, in_dict, mg.latents_for(in_dict, 0))
+    data, _ = mg.run_reference(model, specs, in_dict, mg.latents_for(in_dict, DATA_SEED))
     return model, data, in_dict
 
 

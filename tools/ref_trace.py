@@ -1,5 +1,5 @@
 """DEVELOPMENT AID (build container only: needs /root/reference).  Runs the UNMODIFIED reference on the 300-frame sequence of
-BASELINE.json configs[1] and records, for every Adam iteration, the parameter values after the step and the gradients the step
+BASELINE.json configs[1] (GLAMR_TRACE_DATA_SEED selects the synthetic sequence, default 0) and records, for every Adam iteration, the parameter values after the step and the gradients the step
 used, so a kernel trajectory can be compared with it iteration by iteration (tools/diverge_probe.py).
 
     python tools/ref_trace.py [gap|nogap] [out.npz] [--threads N] [--eps E --seed S]
@@ -9,6 +9,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+
+DATA_SEED = int(os.environ.get('GLAMR_TRACE_DATA_SEED', '0'))      # seed of the synthetic sequence (and of its latent draws)
 
 
 def main(argv):
@@ -34,7 +36,7 @@ def main(argv):
             trace['g'].append(np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).numpy().ravel() for p in ps]))
 
     model, cfg = rh.reference_optimizer('glamr_dynamic', log=Log())
-    in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=synth.make_smpl_model(), gap=None if which == 'gap' else (0, 0))
+    in_dict = synth.make_in_dict(seed=DATA_SEED, num_frames=300, num_persons=1, smpl_model=synth.make_smpl_model(), gap=None if which == 'gap' else (0, 0))
     keep = model.init_opt
 
     def init_opt(data, opt_variables, opt_lr):
@@ -49,7 +51,7 @@ def main(argv):
         trace['p0'] = np.concatenate([p.detach().numpy().ravel() for p in param_list])
         return optimizer, param_list
     model.init_opt = init_opt
-    data, init_state = mg.run_reference(model, cfg.opt_stage_specs, in_dict, mg.latents_for(in_dict, 0))
+    data, init_state = mg.run_reference(model, cfg.opt_stage_specs, in_dict, mg.latents_for(in_dict, DATA_SEED))
     fin = mg._flatten_state(data, mg.PERSON_KEYS_OPT + ['vis_frames'], mg.TOP_KEYS)
     np.savez_compressed(out, p=np.stack(trace['p']), g=np.stack(trace['g']), p0=trace['p0'], names=np.array(trace['names']),
                         sizes=np.array([int(np.prod(s)) for s in trace['shapes']]), **{'fin_' + k: v for k, v in fin.items()})
