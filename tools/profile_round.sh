@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python -m pytest $R/tests -m gpu -q 2>&1 | grep -E "passed|failed" > $R/gpurun_out/r04_gputest.log
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $R/bench.py --streams 1 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-lines --no-host-stream > $R/gpurun_out/r04_bench_b1024_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $R/bench.py --streams 1 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-lines --no-host-stream --no-strong-line > $R/gpurun_out/r04_bench_b1024_under_rocprof.json 2>/dev/null
 cp $(ls /tmp/prof_bench/*/*kernel_stats.csv | head -1) $R/gpurun_out/r04_bench_b1024_kernel_stats.csv
 # the co-scheduled two-stream pipeline (the headline configuration): what every kernel takes THERE
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cos -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-lines > $R/gpurun_out/r04_bench_coscheduled_under_rocprof.json 2>/dev/null < /dev/null
