@@ -23,6 +23,7 @@
 // reads CONTIGUOUS k and operands can be fetched 16 bytes at a time.  Accumulator register r of lane l is
 // element (row = (r & 3) + 8 (r >> 2) + 4 (l >> 5), col = l & 31).
 #include "common.hpp"
+#include "rotmath.hpp"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -105,7 +106,11 @@ __device__ __forceinline__ void rodrigues_smplx(const float r[3], float R[9]) {
   const float angle = sqrtf(ax * ax + ay * ay + az * az);
   const float inv = 1.0f / angle;
   const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
-  const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+  // (rm::sincos_: Cody-Waite reduction + minimax polynomials, 1.5 ulp, ~30 instructions for both; the device library's sinf + cosf carry a
+  // Payne-Hanek large-argument path each -- the prep kernel evaluates 24 of these per frame)
+  float s, cs;
+  rm::sincos_(angle, s, cs);
+  const float c1 = 1.0f - cs;
   // K = [[0,-z,y],[z,0,-x],[-y,x,0]],  K^2 = [[-(y^2+z^2), xy, xz],[xy, -(x^2+z^2), yz],[xz, yz, -(x^2+y^2)]]
   R[0] = 1.0f + c1 * (-(y * y + z * z));
   R[1] = s * (-z) + c1 * (x * y);
@@ -124,7 +129,9 @@ __device__ __forceinline__ void rodrigues_smplx_bwd(const float r[3], const floa
   const float ax = r[0] + 1e-8f, ay = r[1] + 1e-8f, az = r[2] + 1e-8f;
   const float angle = sqrtf(ax * ax + ay * ay + az * az), inv = 1.0f / angle;
   const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
-  const float s = sinf(angle), c = cosf(angle), c1 = 1.0f - c;
+  float s, c;
+  rm::sincos_(angle, s, c);
+  const float c1 = 1.0f - c;
   // R = I + s K + c1 K2
   const float K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
   const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
@@ -1174,19 +1181,21 @@ SmplWs smpl_ws_layout(const glamr_smpl* h, int B, char* base) {
 }
 }  // namespace
 
-// Frame tiles are split over gridDim.y.  The split decides two things: how evenly the frame tiles fall on the (waves x chunks) wave slots of a
-// vertex tile, and how full the last round of workgroups leaves the 256 CUs (one workgroup per CU: the direction tile fills its LDS).
-// 216 vertex tiles x 5 chunks = 1080 workgroups were 4.2 rounds -- a fifth round at 22 % occupancy; 15 chunks = 12.7 rounds (97 %) with the
-// 600 frame tiles of B = 19 200 still 5 per wave.  Every workgroup re-stages its 87 KB direction tile, so a wave keeps >= 3 frame tiles.
+// Frame tiles are split over gridDim.y.  The split decides how evenly the frame tiles fall on the (waves x chunks) wave slots of a vertex tile,
+// how full the last round of workgroups leaves the 256 CUs (one workgroup per CU: the direction tile fills its LDS), and how often the 87 KB
+// direction tile is re-staged (about a third of a tile's time).  Cost model, in units of one (vertex tile, frame tile) pair:
+//   rounds x (0.35 + frame tiles per wave).
+// 216 vertex tiles x 5 chunks = 1080 workgroups were 4.2 rounds of 15 tiles -- a fifth round at 22 % occupancy; 15 chunks = 12.7 rounds of 5.
+// The 3-tile joints pass of a 300-frame call gets 2 chunks (one tile per wave instead of two in sequence on three CUs).
 static int lbs_frame_chunks(int n_tiles, int n_ftiles, int nw) {
   const int cus = 256;
   int best = 1;
-  double best_eff = 0.0;
-  for (int gy = 1; gy <= std::max(1, n_ftiles / (3 * nw)); ++gy) {
-    const int wgs = n_tiles * gy, rounds = (wgs + cus - 1) / cus;
+  double best_cost = 1e300;
+  for (int gy = 1; gy <= std::max(1, (n_ftiles + nw - 1) / nw); ++gy) {
+    const int rounds = (n_tiles * gy + cus - 1) / cus;
     const int per_wave = (n_ftiles + nw * gy - 1) / (nw * gy);
-    const double eff = ((double)wgs / (rounds * cus)) * ((double)n_ftiles / ((double)per_wave * nw * gy));
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = gy; }
+    const double cost = rounds * (0.35 + per_wave);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = gy; }
   }
   return best;
 }
