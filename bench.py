@@ -664,7 +664,7 @@ def run(argv=None):
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
                        'streams_per_gpu': len(streams), 'step_graph': bool(step_graphs), 'coscheduled_streams': bool(coschedule)},
             'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'latency/issue',
-                         'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration: neither HBM nor the matrix pipes limit it. '
+                         'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration, bound by the dependent chain of one wave (3, 4 or 5 waves per scene take the same time: profiles/r04_stage_iteration_vs_waves.log): neither HBM nor the matrix pipes limit it. '
                                        'achieved / peak / frac are SURVEY 8(d) K5\'s yardstick: microseconds per scene-iteration against the 1.45 us dependent-boundary floor '
                                        "(frac = floor / achieved).  The contract's hbm line is kept under `contract_notional` and is NOTIONAL",
                          'achieved': us_scene_iter, 'peak': DEPENDENT_BOUNDARY_US, 'unit': 'us per scene-iteration (lower is better; peak = dependent-boundary floor)',

@@ -577,7 +577,10 @@ class GlobalReconOptimizer:
     def check_inputs(self, rin):
         """Raises WireFormatError for the first person whose uploaded arrays failed the value checks (one small device->host copy)."""
         if getattr(rin, 'verdict', None) is None:
-            return
+            if getattr(rin, 'validate', False) and not torch.cuda.is_current_stream_capturing():
+                self.value_checks(rin)                                  # a batch nobody has checked yet (its only uses so far were graph replays)
+            if getattr(rin, 'verdict', None) is None:
+                return
         from glamr_amd.utils import wire
         rin.verdict_ready.synchronize()                                 # computed on the stream that consumed the batch
         v = rin.verdict.cpu().numpy()
@@ -891,7 +894,10 @@ class GlobalReconOptimizer:
         before (allocations, one-time attribute calls).  check=True replays once against a plain step with the same seed and requires the
         projections to agree bit for bit (RuntimeError otherwise).  Results live in graph.packed (collect() them after a replay)."""
         if self.latent_mode:
-            raise NotImplementedError('the latent-optimisation schedule is host-orchestrated and cannot be captured')
+            raise NotImplementedError('the latent-optimisation schedule captures its own graph per iteration (run_latent_schedule); the whole step is not capturable')
+        # the value checks of the wire format run once per batch, outside a capture (init_resident skips them while capturing): a batch whose
+        # FIRST use is this capture is checked here -- the verdict surfaces in collect() / check_inputs() as usual
+        self.value_checks(rin)
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         if st == torch.cuda.default_stream(self.device):
             st = torch.cuda.Stream(device=self.device)               # the legacy default stream cannot be captured
@@ -915,6 +921,15 @@ class GlobalReconOptimizer:
                 self._capture_split = split
                 try:
                     datas, packed = self.optimize_resident(rin, max_iters)
+                except BaseException:
+                    # leave the stream out of capture mode whatever happened: whichever of the two graphs is capturing is ended and dropped
+                    # (a stream stuck in a broken capture fails every later launch -- bench.py's fall-back to plain launches included)
+                    for gph in (tail, graph):
+                        try:
+                            gph.capture_end()
+                        except Exception:      # noqa: BLE001 -- not capturing / already invalidated
+                            pass
+                    raise
                 finally:
                     self._capture_split = None
                 tail.capture_end()
@@ -947,10 +962,11 @@ class GlobalReconOptimizer:
         reaches `motion_latent` through the reprojection term -> joints -> SMPL (body pose) -> infiller (all windows, autoregressively).
         `traj_latent` is in the parameter list but never receives a gradient: get_pred_trajectory_base detaches traj_local_pred (:396), and
         torch.optim.Adam skips a parameter whose grad is None -- its value stays, exactly as in the reference.
-        Launch by launch over the C ABI: taped infiller (glamr_nets_infill_taped), trajectory predictor (glamr_nets_infer), joints-only
+        Per iteration over the C ABI: taped infiller (glamr_nets_infill_taped), trajectory predictor (glamr_nets_infer), joints-only
         skinning, one gradient launch of the stage kernel (niters 1, lr 0, grads_out, g_j_local), glamr_smpl_backward, glamr_nets_infill_backward,
-        glamr_adam_step on the scene parameters and on the latents (torch.optim.Adam's arithmetic; a parameter's step count advances only
-        when it has a gradient)."""
+        glamr_adam_step_indexed on the scene parameters and on the latents (torch.optim.Adam's arithmetic; a parameter's step count advances only
+        when it has a gradient: two indices on the device).  The first two iterations of a stage are plain launches; the third is CAPTURED as a HIP
+        graph and the rest of the stage replays it (GLAMR_LATENT_GRAPH=0: plain launches throughout; self.latent_graph_replays counts)."""
         import ctypes
         from ... import parallel
         dev, L = self.device, _lib.lib()
