@@ -585,6 +585,12 @@ def run(argv=None):
             torch.cuda.synchronize()
             kms.extend(model.launch_ms(ws) for ws in packed.stage_ws)
     # host dictionaries in -> host dictionaries out, for the record (never `value`): one call, and the pipelined stream of batches
+    # (the FIRST call on a stream nothing ran on before pays hipMalloc for the whole working set -- the caching allocator's pools are per stream
+    # -- and page-locks a 353 MB staging set: reported apart; `single_call` is the call after it, what a caller looping over batches sees)
+    t0 = time.time()
+    model.optimize_batch(in_dicts)
+    host_first = time.time() - t0
+    model.optimize_batch(in_dicts)
     t0 = time.time()
     model.optimize_batch(in_dicts)
     host_single = time.time() - t0
@@ -595,7 +601,7 @@ def run(argv=None):
         # 400 MB each: a one-off ~100 ms the 6-batch figure of rounds 1-2 carried); the timed pass re-uses them
         for _ in model.optimize_stream([in_dicts] * 4):
             pass
-        nb = 12
+        nb = 24                                                          # (fill and drain of the three-deep pipeline are inside the figure)
         t0 = time.time()
         n_out = sum(len(r) for r in model.optimize_stream([in_dicts] * nb))
         host_stream = n_out / (time.time() - t0)
@@ -695,6 +701,7 @@ def run(argv=None):
             'latency_one_sequence_ms': latency,
             'host_inclusive_sequences_per_sec': host_stream if host_stream is not None else B / host_single,
             'host_inclusive_single_call_sequences_per_sec': B / host_single,
+            'host_inclusive_first_call_on_a_new_stream_sequences_per_sec': B / host_first,
             'host_inclusive_stage_seconds': {k: round(v, 4) for k, v in tm.items()},
         }
         if strong is not None:

@@ -437,7 +437,7 @@ class GlobalReconOptimizer:
         cur = pool['sets'][i]
         widths = dict(exist=0, rot=216, betas=10, trans=3, kp=48, K=9)
         if cur is None or cur['shape'] != (n_slots, T):
-            mk = lambda w: torch.zeros((n_slots, T, w) if w else (n_slots, T), dtype=torch.float32).pin_memory()
+            mk = lambda w: torch.empty((n_slots, T, w) if w else (n_slots, T), dtype=torch.float32, pin_memory=True).zero_()
             cur = {'shape': (n_slots, T), 't': {k: mk(w) for k, w in widths.items()}, 'event': None}
             cur['np'] = {k: v.numpy() for k, v in cur['t'].items()}
             pool['sets'][i] = cur
@@ -1131,11 +1131,13 @@ class GlobalReconOptimizer:
         dev = self.device
         # consecutive batches alternate over two compute streams (the launch seams and tails of one batch are covered by the next, as in bench.py)
         computes = self.__dict__.setdefault('_compute_streams', [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
-        # A batch's upload goes on ITS OWN compute stream (enqueued while the previous batch computes on the other one: the copy engines run it
-        # right away), downloads on a third stream.  Not more: the runtime multiplexes HIP streams onto 4 hardware queues, and with a separate
-        # upload stream (5 streams with the default one) two of them shared a queue -- a batch then started only when the previous one had
-        # finished (tools/stream_timeline.py).  (One copy stream for both directions was worse still: the upload of batch i + 1 queued behind
-        # the download of batch i, which waits for batch i's compute.)
+        # Uploads and downloads share ONE third stream.  Not more: the runtime multiplexes HIP streams onto 4 hardware queues, and with a
+        # separate upload stream (5 streams with the default one) two of them shared a queue -- a batch then started only when the previous one
+        # had finished (tools/stream_timeline.py; raising GPU_MAX_HW_QUEUES to 8, three compute streams and the default stream as the uploader
+        # were all measured slower, round 4).  Rounds 2-3 put a batch's upload on ITS OWN compute stream: there it queues behind the batch
+        # before last, so every batch began with 7 ms of PCIe and nothing else (50.5 ms from batch to batch against 43.4 resident).  On the
+        # copy stream the order of the enqueues is what matters: a download waits for its batch's event, and an upload enqueued behind it
+        # waits too -- _stream_loop enqueues a batch's download only when the upload of the batch two later is already in the queue.
         down = self.__dict__.setdefault('_download_stream', torch.cuda.Stream(device=dev))
         it = iter(batches)
         lat = iter(latents) if latents is not None else None
@@ -1144,36 +1146,55 @@ class GlobalReconOptimizer:
         own_gate = self.pipeline_gate is None and not self.latent_mode and coschedule_enabled()
         if own_gate:
             self.pipeline_gate = PipelineGate()
+        # The interpreter's cyclic collector: a full collection walks every container object alive -- with torch imported, 30-45 ms -- and the
+        # ~10 000 containers a batch of output dictionaries is made of trigger one every 5-6 batches (measured: every fifth yield 85-110 ms late,
+        # tools/stream_yield_probe.py).  While the stream runs, everything alive at its start sits in the permanent generation (gc.freeze):
+        # collections still run, over the objects created since.  GLAMR_STREAM_GC_FREEZE=0 leaves the collector alone.
+        import gc
+        frozen = gc.isenabled() and os.environ.get('GLAMR_STREAM_GC_FREEZE', '1') != '0'
+        if frozen:
+            gc.collect()
+            gc.freeze()
         try:
             yield from self._stream_loop(it, lat, turn, computes, down, max_iters)
         finally:
+            if frozen:
+                gc.unfreeze()
             if own_gate:
                 self.pipeline_gate = None
 
     def _stream_loop(self, it, lat, turn, computes, down, max_iters):
+        """Host iteration k: enqueue batch k's device work -> scatter + upload batch k + 1 -> enqueue the download of batch k - 2 -> cut batch
+        k - 2's dictionaries (the only wait: until that download has landed).  Three batches are in flight, so a batch's launches are queued
+        BEFORE its compute stream comes free (the batch before last still runs there) and its inputs were uploaded a batch time earlier."""
         def stage(batch):
-            with torch.cuda.stream(computes[turn[0] % len(computes)]):
+            with torch.cuda.stream(down):
                 return self.stage_inputs(batch, next(lat) if lat is not None else None)
+
+        def fetch(entry):
+            datas, packed, done = entry
+            down.wait_event(done)
+            return datas, packed, self._fetch_async(packed, down)
         nxt = next(it, None)
         if nxt is None:
             return
         rin = stage(nxt)
-        prev = None
+        flight = []                                                     # batches whose download has not been enqueued yet, oldest first
         while rin is not None:
             compute = computes[turn[0] % len(computes)]
             turn[0] += 1
+            compute.wait_event(rin.upload_done)
             with torch.cuda.stream(compute):
                 datas, packed = self.optimize_resident(rin, max_iters) if self.latent_mode else self._resident_for_stream(rin, max_iters)
                 done = torch.cuda.Event()
                 done.record()
-            down.wait_event(done)
-            fetched = self._fetch_async(packed, down)                  # queued behind this batch only
+            flight.append((datas, packed, done))
             nxt = next(it, None)
-            rin = stage(nxt) if nxt is not None else None              # host work under the device's
-            if prev is not None:
-                yield self.collect(*prev)
-            prev = (datas, packed, fetched)
-        yield self.collect(*prev)
+            rin = stage(nxt) if nxt is not None else None              # host work under the device's; the copy stream is idle now
+            if len(flight) > 2:
+                yield self.collect(*fetch(flight.pop(0)))              # (enqueued only now: a download waiting for its batch must not sit in front of that upload)
+        while flight:
+            yield self.collect(*fetch(flight.pop(0)))
 
     def _resident_for_stream(self, rin, max_iters):
         datas, packed = self.init_resident(rin, init_forward=not self._schedule_overwrites_init())

@@ -1,5 +1,5 @@
-"""DEVELOPMENT AID (GPU): the pipelined host path (optimize_stream) batch by batch with host timestamps and device events: where a batch's
-72 ms go when the device work is 51-55 ms."""
+"""DEVELOPMENT AID (GPU): the pipelined host path (optimize_stream) batch by batch with host timestamps and device events: the loop of
+GlobalReconOptimizer._stream_loop spelled out."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,34 +19,35 @@ now = lambda: (time.time() - T0) * 1e3
 log = []
 def stage(k):
     t = now()
-    with torch.cuda.stream(computes[k % 2]):
+    with torch.cuda.stream(down):
         r = m.stage_inputs(base)
     return r, t, now()
 rin, a, b = stage(0)
 log.append(('stage', 0, a, b))
-prev = None
+flight = []
 ev = []
-NB = 8
+NB = 10
+def fetch_collect(k, datas, packed, done):
+    t = now(); down.wait_event(done); f = m._fetch_async(packed, down); t1 = now()
+    m.collect(datas, packed, f); log.append(('fetch_enq', k, t, t1)); log.append(('collect', k, t1, now()))
 for k in range(NB):
     cs = computes[k % 2]
     t_e0 = now()
+    cs.wait_event(rin.upload_done)
     with torch.cuda.stream(cs):
         e0 = torch.cuda.Event(enable_timing=True); e0.record()
         datas, packed = m._resident_for_stream(rin, None)
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
         done = torch.cuda.Event(); done.record()
-    t_e1 = now()
-    down.wait_event(done)
-    fetched = m._fetch_async(packed, down)
-    t_f = now()
+    log.append(('enqueue', k, t_e0, now()))
     ev.append((e0, e1))
-    log.append(('enqueue', k, t_e0, t_e1)); log.append(('fetch_enq', k, t_e1, t_f))
+    flight.append((k, datas, packed, done))
     if k < NB - 1:
         rin, a, b = stage(k + 1); log.append(('stage', k + 1, a, b))
-    if prev is not None:
-        t = now(); m.collect(*prev); log.append(('collect', k - 1, t, now()))
-    prev = (datas, packed, fetched)
-t = now(); m.collect(*prev); log.append(('collect', NB - 1, t, now()))
+    if len(flight) > 2:
+        fetch_collect(*flight.pop(0))
+while flight:
+    fetch_collect(*flight.pop(0))
 torch.cuda.synchronize()
 print('total %.1f ms for %d batches = %.1f ms per batch' % (now(), NB, now() / NB))
 for name, k, a, b in log:
