@@ -17,6 +17,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # (stage launch 42.3 -> 39.2 ms at 1024 scenes)
 # init.hip: no fused multiply-adds -- init_data rounds like the reference's CPU operators (see rotmath.hpp, GLAMR_ROTMATH_IEEE)
 FILE_FLAGS = {'grecon.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize'], 'init.hip': ['-ffp-contract=off']}
+FILE_FLAGS['grecon_wide.hip'] = FILE_FLAGS['grecon.hip']          # (the same file, compiled for scenes of up to 32 persons)
+INCLUDES = {'grecon_wide.hip': ['grecon.hip']}                        # sources that #include another source
 EXTRA_FLAGS = {k: v.split() for k, v in (kv.split('=', 1) for kv in os.environ.get('GLAMR_EXTRA_FLAGS', '').split(';') if kv)}
 
 
@@ -45,7 +47,8 @@ def build_library(force=False, verbose=False):
     hdr_time = max(os.path.getmtime(p) for p in _headers())
     for src in _sources():
         obj = os.path.join(bdir, os.path.basename(src) + '.o')
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+        dep_time = max([os.path.getmtime(src), hdr_time] + [os.path.getmtime(os.path.join(CSRC, d)) for d in INCLUDES.get(os.path.basename(src), [])])
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_time:
             cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + EXTRA_FLAGS.get(os.path.basename(src), []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd))

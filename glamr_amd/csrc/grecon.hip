@@ -16,7 +16,7 @@
 #include <vector>
 
 namespace glamr {
-namespace grecon {
+namespace GLAMR_GRECON_NS {
 
 #ifndef GLAMR_GRECON_MAX_THREADS
 #define GLAMR_GRECON_MAX_THREADS 512
@@ -26,7 +26,11 @@ constexpr int MAX_THREADS = GLAMR_GRECON_MAX_THREADS;
 #define GLAMR_GRECON_WAVES_PER_EU 2
 #endif
 #ifndef GLAMR_GRECON_LDS_KB
+#ifdef GLAMR_GRECON_WIDE
+#define GLAMR_GRECON_LDS_KB 96      // (the description of 32 persons takes ~25 KB of static LDS)
+#else
 #define GLAMR_GRECON_LDS_KB 153
+#endif
 #endif
 
 struct KernelArgs {
@@ -70,22 +74,36 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
   if (threadIdx.x == 0) atomicMax(a.stamps + 1, (unsigned long long)wall_clock64());
 }
 
-}  // namespace grecon
+}  // namespace GLAMR_GRECON_NS
 }  // namespace glamr
 
 using namespace glamr;
-using namespace glamr::grecon;
+using namespace glamr::GLAMR_GRECON_NS;
+
+// Scenes of more than 8 persons (up to GLAMR_GRECON_MAX_PERSONS = 32) run on the instances of csrc/grecon_wide.hip: this file compiled a
+// second time with the person arrays of the scene description four times as long (too large for the static LDS the 153 KB arena of the
+// instances below leaves), parameters and exchange arrays in the workspace or the lite arena.
+constexpr int WIDE_MAX_PERSONS = 32;
+#ifdef GLAMR_GRECON_WIDE
+#define glamr_grecon_workspace_bytes glamr_grecon_workspace_bytes_wide_
+#define glamr_grecon_run_stage glamr_grecon_run_stage_wide_
+static_assert(MAXP == WIDE_MAX_PERSONS, "grecon_wide.hip sets GLAMR_MAX_PERSONS");
+#else
+extern "C" size_t glamr_grecon_workspace_bytes_wide_(int n_scenes, int max_persons, int max_len);
+extern "C" int glamr_grecon_run_stage_wide_(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out, void* workspace, void* stream_);
 
 extern "C" int glamr_grecon_param_layout(int max_persons, int max_len, glamr_param_layout* out) {
-  GLAMR_REQUIRE(out && max_persons >= 1 && max_persons <= 8 && max_len >= 2, "bad arguments (1 <= max_persons <= 8, max_len >= 2)");
+  GLAMR_REQUIRE(out && max_persons >= 1 && max_persons <= WIDE_MAX_PERSONS && max_len >= 2, "bad arguments (1 <= max_persons <= %d, max_len >= 2)", WIDE_MAX_PERSONS);
   param_layout(max_persons, max_len, *out);
   return GLAMR_OK;
 }
+#endif
 
 // workspace header: the launch's clock stamps
 constexpr size_t GLAMR_GRECON_WS_HEADER = 256;
 
 namespace {
+#ifndef GLAMR_GRECON_WIDE
 // completion event of the last stage launch per workspace: glamr_grecon_last_launch_ns waits for THAT launch only, not for the device
 std::mutex g_ws_mu;
 std::map<const void*, hipEvent_t> g_ws_event;      // (an EVENT, not the stream handle: the caller may destroy its stream; an event outlives it)
@@ -93,6 +111,8 @@ void forget_workspaces_locked() {
   for (auto& kv : g_ws_event) (void)hipEventDestroy(kv.second);
   g_ws_event.clear();
 }
+void record_launch(const void* workspace, hipStream_t stream);
+#endif
 int current_device() {
   int dev = 0;
   return hipGetDevice(&dev) == hipSuccess ? dev : 0;
@@ -100,15 +120,25 @@ int current_device() {
 }  // namespace
 
 extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, int max_len) {
-  if (n_scenes <= 0 || max_persons < 1 || max_persons > 8 || max_len < 2) return 0;
+  if (n_scenes <= 0 || max_persons < 1 || max_persons > WIDE_MAX_PERSONS || max_len < 2) return 0;
+#ifndef GLAMR_GRECON_WIDE
+  if (max_persons > MAXP) return glamr_grecon_workspace_bytes_wide_(n_scenes, max_persons, max_len);
+#endif
   return GLAMR_GRECON_WS_HEADER + (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, layout_frames(max_persons, max_len)), 64) * sizeof(float);
 }
 
 extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glamr_stage_desc* stage, float* grads_out,
                                       void* workspace, void* stream_) {
   GLAMR_REQUIRE(batch && stage && workspace, "null argument");
-  GLAMR_REQUIRE(batch->n_scenes > 0 && batch->max_persons >= 1 && batch->max_persons <= 8 && batch->max_len >= 2,
-                "bad batch geometry: n_scenes=%d max_persons=%d max_len=%d", batch->n_scenes, batch->max_persons, batch->max_len);
+  GLAMR_REQUIRE(batch->n_scenes > 0 && batch->max_persons >= 1 && batch->max_persons <= WIDE_MAX_PERSONS && batch->max_len >= 2,
+                "bad batch geometry: n_scenes=%d max_persons=%d (at most %d) max_len=%d", batch->n_scenes, batch->max_persons, WIDE_MAX_PERSONS, batch->max_len);
+#ifndef GLAMR_GRECON_WIDE
+  if (batch->max_persons > MAXP) {
+    const int rc = glamr_grecon_run_stage_wide_(batch, stage, grads_out, workspace, stream_);
+    if (rc == GLAMR_OK) record_launch(workspace, static_cast<hipStream_t>(stream_));
+    return rc;
+  }
+#endif
   GLAMR_REQUIRE(batch->n_joints == NJ, "n_joints must be %d", NJ);
   GLAMR_REQUIRE(batch->max_len <= GLAMR_GRECON_MAX_FRAMES, "max_len=%d exceeds %d frames", batch->max_len, GLAMR_GRECON_MAX_FRAMES);
   GLAMR_REQUIRE(batch->n_persons && batch->seq_len && batch->fr_start && batch->fr_end && batch->vis && batch->j_local && batch->kp_2d &&
@@ -203,7 +233,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
   ka.fast_floats = (unsigned)(dyn / sizeof(float));
   // SINGLE needs every scene of the batch to hold exactly one person: max_persons == 1 guarantees it
-  const bool single = batch->max_persons == 1;
+  [[maybe_unused]] const bool single = batch->max_persons == 1;
   auto launch = [&](auto kern, size_t lds) -> int {
     if (lds) {      // once per (device, instance) and process (a driver call per launch is host time on every step)
       static std::mutex amu;
@@ -216,6 +246,15 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     return GLAMR_OK;
   };
   int rc;
+#ifdef GLAMR_GRECON_WIDE
+  if (ka.use_lds == 1 || ka.use_lds == 3) {      // (the full arena of > 8 persons never fits; kept from being instantiated)
+    ka.use_lds = lite <= LDS_BUDGET ? 2 : 0;
+    const size_t want2 = lite + (size_t)NJ * 6 * batch->max_persons * arena_len * sizeof(float);
+    ka.fast_floats = (unsigned)((ka.use_lds ? (want2 < LDS_BUDGET ? want2 : LDS_BUDGET) : 0) / sizeof(float));
+  }
+  const size_t dynw = (size_t)ka.fast_floats * sizeof(float);
+  rc = ka.use_lds == 2 ? launch(grecon_stage_kernel<2, false, 0>, dynw) : launch(grecon_stage_kernel<0, false, 0>, 0);
+#else
   const int cam = camera_mode(*stage);      // per-camera-mode instances: 24.1 vs 26.1 us per iteration (1 person), 61.8 vs 66.2 (2 persons, main stage)
   constexpr int CL = GLAMR_CONST_LAYOUT_FRAMES;
   if (ka.use_lds == 1 && single && const_layout)
@@ -232,8 +271,18 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     rc = cam == 1 ? launch(grecon_stage_kernel<2, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, false, 2>, dyn) : launch(grecon_stage_kernel<2, false, 0>, dyn);
   else
     rc = launch(grecon_stage_kernel<0, false, 0>, 0);
+#endif
   if (rc) return rc;
   GLAMR_HIP_CHECK(hipGetLastError());
+#ifndef GLAMR_GRECON_WIDE
+  record_launch(workspace, stream);
+#endif
+  return GLAMR_OK;
+}
+
+#ifndef GLAMR_GRECON_WIDE
+namespace {
+void record_launch(const void* workspace, hipStream_t stream) {
   {
     // completion event of this launch, per workspace (not under stream capture: a captured launch has no completion of its own, and
     // glamr_grecon_last_launch_ns then falls back to a device-wide wait)
@@ -254,8 +303,8 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
       if (it != g_ws_event.end()) { (void)hipEventDestroy(it->second); g_ws_event.erase(it); }
     }
   }
-  return GLAMR_OK;
 }
+}  // namespace
 
 // torch.optim.Adam on a flat parameter vector, with the optimiser's own update function: the entry point the parity tests use to
 // check the device arithmetic bit for bit against torch.optim.Adam (and a plain fused Adam for callers that keep their own loop)
@@ -336,3 +385,4 @@ extern "C" int glamr_grecon_last_launch_ns(const void* workspace, double* ns) {
   *ns = st[1] > st[0] ? (double)(st[1] - st[0]) * 10.0 : 0.0;
   return GLAMR_OK;
 }
+#endif  // !GLAMR_GRECON_WIDE

@@ -37,8 +37,17 @@
 #ifndef GLAMR_HOIST_FRAME_CONSTS
 #define GLAMR_HOIST_FRAME_CONSTS 0
 #endif
+// Persons per scene: 8 in the instances the library normally launches (the scene description sits in static LDS next to a 153 KB arena: no
+// room for more), 32 in the second copy of this header that csrc/grecon_wide.hip compiles into namespace grecon_wide for larger scenes.
+#ifndef GLAMR_MAX_PERSONS
+#define GLAMR_MAX_PERSONS 8
+#endif
+#ifndef GLAMR_GRECON_NS
+#define GLAMR_GRECON_NS grecon
+#endif
 namespace glamr {
-namespace grecon {
+namespace GLAMR_GRECON_NS {
+constexpr int MAXP = GLAMR_MAX_PERSONS;
 
 constexpr int NJ = 26;
 #ifndef GLAMR_KP_DEPTH
@@ -95,10 +104,10 @@ struct Scene {
   int P, T;
   const glamr_param_layout* lay;
   const glamr_stage_desc* st;
-  PersonConst pc[8];
-  PersonState ps[8];
+  PersonConst pc[MAXP];
+  PersonState ps[MAXP];
   const float* rel_cam;               // [P][P][T][12] or null
-  int* pair_first;                    // [8][8] first co-visible frame or -1 (setup_tables)
+  int* pair_first;                    // [MAXP][MAXP] first co-visible frame or -1 (setup_tables)
   int* fill_src;                      // [T] frame whose averaged camera a frame without persons inherits (:493-498)
   int* n_vis_persons;                 // [T] fr_num_persons
   float* cam_pose;                    // [T][12]  in/out
@@ -380,7 +389,7 @@ struct PersonOff {
 };
 struct SceneOff {
   ArrOff cm_ws, cv_ws, cm, cv, cp, cg_ws, cam_inv, cam_t, g_cam, g_caminv, g_avg, fill_src, n_vis_persons, pair_first;
-  PersonOff ps[8];
+  PersonOff ps[MAXP];
   unsigned ws_end, fast_end;
   bool adam_fast;
 };
@@ -404,9 +413,9 @@ GLAMR_HD constexpr SceneOff scene_offsets(int max_persons, int max_len, bool fas
   if (af) o.cp = lds(9 * TM);
   o.cg_ws = take(person0);
   o.cam_inv = takef(12 * TM); o.cam_t = takef(3 * TM); o.g_cam = take(12 * TM); o.g_caminv = take(12 * TM); o.g_avg = take(12 * TM);
-  o.fill_src = take(TM); o.n_vis_persons = take(TM); o.pair_first = take(64);
+  o.fill_src = take(TM); o.n_vis_persons = take(TM); o.pair_first = take(MAXP * MAXP);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {           // (fully unrolled: o.ps[p] is then addressed statically and the struct stays in registers)
+  for (int p = 0; p < MAXP; ++p) {        // (fully unrolled: o.ps[p] is then addressed statically and the struct stays in registers)
     if (p >= max_persons) break;
     PersonOff& s = o.ps[p];
     s.m_ws = take(pstride); s.v_ws = take(pstride);
@@ -527,7 +536,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   sc.cam_inv = at(o.cam_inv); sc.cam_t = at(o.cam_t); sc.g_cam = at(o.g_cam); sc.g_caminv = at(o.g_caminv); sc.g_avg = at(o.g_avg);
   sc.fill_src = ati(o.fill_src); sc.n_vis_persons = ati(o.n_vis_persons); sc.pair_first = ati(o.pair_first);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < MAXP; ++p) {
     if (p >= b.max_persons) break;
     const size_t slot = (size_t)si * b.max_persons + p;
     const PersonOff& q = o.ps[p];
@@ -597,7 +606,7 @@ GLAMR_HD void setup_tables(RT& rt, Scene& sc) {
     const int a = i / P, b = i % P;
     int first = -1;
     for (int t = 0; t < T && first < 0; ++t) if (sc.pc[a].vis[t] != 0.f && sc.pc[b].vis[t] != 0.f) first = t;
-    sc.pair_first[a * 8 + b] = first;
+    sc.pair_first[a * MAXP + b] = first;
   }
   rt.sync();
   for (int t = rt.tid(); frame_in(t, T); t += rt.nthreads()) {
@@ -634,7 +643,7 @@ GLAMR_HD float rel_transform_term(RT& rt, const Scene& sc, const SceneView& sh, 
       for (int dir = 0; dir < 2; ++dir) {
         const int a = dir == 0 ? p : o, b = dir == 0 ? o : p;
         const float* target = sh.rel_cam + (((size_t)a * sh.rel_stride_p + b) * sh.rel_stride_t + t) * 12;
-        const float fw = (sh.pair_first[a * 8 + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
+        const float fw = (sh.pair_first[a * MAXP + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
         float rel[12];
         if (dir == 0) mul34(Tiinv, To, rel); else mul34(Toinv, Ti, rel);
         float grel[12];
@@ -901,8 +910,16 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       }
     {
       float* ch[8];
-      for (int p = 0; p < P; ++p) ch[p] = pv(p).theta;
-      rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false);
+      if constexpr (MAXP <= 8) {
+        for (int p = 0; p < P; ++p) ch[p] = pv(p).theta;
+        rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false);
+      } else {
+        for (int p0 = 0; p0 < P; p0 += 8) {      // (the scan scratch holds 16 channels: 8 persons a call)
+          const int np = P - p0 < 8 ? P - p0 : 8;
+          for (int p = 0; p < np; ++p) ch[p] = pv(p0 + p).theta;
+          rt.template scan_multi<(FAST != 0)>(ch, np, T, 1, false);
+        }
+      }
     }
     // own element of the prefix sum is final: its cos / sin serve phases B, C and I (this frame's and the next frame's)
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
@@ -934,8 +951,16 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       }
     {
       float* ch[16];
-      for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).xy; ch[2 * p + 1] = pv(p).xy + 1; }
-      rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, false);
+      if constexpr (MAXP <= 8) {
+        for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).xy; ch[2 * p + 1] = pv(p).xy + 1; }
+        rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, false);
+      } else {
+        for (int p0 = 0; p0 < P; p0 += 8) {
+          const int np = P - p0 < 8 ? P - p0 : 8;
+          for (int p = 0; p < np; ++p) { ch[2 * p] = pv(p0 + p).xy; ch[2 * p + 1] = pv(p0 + p).xy + 1; }
+          rt.template scan_multi<(FAST != 0)>(ch, 2 * np, T, 2, false);
+        }
+      }
     }
     GLAMR_MARK(rt, 1);
     // ---- C: world orientation / translation (own elements of theta / xy only: no barrier needed) ----------------------------
@@ -1502,8 +1527,16 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     if (update) {
       {
         float* ch[16];
-        for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).g_xy; ch[2 * p + 1] = pv(p).g_xy + 1; }
-        rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, true);
+        if constexpr (MAXP <= 8) {
+          for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).g_xy; ch[2 * p + 1] = pv(p).g_xy + 1; }
+          rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, true);
+        } else {
+          for (int p0 = 0; p0 < P; p0 += 8) {
+            const int np = P - p0 < 8 ? P - p0 : 8;
+            for (int p = 0; p < np; ++p) { ch[2 * p] = pv(p0 + p).g_xy; ch[2 * p + 1] = pv(p0 + p).g_xy + 1; }
+            rt.template scan_multi<(FAST != 0)>(ch, 2 * np, T, 2, true);
+          }
+        }
       }
       rt.sync();
       GLAMR_MARK(rt, 6);
@@ -1546,8 +1579,16 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         }
       {
         float* ch[8];
-        for (int p = 0; p < P; ++p) ch[p] = pv(p).g_theta;
-        rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, true);
+        if constexpr (MAXP <= 8) {
+          for (int p = 0; p < P; ++p) ch[p] = pv(p).g_theta;
+          rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, true);
+        } else {
+          for (int p0 = 0; p0 < P; p0 += 8) {
+            const int np = P - p0 < 8 ? P - p0 : 8;
+            for (int p = 0; p < np; ++p) ch[p] = pv(p0 + p).g_theta;
+            rt.template scan_multi<(FAST != 0)>(ch, np, T, 1, true);
+          }
+        }
       }
       GLAMR_MARK(rt, 7);
       // ---- J: reverse of A (own element of the suffix sum) ------------------------------------------------------------------
@@ -1627,5 +1668,5 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   GLAMR_MARK_END(rt);
 }
 
-}  // namespace grecon
+}  // namespace GLAMR_GRECON_NS
 }  // namespace glamr

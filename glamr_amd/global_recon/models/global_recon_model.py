@@ -513,8 +513,8 @@ class GlobalReconOptimizer:
         P = max(len(x) for x in ids)
         Ts = [len(d['est'][i[0]]['bboxes_dict']['exist']) for d, i in zip(in_dicts, ids)]
         T = max(Ts)
-        if P > 8:
-            raise NotImplementedError('at most 8 persons per scene')
+        if P > 32:
+            raise NotImplementedError('at most 32 persons per scene (csrc/grecon_wide.hip)')
         n_slots = S * P
         stg = self._staging(n_slots, T)
         h = stg['np']

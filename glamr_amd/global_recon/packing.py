@@ -131,8 +131,8 @@ class PackedScenes:
         self.person_ids = [list(d['person_data'].keys()) for d in datas]
         P = max(len(ids) for ids in self.person_ids)
         T = max(int(d['seq_len']) for d in datas)
-        if P > 8:
-            raise NotImplementedError('at most 8 persons per scene')
+        if P > 32:
+            raise NotImplementedError('at most 32 persons per scene (csrc/grecon_wide.hip)')
         self.S, self.P, self.T = S, P, T
         self.layout = param_layout_py(P, T)
         f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32)

@@ -19,6 +19,7 @@ import pickle
 
 import numpy as np
 
+MAX_PERSONS = 32          # per scene (csrc/grecon_wide.hip; 8 on the instances with the on-chip arena)
 REQUIRED = ('smpl_pose_quat_wroot', 'smpl_beta', 'root_trans', 'kp_2d', 'cam_K', 'bboxes_dict')
 
 
@@ -96,8 +97,8 @@ def check_layout(est):
     checks the values on the device.  Returns the video length."""
     if not isinstance(est, dict) or not est:
         raise WireFormatError('est_dict must be a non-empty {person_id: dict}')
-    if len(est) > 8:
-        raise WireFormatError('at most 8 persons per sequence are supported (got %d)' % len(est))
+    if len(est) > MAX_PERSONS:
+        raise WireFormatError('at most %d persons per sequence are supported (got %d)' % (MAX_PERSONS, len(est)))
     n_fr = None
     for pid, src in est.items():
         for k in REQUIRED:
@@ -134,8 +135,8 @@ def normalise_est(est, check_rotations=True, check_values=True):
     """Validated copy of `est_dict`.  All persons must cover the same number of video frames (global_recon_model.py:85)."""
     if not isinstance(est, dict) or not est:
         raise WireFormatError('est_dict must be a non-empty {person_id: dict}')
-    if len(est) > 8:
-        raise WireFormatError('at most 8 persons per sequence are supported (got %d)' % len(est))
+    if len(est) > MAX_PERSONS:
+        raise WireFormatError('at most %d persons per sequence are supported (got %d)' % (MAX_PERSONS, len(est)))
     out = {pid: normalise_person(pid, src, check_rotations, check_values) for pid, src in est.items()}
     lens = {pid: len(d['bboxes_dict']['exist']) for pid, d in out.items()}
     if len(set(lens.values())) != 1:

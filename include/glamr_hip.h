@@ -258,7 +258,7 @@ typedef struct glamr_stage_desc {
 typedef struct glamr_scene_batch {
   int32_t n_scenes, max_persons, max_len, n_joints;   /* n_joints = 26 */
   /* dev, int32 */
-  const int32_t* n_persons;              /* (n_scenes) persons actually present in each scene (<= max_persons <= 8) */
+  const int32_t* n_persons;              /* (n_scenes) persons actually present in each scene (<= max_persons <= 32; more than 8: the workspace / lite-arena instances of csrc/grecon_wide.hip) */
   const int32_t* seq_len;                /* (n_scenes) frames actually present in each scene (<= max_len) */
   const int32_t* fr_start;               /* (slots) first existing frame  (exist_frames = [fr_start, fr_end), :92-95) */
   const int32_t* fr_end;                 /* (slots) */

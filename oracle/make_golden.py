@@ -369,6 +369,8 @@ def _param_names(model, data, opt_variables):
 GRECON_CASES = [('glamr_dynamic', 120, 1, 25), ('glamr_static', 90, 1, 25), ('glamr_static_multi', 120, 2, 15),
                 ('glamr_dynamic_multi', 100, 2, 15), ('glamr_3dpw', 120, 1, 15), ('glamr_h36m', 100, 2, 10),
                 ('glamr_static_multi', 300, 4, 5)]          # BASELINE.json configs[3]: 4 persons, shared fixed camera, 300 frames
+# scenes of more than 8 persons (csrc/grecon_wide.hip; the reference's loops over persons have no limit): shared fixed camera / per-frame camera
+GRECON_CASES_WIDE = [('glamr_static_multi', 60, 10, 6), ('glamr_dynamic_multi', 48, 9, 6)]
 
 
 def gen_grecon(cases=GRECON_CASES):
@@ -845,7 +847,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

@@ -65,13 +65,15 @@ def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
     # parameter layout / workspace size
     lay = _lib.ParamLayout()
     assert L.glamr_grecon_param_layout(0, 300, ctypes.byref(lay)) == E_INVALID
-    assert L.glamr_grecon_param_layout(9, 300, ctypes.byref(lay)) == E_INVALID
+    assert L.glamr_grecon_param_layout(33, 300, ctypes.byref(lay)) == E_INVALID
+    assert L.glamr_grecon_param_layout(9, 300, ctypes.byref(lay)) == 0            # more than 8 persons: csrc/grecon_wide.hip
     assert L.glamr_grecon_param_layout(1, 1, ctypes.byref(lay)) == E_INVALID
     assert b'max_persons' in L.glamr_last_error()
     assert L.glamr_grecon_param_layout(1, 300, ctypes.byref(lay)) == 0
     # the layout holds every variable group of every stage: camera 6T + 3T, camera residuals 6T + 3T, then one block per person
     assert lay.person0 == 18 * 300 and lay.scene_stride == lay.person0 + lay.person_stride and lay.world_dheading + 300 == lay.person_stride
-    assert L.glamr_grecon_workspace_bytes(0, 1, 300) == 0 and L.glamr_grecon_workspace_bytes(4, 9, 300) == 0
+    assert L.glamr_grecon_workspace_bytes(0, 1, 300) == 0 and L.glamr_grecon_workspace_bytes(4, 33, 300) == 0
+    assert L.glamr_grecon_workspace_bytes(4, 12, 300) > 12 * L.glamr_grecon_workspace_bytes(4, 1, 300) // 2      # (the wide instances' workspace)
     assert L.glamr_grecon_workspace_bytes(4, 1, 300) > 4 * 3 * lay.scene_stride * 4      # Adam moments + gradient per scene at least
     # stage launch: null pointers, bad geometry, missing arrays, too long a sequence
     sd, sb = _lib.StageDesc(), _lib.SceneBatch()

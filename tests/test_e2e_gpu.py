@@ -37,7 +37,7 @@ def make_model(asset_root):
     return make
 
 
-@pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES)
+@pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES + mg.GRECON_CASES_WIDE)
 def test_optimize_matches_reference_fixture(make_model, golden, cfg_id, T, P, K):
     g = golden('grecon_%s_T%d_P%d' % (cfg_id, T, P))
     md = synth.make_smpl_model()

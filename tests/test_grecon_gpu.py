@@ -8,7 +8,7 @@ from tests import grecon_common as gc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES)
+@pytest.mark.parametrize('cfg_id,T,P,K', mg.GRECON_CASES + mg.GRECON_CASES_WIDE)      # (_WIDE: 9 and 10 persons, csrc/grecon_wide.hip)
 def test_fused_optimiser_kernel_vs_reference_fixture(asset_root, golden, cfg_id, T, P, K):
     gc.check_case(gc.device_runner(), asset_root, golden, cfg_id, T, P, K)
 
