@@ -597,6 +597,10 @@ def run(argv=None):
     tm = dict(model.timings)
     host_stream = None
     if hasattr(model, 'optimize_stream') and not args.no_host_stream:
+        # the pipelined stream alternates batches over two compute streams: the two this run already has (the runtime multiplexes HIP streams
+        # onto 4 hardware queues; with two more of its own the stream's batches shared queues with idle ones: 15 700 instead of 22 000 seq/s)
+        if len(streams) == 2:
+            model.__dict__.setdefault('_compute_streams', list(streams))
         # steady state of the pipelined stream: the first pass creates the three pinned output sets a depth-3 pipeline holds (page-locking
         # 400 MB each: a one-off ~100 ms the 6-batch figure of rounds 1-2 carried); the timed pass re-uses them
         for _ in model.optimize_stream([in_dicts] * 4):

@@ -156,7 +156,8 @@ constexpr int PREP_FRAMES = 8;   // 8 * 24 = 192 active threads of 256
 
 struct PrepArgs {
   int B, Bpad, num_betas, n_levels, use_shape;      // frames [B, Bpad) are the padding of the last 32-frame tile: their operand rows are written as zeros
-  const float* pose;        // (B,72)
+  const float* pose;        // (B,72), or (B,69) = the body pose alone when body_only (the global orientation is then zero)
+  int body_only;
   const float* betas;       // (B,num_betas) or null
   const float* j_template;  // (24,3)
   const float* j_shapedirs; // (24,3,num_betas)
@@ -192,7 +193,9 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
   float Jr[3] = {0.f, 0.f, 0.f};
   if (active || padding) {
     if (active) {
-      float r[3] = {a.pose[(size_t)b * 72 + j * 3 + 0], a.pose[(size_t)b * 72 + j * 3 + 1], a.pose[(size_t)b * 72 + j * 3 + 2]};
+      const float* pr = a.body_only ? a.pose + (size_t)b * 69 + (j - 1) * 3 : a.pose + (size_t)b * 72 + j * 3;
+      float r[3] = {0.f, 0.f, 0.f};
+      if (!a.body_only || j > 0) { r[0] = pr[0]; r[1] = pr[1]; r[2] = pr[2]; }
       rodrigues_smplx(r, R);
       for (int c = 0; c < 3; ++c) {
         float v = a.j_template[j * 3 + c];
@@ -1217,7 +1220,7 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   const bool planes = std::getenv("GLAMR_SMPL_FP32_BLEND") == nullptr && h->full.dirs_h != nullptr && (h->joints.n_tiles == 0 || h->joints.dirs_h != nullptr);
   // (rows [B, Bpad) of the operand arrays, read by the padded MFMA tiles, are written as zeros by the prep kernel)
   // (the fp16-plane instances read nothing but the planes: the fp32 rows are only written for the fp32-MFMA instances)
-  PrepArgs pa{B, w.Bpad, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, planes ? nullptr : w.feat,
+  PrepArgs pa{B, w.Bpad, h->num_betas, h->n_levels, 1, pose, (flags & GLAMR_SMPL_BODY_POSE_ONLY) ? 1 : 0, betas, h->j_template, h->j_shapedirs, h->parents, h->level, planes ? nullptr : w.feat,
               planes ? reinterpret_cast<unsigned short*>(w.feat_h) : nullptr, planes ? nullptr : w.askin, planes ? reinterpret_cast<unsigned short*>(w.askin_h) : nullptr, w.chain};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((w.Bpad + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   const int n_ftiles = w.Bpad / TILE_F;
@@ -1282,7 +1285,7 @@ extern "C" int glamr_smpl_fk(glamr_smpl* h, int B, const float* pose, const floa
   GLAMR_REQUIRE(h && pose && joints, "null argument");
   GLAMR_REQUIRE(B > 0, "B must be positive");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  PrepArgs pa{B, B, h->num_betas, h->n_levels, 0, pose, nullptr, h->j_template, h->j_shapedirs, h->parents, h->level, nullptr, nullptr, nullptr, nullptr, joints};
+  PrepArgs pa{B, B, h->num_betas, h->n_levels, 0, pose, 0, nullptr, h->j_template, h->j_shapedirs, h->parents, h->level, nullptr, nullptr, nullptr, nullptr, joints};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   if (root_trans) hipLaunchKernelGGL(smpl_fk_anchor_kernel, dim3(B), dim3(NJ), 0, stream, B, root_trans, root_scale, joints);
   GLAMR_HIP_CHECK(hipGetLastError());
@@ -1341,7 +1344,7 @@ extern "C" int glamr_smpl_backward(glamr_smpl* h, int B, const float* pose, cons
   const int with_verts = g_verts != nullptr;
   SmplBwdWs w = smpl_bwd_ws_layout(h, B, with_verts, static_cast<char*>(workspace));
   const glamr_tileset& ts = (!with_verts && h->joints.n_tiles > 0) ? h->joints : h->full;
-  PrepArgs pa{B, B, h->num_betas, h->n_levels, 1, pose, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, nullptr, w.askin, nullptr, w.chain};
+  PrepArgs pa{B, B, h->num_betas, h->n_levels, 1, pose, 0, betas, h->j_template, h->j_shapedirs, h->parents, h->level, w.feat, nullptr, w.askin, nullptr, w.chain};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((B + PREP_FRAMES - 1) / PREP_FRAMES), dim3(256), 0, stream, pa);
   BwdGenArgs a{B, w.Bpad, h->V, ts.Vpad, ts.n_tiles, h->n_extra_used, h->n_picked, h->n_out, orig ? 1 : 0, h->num_betas,
                pose, betas, root_trans, root_scale, verts, joints, g_verts, g_joints, h->joint_map, h->extra_slot, h->parents,

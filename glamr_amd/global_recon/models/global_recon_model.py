@@ -676,11 +676,7 @@ class GlobalReconOptimizer:
         _lib.check(L.glamr_init_scenes(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
                                        _lib.ptr(out['orient']), _lib.ptr(ws), st))
         # root-relative joints of every frame, cached for the whole optimisation
-        zeros = f32(n_slots * T, 3)
-        with torch.no_grad():
-            jl = self.smpl(global_orient=zeros, body_pose=pa_t['smpl_pose'].view(-1, 69), betas=pa_t['smpl_beta'].view(-1, 10), root_trans=zeros,
-                           return_verts=False).joints
-        packed.t['j_local'] = jl.view(n_slots, T, 26, 3)
+        packed.t['j_local'] = self.smpl.root_relative_joints(pa_t['smpl_pose'].view(-1, 69), pa_t['smpl_beta'].view(-1, 10)).view(n_slots, T, 26, 3)
         # with flag_init_cam_all_frames this pass is only there for the world poses the cameras are initialised from; whoever needs the 'init'
         # outputs gets them from the second pass (init_forward), or from the first stage's last evaluation
         self._run(packed, self._forward_only_desc(poses_only=self.flag_init_cam_all_frames or not init_forward))

@@ -227,6 +227,27 @@ class SMPL(nn.Module):
         return ModelOutput(vertices=verts if return_verts else None, joints=joints, betas=betas, global_orient=global_orient,
                            body_pose=body_pose, full_pose=pose if return_full_pose else None)
 
+    def root_relative_joints(self, body_pose, betas):
+        """forward(global_orient=0, body_pose, betas, root_trans=0, return_verts=False).joints -- the joints the optimiser caches for the whole
+        schedule -- without the (B,72) concatenation and the two zero arrays per call: GLAMR_SMPL_BODY_POSE_ONLY, the
+        origin from a zero array kept by this module.  body_pose (B,69), betas (B,10) float32 contiguous on the device.  No autograd."""
+        B, dev = body_pose.shape[0], body_pose.device
+        if body_pose.dtype != torch.float32 or betas.dtype != torch.float32 or not body_pose.is_contiguous() or not betas.is_contiguous() \
+                or tuple(body_pose.shape) != (B, 69) or betas.shape[0] != B:
+            raise ValueError('root_relative_joints takes contiguous float32 body_pose (B,69) and betas (B,num_betas)')
+        z = self.__dict__.get('_origin')
+        if z is None or z.shape[0] < B or z.device != dev:
+            if torch.cuda.is_current_stream_capturing() and z is not None:
+                raise RuntimeError('root_relative_joints: the origin array must not grow inside a stream capture')
+            z = self.__dict__['_origin'] = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+            torch.cuda.current_stream(dev).synchronize()          # (once: other streams read it without an event of this fill)
+        h, L = self._handle(dev), _lib.lib()
+        joints = torch.empty((B, self.n_out, 3), device=dev, dtype=torch.float32)
+        ws = torch.empty(L.glamr_smpl_workspace_bytes(h, B), device=dev, dtype=torch.uint8)
+        _lib.check(L.glamr_smpl_forward(h, B, _lib.ptr(body_pose), _lib.ptr(betas), _lib.ptr(z), None, None, _lib.ptr(joints), 2, _lib.ptr(ws),
+                                        _lib.current_stream()))
+        return joints
+
     def get_joints(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, root_trans=None, root_scale=None,
                    dtype=torch.float32):
         """Forward kinematics of the 24 chain joints from the unshaped template (betas are ignored, as in the reference)."""

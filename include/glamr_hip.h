@@ -51,6 +51,8 @@ int glamr_smpl_destroy(glamr_smpl* h);
 size_t glamr_smpl_workspace_bytes(const glamr_smpl* h, int B);
 
 #define GLAMR_SMPL_ORIG_JOINTS 1   /* joints = the 24 chain joints (smpl.py:296-297), n_out is ignored */
+#define GLAMR_SMPL_BODY_POSE_ONLY 2 /* glamr_smpl_forward: `pose` is (B,69), the body pose alone; the global orientation is zero (the cached
+                                    * root-relative joints of the optimiser, global_recon_model.py:517-524 with SURVEY.md 8 row a9) */
 
 /* SMPL.forward (smpl.py:289-316).  dev in: pose (B,72) = [global_orient | body_pose] axis-angle, betas (B,num_betas),
  * root_trans (B,3) or NULL (no re-anchoring), root_scale (B) or NULL (=1).  dev out: verts (B,V,3) or NULL (skips the

@@ -83,6 +83,22 @@ def test_smpl_rigid_root_identity_full_size(models):
     assert _err(torch.einsum('bij,bvj->bvi', R, a.joints) + trans[:, None], b.joints) < TOL
 
 
+@pytest.mark.parametrize('B', [1, 37, 300, 19200])
+def test_root_relative_joints_are_the_zero_orientation_forward_bit_for_bit(models, B):
+    """SMPL.root_relative_joints (GLAMR_SMPL_BODY_POSE_ONLY: the optimiser's cached joints without the (B,72) concatenation and the zero
+    arrays) against forward(global_orient=0, root_trans=0, return_verts=False): the same kernels on the same numbers."""
+    ora, mine, dev = models
+    gen = torch.Generator().manual_seed(11 + B)
+    body = (torch.randn(B, 69, generator=gen) * 0.3).to(dev)
+    betas = torch.randn(B, 10, generator=gen).to(dev)
+    zero = torch.zeros(B, 3, device=dev)
+    a = mine(global_orient=zero, body_pose=body, betas=betas, root_trans=zero, return_verts=False).joints
+    b = mine.root_relative_joints(body, betas)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        mine.root_relative_joints(body[:, :60], betas)
+
+
 def test_smpl_backward_root(models):
     ora, mine, dev = models
     B = 40
