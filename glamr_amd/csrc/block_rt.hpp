@@ -5,6 +5,15 @@
 
 namespace glamr {
 
+// Wave scans through DPP row shifts (2: prefix and suffix sums, 1: prefix sums only, 0 / GLAMR_SCAN_SHUFFLE: the ds_bpermute shuffles of rounds
+// 1-3).  Exact on integer data for every length, channel count, stride and direction (tools/scan_probe.hip, tests/test_scan_gpu.py); the
+// optimiser stage is 4.8 % shorter with it (profiles/r04_scan_dpp_ab.log).
+#if !defined(GLAMR_SCAN_DPP) && !defined(GLAMR_SCAN_SHUFFLE)
+#define GLAMR_SCAN_DPP 2
+#endif
+#if defined(GLAMR_SCAN_DPP) && GLAMR_SCAN_DPP == 0
+#undef GLAMR_SCAN_DPP
+#endif
 constexpr int RT_MAX_CH = 16;
 constexpr int RT_SCAN_FLOATS = 2 * RT_MAX_CH * 16;    // two generations x channels x waves
 constexpr int RT_RED_FLOATS = RT_SCAN_FLOATS + 16;     // + a region of its own for reduce_sum (scans may follow it without a barrier)
@@ -81,10 +90,15 @@ struct DeviceRT {
       for (int c = 0; c < nch; ++c) {
         float v = (i < n) ? elem<LDS>(ch[c], idx) : 0.f;
 #ifdef GLAMR_SCAN_DPP
-        // NOT YET VALIDATED ON HARDWARE (off by default; next round): the wave scan through DPP row shifts inside the 16-lane rows
-        // (out-of-row sources read 0: bound_ctrl) and v_readlane of the three row totals, instead of six ds_bpermute round trips
-        v = wave_scan_dpp(v, reverse);
-        if (lane == (reverse ? 0 : 63)) r[c * 16 + wave] = v;
+        // the wave scan through DPP row shifts inside the 16-lane rows (out-of-row sources read 0: bound_ctrl) and v_readlane of the three
+        // row totals, instead of six ds_bpermute round trips.  GLAMR_SCAN_DPP=1: prefix sums only; 2: suffix sums as well
+        if (!reverse || GLAMR_SCAN_DPP >= 2) {
+          v = wave_scan_dpp(v, reverse);
+          if (lane == (reverse ? 0 : 63)) r[c * 16 + wave] = v;
+        } else {
+          for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_down(v, off); if (lane + off < 64) v += y; }
+          if (lane == 0) r[c * 16 + wave] = v;
+        }
 #else
         if (!reverse) {
           for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_up(v, off); if (lane >= off) v += y; }

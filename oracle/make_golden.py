@@ -391,6 +391,49 @@ def gen_grecon(cases=GRECON_CASES):
         print('wrote', cfg_id, T, P)
 
 
+KSTEP_FAMILY = [('threads1', dict(threads=1)), ('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-7_seed1', dict(eps=1e-7, seed=1)),
+                ('eps1e-7_seed2', dict(eps=1e-7, seed=2)), ('eps1e-7_seed3', dict(eps=1e-7, seed=3))]
+
+
+def gen_grecon_family(cases=(('glamr_3dpw', 120, 1, 15),), members=KSTEP_FAMILY):
+    """The reference's own spread on a K-step fixture: in `glamr_3dpw` the camera rides on the person (flag_opt_cam_from_person_pose), so the
+    world trajectory is a gauge -- the gradients of its variables are rounding noise, and Adam's first steps follow the noise's SIGN.
+    Members: other intra-op thread counts, the predicted local trajectory x (1 + eps U(-1, 1)) before the first stage.  Stored: every
+    member's projected keypoints after K steps per stage, next to the committed fixture (`<fixture>_family.npz`)."""
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    keep_threads = torch.get_num_threads()
+    for cfg_id, T, P, K in cases:
+        base = np.load(os.path.join(GOLD, 'grecon_%s_T%d_P%d.npz' % (cfg_id, T, P)))
+        out = {}
+        for name, opt in members:
+            torch.set_num_threads(opt.get('threads', keep_threads))
+            model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+            in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md)
+            keep, done = model.init_opt, []
+
+            def init_opt(data, opt_variables, opt_lr, keep=keep, opt=opt, done=done):
+                if opt.get('eps') and not done:
+                    rng = np.random.RandomState(opt['seed'])
+                    for pd in data['person_data'].values():
+                        tl = pd['traj_local_pred']
+                        tl.mul_(torch.from_numpy((1 + opt['eps'] * rng.uniform(-1, 1, tuple(tl.shape))).astype(np.float32)))
+                    done.append(1)
+                return keep(data, opt_variables, opt_lr)
+            model.init_opt = init_opt
+            data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 3), niters=K)
+            worst = 0.0
+            for pi in range(P):
+                kp = _np(data['person_data'][pi]['kp_2d_pred'])
+                out['%s_p%d_kp_2d_pred' % (name, pi)] = kp
+                vis = base['init_p%d_vis_frames' % pi] & base['init_p0_vis_frames']
+                worst = max(worst, float(np.abs(kp - base['opt_p%d_kp_2d_pred' % pi])[vis].max()))
+            print('K-step family %s T=%d P=%d member %-14s max %.4f px from the committed fixture' % (cfg_id, T, P, name, worst), flush=True)
+        torch.set_num_threads(keep_threads)
+        np.savez_compressed(os.path.join(GOLD, 'grecon_%s_T%d_P%d_family.npz' % (cfg_id, T, P)), **out)
+
+
 def gen_full(which=('gap', 'nogap')):
     """Full schedule on BASELINE.json configs[1].  'gap': person 0 undetected in frames [100,160) -- there the optimisation is
     chaotic (the gradients of the unseen frames are rounding noise that Adam turns into +-lr steps), so this file is compared through
@@ -847,7 +890,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'grecon_family': gen_grecon_family, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

@@ -69,7 +69,7 @@ def test_optimize_matches_reference_fixture(make_model, golden, cfg_id, T, P, K)
         tol_kp, tol_tr, tol_rot = KSTEP_TOL[(cfg_id, T, P)]
         err = kp_err(pd['kp_2d_pred'], g['opt_p%d_kp_2d_pred' % pi], vis)
         worst[0] = max(worst[0], err)
-        assert err < max(3 * tol_kp, 0.1), 'kp_2d_pred after optimisation: %g px' % err
+        assert err < (tol_kp if cfg_id == 'glamr_3dpw' else max(3 * tol_kp, 0.1)), 'kp_2d_pred after optimisation: %g px' % err      # (3dpw: a gauge bound already, grecon_common.KSTEP_TOL)
         if cfg_id != 'glamr_3dpw':
             err = np.abs(pd['root_trans_world'] - g['opt_p%d_root_trans_world' % pi]).max()
             worst[1] = max(worst[1], err)
