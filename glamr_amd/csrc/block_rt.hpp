@@ -110,7 +110,9 @@ struct DeviceRT {
 #endif
         x[c] = v;
       }
+#if !defined(GLAMR_EXP_NOSYNC) || GLAMR_EXP_NOSYNC < 2
       __syncthreads();
+#endif
       for (int c = 0; c < nch; ++c) {
         float pre = carry[c], tot = 0.f;
         for (int w = 0; w < nw; ++w) { const float t = r[c * 16 + w]; tot += t; if (reverse ? (w > wave) : (w < wave)) pre += t; }
@@ -125,7 +127,11 @@ struct DeviceRT {
   }
   __device__ __forceinline__ int tid() const { return threadIdx.x; }
   __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+#ifdef GLAMR_EXP_NOSYNC      // development aid (WRONG results): what the workgroup barriers of the iteration cost -- 1: rt.sync() only, 2: the scans' as well
+  __device__ __forceinline__ void sync() const {}
+#else
   __device__ __forceinline__ void sync() const { __syncthreads(); }
+#endif
   __device__ float reduce_sum(float v) const {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     __syncthreads();
