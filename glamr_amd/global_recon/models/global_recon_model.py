@@ -200,7 +200,11 @@ class GlobalReconOptimizer:
                 or not g('flag_opt_traj', True) or not g('flag_infill_motion', True):
             raise NotImplementedError('only est_type=hybrik with motion infilling + trajectory prediction + trajectory optimisation '
                                       '(every shipped config) is supported')
-        for flag in ('flag_opt_vis_local_rot', 'flag_opt_person2cam_rot',
+        # flag_opt_vis_local_rot (:45,416-419): the per-frame rotation residual `traj_local_rot` is only applied at the frames a person is SEEN in.
+        # A residual that is never applied gets no gradient (its regulariser's is 2 w r = 0 at r = 0) and Adam leaves it at its initial zero: the
+        # flag amounts to "no update of traj_local_rot at invisible frames" -- run_schedule then goes launch by launch with that gradient mask
+        self.flag_opt_vis_local_rot = bool(g('flag_opt_vis_local_rot', False))
+        for flag in ('flag_opt_person2cam_rot',
                      'flag_opt_person2cam_trans', 'flag_traj_from_cam', 'flag_use_pen_loss', 'absolute_heading'):
             if g(flag, False):
                 raise NotImplementedError('%s is not supported by the MI355X path' % flag)
@@ -859,6 +863,8 @@ class GlobalReconOptimizer:
         """The staged optimisation (:250-262) of an initialised batch: one kernel launch per stage, asynchronous on the current
         stream.  `max_iters` caps the iterations of every stage (tests); None = the configured schedule.  `has_wd`: the scenes already
         carry a world heading offset (a continued optimisation, :459-465 applies it whenever the variable exists)."""
+        if self.flag_opt_vis_local_rot:
+            return self._run_schedule_masked(packed, max_iters, has_wd)
         events = []
         for stage, spec in self.opt_stage_specs.items():
             sd = packing.stage_desc(spec, self.specs, has_world_dheading=has_wd,
@@ -869,6 +875,36 @@ class GlobalReconOptimizer:
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
         packed.has_world_dheading = has_wd
         packed.stage_ws = events
+        return packed
+
+    def _run_schedule_masked(self, packed, max_iters, has_wd):
+        """flag_opt_vis_local_rot: the schedule launch by launch (parallel.PersonShardedSchedule on ONE rank without collectives: a gradient launch
+        and glamr_adam_step per iteration, ~0.4 ms each) with the gradient of `traj_local_rot` zeroed at the frames a person is not seen in.  No
+        shipped config sets the flag; the one-launch-per-stage kernel is untouched by it."""
+        from glamr_amd import parallel
+        if torch.cuda.is_current_stream_capturing():
+            raise NotImplementedError('flag_opt_vis_local_rot runs launch by launch and cannot be captured into a step graph')
+        if any(self.specs.get('flag_opt_cam_from_person_pose', False) and 'cam' not in spec['opt_variables'] for spec in self.opt_stage_specs.values()):
+            raise NotImplementedError('flag_opt_vis_local_rot with a camera derived from the persons')
+        S, P, T, l = packed.S, packed.P, packed.T, packed.layout
+        vis = packed.t['vis'].view(S, P, T) > 0
+        fr_start = packed.t['fr_start'].view(S, P).long()
+        keep = torch.ones_like(packed.t['params'])
+        t_idx = torch.arange(T, device=packed.device)
+        for pi in range(P):
+            # the residual of video frame t sits at row t - fr_start of the person's block (rows of frames before fr_start do not exist)
+            e = t_idx[None, :] - fr_start[:, pi:pi + 1]                                        # (S, T)
+            col = l['person0'] + pi * l['person_stride'] + l['local_rot'] + e * 6
+            ok = (~vis[:, pi]) & (e >= 0)
+            s_idx = torch.arange(S, device=packed.device)[:, None].expand(S, T)
+            for k in range(6):
+                keep[s_idx[ok], (col + k)[ok]] = 0.0
+
+        def hook(packed_, stage, spec, grads):
+            grads.mul_(keep)
+        sched = parallel.PersonShardedSchedule(rank=0, world=1, grad_hook=hook, use_dist=False)
+        sched.run(packed, self.opt_stage_specs, self.specs, max_iters=max_iters, has_wd=has_wd)
+        packed.stage_ws = []
         return packed
 
     def optimize_resident(self, rin, max_iters=None):

@@ -145,7 +145,7 @@ class PersonShardedSchedule:
     `run_stage(packed, stage_desc, want_grads)` / `adam_step(p, m, v, g, lr, step)`: the device entry points by default; the CPU tests
     inject the host runtime of tests/hostsim and run two ranks over gloo."""
 
-    def __init__(self, rank=None, world=None, group=None, run_stage=None, adam_step=None):
+    def __init__(self, rank=None, world=None, group=None, run_stage=None, adam_step=None, grad_hook=None, use_dist=None):
         initialised = dist.is_available() and dist.is_initialized()
         self.rank = rank if rank is not None else (dist.get_rank(group) if initialised else 0)
         self.world = world if world is not None else (dist.get_world_size(group) if initialised else 1)
@@ -154,7 +154,10 @@ class PersonShardedSchedule:
         self.adam_step = adam_step or _device_adam_step
         # collectives are issued whenever a process group exists -- also in a world of ONE rank (bench.py --force-dist, the single-GPU test of
         # the RCCL path): nothing is exchanged then, but the calls and their stream ordering are the ones of the N-rank run
-        self.use_dist = initialised
+        self.use_dist = initialised if use_dist is None else bool(use_dist)
+        # grad_hook(packed, stage, spec, grads): edits the gradient record of an iteration in place before the Adam step -- how the launch-by-launch
+        # schedule also serves model flags that only change WHICH variables move (GlobalReconOptimizer: flag_opt_vis_local_rot)
+        self.grad_hook = grad_hook
         self.collective_seconds = 0.0
         self.launches = 0
 
@@ -227,6 +230,8 @@ class PersonShardedSchedule:
                 for pi in range(P):
                     if pi not in own:
                         grads[:, person_cols[pi]] = 0.0
+                if self.grad_hook is not None:
+                    self.grad_hook(packed, stage, spec, grads)
                 self.adam_step(params.view(-1), m.view(-1), v.view(-1), grads.view(-1), spec['opt_lr'], it + 1)      # 5.
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             if spec.get('reinitialize_cam', False):

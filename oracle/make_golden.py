@@ -434,6 +434,32 @@ def gen_grecon_family(cases=(('glamr_3dpw', 120, 1, 15),), members=KSTEP_FAMILY)
         np.savez_compressed(os.path.join(GOLD, 'grecon_%s_T%d_P%d_family.npz' % (cfg_id, T, P)), **out)
 
 
+# model flags no shipped config sets (global_recon_model.py:45): (tag, cfg, T, P, K, spec overrides, detection gap)
+FLAG_CASES = [('vis_local_rot', 'glamr_dynamic', 120, 1, 12, {'flag_opt_vis_local_rot': True}, (40, 70))]
+
+
+def gen_grecon_flags(cases=FLAG_CASES):
+    """K-step fixtures of the unmodified reference with a model flag switched on that no shipped config sets (the attribute the
+    constructor read from `grecon_model_specs`, set on the instance)."""
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    for tag, cfg_id, T, P, K, flags, gap in cases:
+        model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+        for k, v in flags.items():
+            assert hasattr(model, k), k
+            setattr(model, k, v)
+        in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md, gap=gap)
+        data, init_state = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 3), niters=K)
+        out = {'init_' + k: v for k, v in init_state.items()}
+        out.update({'opt_' + k: v for k, v in _flatten_state(data, PERSON_KEYS_OPT, TOP_KEYS).items()})
+        out['niters'] = np.array(K)
+        np.savez_compressed(os.path.join(GOLD, 'grecon_%s_T%d_P%d_%s.npz' % (cfg_id, T, P, tag)), **out)
+        rot = out['opt_p0_traj_local_rot']
+        vis = out['init_p0_vis_frames']
+        print('wrote', tag, cfg_id, T, P, '| traj_local_rot at invisible frames: max |.| = %.3g, at visible frames %.3g' % (np.abs(rot[~vis]).max(), np.abs(rot[vis]).max()))
+
+
 def gen_full(which=('gap', 'nogap')):
     """Full schedule on BASELINE.json configs[1].  'gap': person 0 undetected in frames [100,160) -- there the optimisation is
     chaotic (the gradients of the unseen frames are rounding noise that Adam turns into +-lr steps), so this file is compared through
@@ -890,7 +916,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'grecon_family': gen_grecon_family, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'grecon_family': gen_grecon_family, 'grecon_flags': gen_grecon_flags, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

@@ -81,6 +81,38 @@ def test_optimize_matches_reference_fixture(make_model, golden, cfg_id, T, P, K)
     assert out['cam_pose'].shape == (T, 4, 4) and out['seq_len'] == T
 
 
+def test_flag_opt_vis_local_rot_matches_the_reference(make_model, golden, asset_root):
+    """A model flag no shipped config sets (global_recon_model.py:45,416-419): the rotation residual `traj_local_rot` is applied at the frames a
+    person is SEEN in only.  Fixture: the unmodified reference with the flag on, 120 frames with detections missing in [40, 70), 12 iterations per
+    stage (oracle/make_golden.py gen_grecon_flags).  Here the schedule then runs launch by launch with the residual's gradient masked."""
+    from glamr_amd.global_recon.models import model_dict
+    from glamr_amd.global_recon.configs import get_config
+    tag, cfg_id, T, P, K, flags, gap = mg.FLAG_CASES[0]
+    g = golden('grecon_%s_T%d_P%d_%s' % (cfg_id, T, P, tag))
+    base = make_model(cfg_id)
+    cfg = get_config(cfg_id)
+    cfg['grecon_model_specs'].update(flags)
+    model = model_dict['global_recon_model'](cfg, base.device, None, smpl=base.smpl, mt_model=base.mt_model)
+    in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model(), gap=gap)
+    lat = mg.latents_for(in_dict, 3)
+    out = model.optimize(in_dict, latents=lat, max_iters=K)
+    pd = out['person_data'][0]
+    vis = g['init_p0_vis_frames']
+    assert (~vis).sum() == gap[1] - gap[0]
+    rot = np.asarray(pd['traj_local_rot'])
+    assert np.abs(rot[~vis]).max() == 0.0 and np.abs(g['opt_p0_traj_local_rot'][~vis]).max() == 0.0      # never moved, here and in the reference
+    e_rot = np.abs(rot - g['opt_p0_traj_local_rot']).max()
+    e_kp = kp_err(pd['kp_2d_pred'], g['opt_p0_kp_2d_pred'], vis)
+    e_tr = np.abs(pd['root_trans_world'] - g['opt_p0_root_trans_world']).max()
+    e_or = _rot_err(pd['smpl_orient_world'], g['opt_p0_smpl_orient_world'])
+    print('flag_opt_vis_local_rot, %d iterations per stage: kp %.4f px, root_trans_world %.2e m, smpl_orient_world %.2e, traj_local_rot %.2e (largest %.3g)'
+          % (K, e_kp, e_tr, e_or, e_rot, np.abs(g['opt_p0_traj_local_rot']).max()))
+    assert e_kp < 0.1 and e_tr < 5e-4 and e_or < 5e-3 and e_rot < 5e-4
+    # and the flag matters on this input: without it the residual of the unseen frames moves
+    plain = base.optimize(in_dict, latents=lat, max_iters=K)
+    assert np.abs(np.asarray(plain['person_data'][0]['traj_local_rot'])[~vis]).max() > 1e-4      # (7e-4 after 12 iterations per stage)
+
+
 def _full_schedule(make_model, golden, tag, gap, host_init=False):
     g = golden('full_glamr_dynamic_T300' + tag)
     md = synth.make_smpl_model()
