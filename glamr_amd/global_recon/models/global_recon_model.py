@@ -204,8 +204,15 @@ class GlobalReconOptimizer:
         # A residual that is never applied gets no gradient (its regulariser's is 2 w r = 0 at r = 0) and Adam leaves it at its initial zero: the
         # flag amounts to "no update of traj_local_rot at invisible frames" -- run_schedule then goes launch by launch with that gradient mask
         self.flag_opt_vis_local_rot = bool(g('flag_opt_vis_local_rot', False))
+        # flag_traj_from_cam (:55,237,325-351): the world trajectory is first read off the initial camera (orientation interpolated between the
+        # frames a person is seen in, heading separately).  With a trajectory predictor -- the only mode this path runs -- init_traj_heading_from_cam
+        # then overwrites every EXISTING frame (:283-289), so what the flag changes is the base pose of the frames outside a person's existence
+        # range.  Host initialisation only (init_data_batch_host).
+        self.flag_traj_from_cam = bool(g('flag_traj_from_cam', False))
+        if self.flag_traj_from_cam and g('traj_interp_method', 'linear_interp') != 'linear_interp':
+            raise NotImplementedError("flag_traj_from_cam with traj_interp_method other than 'linear_interp'")
         for flag in ('flag_opt_person2cam_rot',
-                     'flag_opt_person2cam_trans', 'flag_traj_from_cam', 'flag_use_pen_loss', 'absolute_heading'):
+                     'flag_opt_person2cam_trans', 'flag_use_pen_loss', 'absolute_heading'):
             if g(flag, False):
                 raise NotImplementedError('%s is not supported by the MI355X path' % flag)
         if g('heading_type', 'scalar') != 'scalar' or not g('flag_cam_inv_trans_res_all', True) or not g('flag_opt_cam', True):
@@ -328,6 +335,14 @@ class GlobalReconOptimizer:
             'meta': {'algo': 'global_recon', 'num_fr': num_fr},
         }
         self._init_cam_pose(data, all_frames=False)
+        if self.flag_traj_from_cam:                                  # get_traj_from_cam (:325-351), traj_interp_method 'linear_interp'
+            for d in persons.values():
+                w = np.matmul(data['cam_pose_inv'], d['person_transform_cam'])
+                d['person_transform_world'] = w
+                q = nt.rotmat_to_quat(np.ascontiguousarray(w[:, :3, :3]))
+                qi = nt.interp_orient_sep_heading(q[d['vis_frames']], d['vis_frames'])
+                d['root_trans_world'] = d['root_trans_world_base'] = np.ascontiguousarray(w[:, :3, 3]).astype(np.float32)
+                d['smpl_orient_world'] = d['smpl_orient_world_base'] = nt.quat_to_aa(qi).astype(np.float32)
         # heading initialisation from the camera (:273-292); the resulting world trajectory is produced by the device forward pass
         for d in persons.values():
             w = np.matmul(data['cam_pose_inv'], d['person_transform_cam'])
@@ -634,6 +649,8 @@ class GlobalReconOptimizer:
         the 'init' forward pass -- kernel launches only, nothing crosses PCIe.  Returns (datas, packed): `datas` are light
         per-sequence dictionaries that collect() completes from the device arrays."""
         import ctypes
+        if getattr(self, 'flag_traj_from_cam', False):
+            raise NotImplementedError('flag_traj_from_cam is initialised on the host: use optimize() / optimize_batch() (init_data_batch_host)')
         t1 = time.time()
         dev, L = self.device, _lib.lib()
         S, P, T, g = rin.S, rin.P, rin.T, rin.g
@@ -700,7 +717,7 @@ class GlobalReconOptimizer:
 
     def init_data_batch(self, in_dicts, latents=None, init_forward=True):
         """init_data (:76-248) for a batch of host dictionaries: stage_inputs + init_resident."""
-        if self.cam_fix_frames != [(0, None)]:
+        if self.cam_fix_frames != [(0, None)] or self.flag_traj_from_cam:
             return self.init_data_batch_host(in_dicts, latents)
         return self.init_resident(self.stage_inputs(in_dicts, latents), init_forward=init_forward)
 

@@ -319,3 +319,20 @@ def inject_orient_jumps(in_dict, idx, events):
             raise KeyError(ev[0])
     src['smpl_pose_quat_wroot'] = rot.reshape(rot.shape[0], -1, 4).astype(np.float32)
     return in_dict
+
+
+def trim_person(in_dict, idx, first, last):
+    """Person `idx` is detected only in frames [first, last): appears late / leaves early (ragged existence inside a sequence).  In place."""
+    src = in_dict['est'][idx]
+    ex = np.asarray(src['bboxes_dict']['exist']).copy()
+    keep_frames = np.flatnonzero(ex)
+    keep = (keep_frames >= first) & (keep_frames < last)
+    ex[:first] = 0
+    ex[last:] = 0
+    for k in ('smpl_pose_quat_wroot', 'smpl_beta', 'root_trans', 'kp_2d', 'cam_K'):
+        src[k] = src[k][keep]
+    frames = np.flatnonzero(ex)
+    src['frames'] = frames
+    src['frame2ind'] = {int(f): i for i, f in enumerate(frames)}
+    src['bboxes_dict'] = dict(src['bboxes_dict'], exist=ex, start=int(frames[0]), end=int(frames[-1]), num_frames=float(ex.sum()), exist_frames=frames)
+    return in_dict

@@ -435,7 +435,10 @@ def gen_grecon_family(cases=(('glamr_3dpw', 120, 1, 15),), members=KSTEP_FAMILY)
 
 
 # model flags no shipped config sets (global_recon_model.py:45): (tag, cfg, T, P, K, spec overrides, detection gap)
-FLAG_CASES = [('vis_local_rot', 'glamr_dynamic', 120, 1, 12, {'flag_opt_vis_local_rot': True}, (40, 70))]
+FLAG_CASES = [('vis_local_rot', 'glamr_dynamic', 120, 1, 12, {'flag_opt_vis_local_rot': True}, (40, 70), None),
+              # person 1 exists in frames [17, 83) of 100 only: flag_traj_from_cam decides the base pose of the frames outside that range
+              ('traj_from_cam', 'glamr_dynamic_multi', 100, 2, 8, {'flag_traj_from_cam': True}, None, (1, 17, 83))]
+FLAG_SEED = {'vis_local_rot': 3, 'traj_from_cam': 11}
 
 
 def gen_grecon_flags(cases=FLAG_CASES):
@@ -444,20 +447,24 @@ def gen_grecon_flags(cases=FLAG_CASES):
     from oracle import ref_harness as rh
     from glamr_amd.utils import synth
     md = synth.make_smpl_model()
-    for tag, cfg_id, T, P, K, flags, gap in cases:
+    for tag, cfg_id, T, P, K, flags, gap, trim in cases:
         model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
         for k, v in flags.items():
             assert hasattr(model, k), k
             setattr(model, k, v)
-        in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md, gap=gap)
-        data, init_state = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, 3), niters=K)
+        seed = FLAG_SEED[tag]
+        in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=md, gap=gap)
+        if trim:
+            synth.trim_person(in_dict, *trim)
+        data, init_state = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, seed), niters=K)
         out = {'init_' + k: v for k, v in init_state.items()}
         out.update({'opt_' + k: v for k, v in _flatten_state(data, PERSON_KEYS_OPT, TOP_KEYS).items()})
         out['niters'] = np.array(K)
         np.savez_compressed(os.path.join(GOLD, 'grecon_%s_T%d_P%d_%s.npz' % (cfg_id, T, P, tag)), **out)
         rot = out['opt_p0_traj_local_rot']
         vis = out['init_p0_vis_frames']
-        print('wrote', tag, cfg_id, T, P, '| traj_local_rot at invisible frames: max |.| = %.3g, at visible frames %.3g' % (np.abs(rot[~vis]).max(), np.abs(rot[vis]).max()))
+        print('wrote', tag, cfg_id, T, P, '| traj_local_rot at invisible frames: max |.| = %.3g, at visible frames %.3g'
+              % (np.abs(rot[~vis]).max() if (~vis).any() else 0.0, np.abs(rot[vis]).max()))
 
 
 def gen_full(which=('gap', 'nogap')):
