@@ -245,7 +245,7 @@ def kernel_lines(asset_root, model, dev):
                                        'ms_per_iteration_round3_host_orchestrated': 20.3,
                                        'note': 'slope between a %d- and a %d-iteration run (init_data, the two plain iterations and the capture cancel): from the third iteration of '
                                                'a stage on the iteration -- taped infiller (10 windows), trajectory predictor, skinning, one gradient launch of the stage kernel, '
-                                               'SMPL backward, infiller backward, two Adam steps with their step numbers on the device: ~2 600 launches -- is ONE replayed HIP graph' % (K1, K2)}
+                                               'SMPL backward, infiller backward, two Adam steps with their step numbers on the device: 1 271 kernels (profiles/r04_latent_kernel_stats.csv) -- is ONE replayed HIP graph' % (K1, K2)}
     return out
 
 

@@ -51,63 +51,92 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dY, con
 // recomputed.  O = P V, P = softmax(Q K^T / sqrt(32)) over the unmasked keys:
 //   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - rowsum(dP o P)),  dQ = dS K / sqrt(32),  dK = dS^T Q / sqrt(32)        (accumulated into dQ / dK / dV)
 // q_shared: the queries are constants shared by all sequences (the prior's learned tokens): no dQ.
-__global__ __launch_bounds__(64) void attention_bwd_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
-                                                           const float* dO, int ldo, float* dQ, float* dK, float* dV, int Lq, int Lk, int q_shared) {
-  __shared__ float sQ[64][33], sK[64][33], sV[64][33], sdO[64][33], sP[64][65], sdS[64][65];
+// 256 threads per (sequence, head): thread (i, g) = (row, quarter).  Every output element is formed by the SAME chain of operations as when one
+// lane did a whole row (round 3: 98 us per call, 70 calls per iteration of the latent-optimisation mode = a third of it): the rows' scores and
+// dO V^T are spread over the quarters by key (j = g mod 4), the softmax of a row stays with one thread, dQ / dK / dV are spread by channel
+// (8 of the 32 per thread).
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
+                                                            const float* dO, int ldo, float* dQ, float* dK, float* dV, int Lq, int Lk, int q_shared) {
+  // (rows of 36 floats: 16-byte aligned, so the channel loops below read four values per LDS instruction -- most of them broadcasts of one key row)
+  __shared__ __attribute__((aligned(16))) float sQ[64][36], sK[64][36], sV[64][36], sdO[64][36];
+  __shared__ float sP[64][65], sdS[64][65];
   __shared__ unsigned char sM[64];
-  const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, i = tid & 63, g = tid >> 6;
   const float scale = 0.17677669529663687f;      // 1 / sqrt(32)
-  for (int idx = lane; idx < 64 * 32; idx += 64) {
-    const int i = idx >> 5, d = idx & 31;
-    sQ[i][d] = i < Lq ? Q[(size_t)((q_shared ? 0 : b * Lq) + i) * ldq + h * 32 + d] : 0.f;
-    sdO[i][d] = i < Lq ? dO[(size_t)(b * Lq + i) * ldo + h * 32 + d] : 0.f;
-    sK[i][d] = i < Lk ? K[(size_t)(b * Lk + i) * ldk + h * 32 + d] : 0.f;
-    sV[i][d] = i < Lk ? V[(size_t)(b * Lk + i) * ldk + h * 32 + d] : 0.f;
+  for (int idx = tid; idx < 64 * 32; idx += 256) {
+    const int r = idx >> 5, d = idx & 31;
+    sQ[r][d] = r < Lq ? Q[(size_t)((q_shared ? 0 : b * Lq) + r) * ldq + h * 32 + d] : 0.f;
+    sdO[r][d] = r < Lq ? dO[(size_t)(b * Lq + r) * ldo + h * 32 + d] : 0.f;
+    sK[r][d] = r < Lk ? K[(size_t)(b * Lk + r) * ldk + h * 32 + d] : 0.f;
+    sV[r][d] = r < Lk ? V[(size_t)(b * Lk + r) * ldk + h * 32 + d] : 0.f;
   }
-  sM[lane] = (lane < Lk) ? (key_mask ? key_mask[(size_t)b * Lk + lane] : 0) : 1;
+  if (tid < 64) sM[tid] = (tid < Lk) ? (key_mask ? key_mask[(size_t)b * Lk + tid] : 0) : 1;
   __syncthreads();
-  // lane = query row i
-  const int i = lane;
+  // scaled scores and dP = dO V^T of row i, keys j = g, g + 4, ...
   if (i < Lq) {
-    float mx = -3.0e38f;
-    for (int j = 0; j < Lk; ++j) {
-      float s = 0.f;
-      for (int d = 0; d < 32; ++d) s = fmaf(sQ[i][d], sK[j][d], s);
-      s *= scale;
-      sP[i][j] = s;
-      if (!sM[j]) mx = fmaxf(mx, s);
+    float q[32], o[32];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sQ[i][d4 * 4]), b4 = *reinterpret_cast<const f32x4*>(&sdO[i][d4 * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { q[d4 * 4 + e] = a4[e]; o[d4 * 4 + e] = b4[e]; }
     }
+    for (int j = g; j < Lk; j += 4) {
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < 8; ++d4) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(&sK[j][d4 * 4]), v4 = *reinterpret_cast<const f32x4*>(&sV[j][d4 * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc = fmaf(q[d4 * 4 + e], k4[e], sc); dp = fmaf(o[d4 * 4 + e], v4[e], dp); }
+      }
+      sP[i][j] = sc * scale;
+      sdS[i][j] = dp;
+    }
+  } else {
+    for (int j = g; j < 64; j += 4) { sP[i][j] = 0.f; sdS[i][j] = 0.f; }
+  }
+  __syncthreads();
+  // softmax over the unmasked keys and dS = P o (dP - rowsum(dP o P)): one thread per row
+  if (g == 0 && i < Lq) {
+    float mx = -3.0e38f;
+    for (int j = 0; j < Lk; ++j) if (!sM[j]) mx = fmaxf(mx, sP[i][j]);
     float sum = 0.f;
     for (int j = 0; j < Lk; ++j) { const float e = sM[j] ? 0.f : expf(sP[i][j] - mx); sP[i][j] = e; sum += e; }
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
     float dot = 0.f;
-    for (int j = 0; j < Lk; ++j) {
-      const float p = sP[i][j] * inv;
-      sP[i][j] = p;
-      float dp = 0.f;
-      for (int d = 0; d < 32; ++d) dp = fmaf(sdO[i][d], sV[j][d], dp);
-      sdS[i][j] = dp;
-      dot = fmaf(dp, p, dot);
-    }
+    for (int j = 0; j < Lk; ++j) { const float p = sP[i][j] * inv; sP[i][j] = p; dot = fmaf(sdS[i][j], p, dot); }
     for (int j = 0; j < Lk; ++j) sdS[i][j] = sP[i][j] * (sdS[i][j] - dot);
-    if (dQ && !q_shared)
-      for (int d = 0; d < 32; ++d) {
-        float acc = 0.f;
-        for (int j = 0; j < Lk; ++j) acc = fmaf(sdS[i][j], sK[j][d], acc);
-        dQ[(size_t)(b * Lq + i) * ldq + h * 32 + d] += acc * scale;
-      }
-  } else {
-    for (int j = 0; j < 64; ++j) { sP[i][j] = 0.f; sdS[i][j] = 0.f; }
   }
   __syncthreads();
-  // lane = key row j
-  const int j = lane;
-  if (j < Lk) {
-    for (int d = 0; d < 32; ++d) {
-      float gk = 0.f, gv = 0.f;
-      for (int q = 0; q < Lq; ++q) { gk = fmaf(sdS[q][j], sQ[q][d], gk); gv = fmaf(sP[q][j], sdO[q][d], gv); }
-      dK[(size_t)(b * Lk + j) * ldk + h * 32 + d] += gk * scale;
-      dV[(size_t)(b * Lk + j) * ldk + h * 32 + d] += gv;
+  const int d0 = g * 8;
+  if (i < Lq && dQ && !q_shared) {               // dQ = dS K / sqrt(32): row i, channels d0 .. d0 + 7
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < Lk; ++j) {
+      const float ds = sdS[i][j];
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(&sK[j][d0]), k1 = *reinterpret_cast<const f32x4*>(&sK[j][d0 + 4]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) { acc[d] = fmaf(ds, k0[d], acc[d]); acc[4 + d] = fmaf(ds, k1[d], acc[4 + d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dQ[(size_t)(b * Lq + i) * ldq + h * 32 + d0 + d] += acc[d] * scale;
+  }
+  if (i < Lk) {                                  // dK = dS^T Q / sqrt(32), dV = P^T dO: key row j = i, channels d0 .. d0 + 7
+    const int j = i;
+    float gk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int qr = 0; qr < Lq; ++qr) {
+      const float ds = sdS[qr][j], pp = sP[qr][j];
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(&sQ[qr][d0]), q1 = *reinterpret_cast<const f32x4*>(&sQ[qr][d0 + 4]);
+      const f32x4 o0 = *reinterpret_cast<const f32x4*>(&sdO[qr][d0]), o1 = *reinterpret_cast<const f32x4*>(&sdO[qr][d0 + 4]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        gk[d] = fmaf(ds, q0[d], gk[d]); gk[4 + d] = fmaf(ds, q1[d], gk[4 + d]);
+        gv[d] = fmaf(pp, o0[d], gv[d]); gv[4 + d] = fmaf(pp, o1[d], gv[4 + d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      dK[(size_t)(b * Lk + j) * ldk + h * 32 + d0 + d] += gk[d] * scale;
+      dV[(size_t)(b * Lk + j) * ldk + h * 32 + d0 + d] += gv[d];
     }
   }
 }
@@ -231,7 +260,7 @@ int ln_bwd(const TapeCtx& c, const LN& n, const float* dY, const float* X, const
 }
 void attn_bwd(const TapeCtx& c, const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* mask, const float* dO, float* dQ, float* dK,
               float* dV, int B, int Lq, int Lk, int q_shared) {
-  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B, 8), dim3(64), 0, c.st, Q, ldq, K, V, ldk, mask, dO, D, dQ, dK, dV, Lq, Lk, q_shared);
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B, 8), dim3(256), 0, c.st, Q, ldq, K, V, ldk, mask, dO, D, dQ, dK, dV, Lq, Lk, q_shared);
 }
 
 // ---- forward of one window, every activation kept (mirrors infiller_window / encoder_layer / decoder_layer, small-batch path) -------

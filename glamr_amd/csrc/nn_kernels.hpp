@@ -32,8 +32,11 @@ struct GemmArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float sA[GT_M * GT_LD];
-  __shared__ __attribute__((aligned(16))) float sB[GT_N * GT_LD];
+  // (two LDS buffers: one barrier per 32-deep chunk; the chunks' global loads run GT_PF chunks ahead in registers.  Round 3 loaded a chunk,
+  // waited, stored it and computed, with two barriers: a call with 64 rows -- the latent-optimisation mode makes 670 per iteration -- spent
+  // 8 memory latencies on K = 256: 14.8 us)
+  __shared__ __attribute__((aligned(16))) float sA[2][GT_M * GT_LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][GT_N * GT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int col = lane & 31, half = lane >> 5;
@@ -41,30 +44,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   f32x16 acc = {0};
   // staging map: 512 float4 per operand tile, two per thread
   const int r0 = tid >> 3, c4 = (tid & 7) * 4;          // rows r0 and r0 + 32, k offset c4
-  for (int k0 = 0; k0 < a.K; k0 += GT_K) {
-    f32x4 va[2], vb[2];
+  constexpr int GT_PF = 4;
+  const int nchunks = a.K / GT_K;
+  f32x4 va[GT_PF][2], vb[GT_PF][2];
+  const float* xa[2];
+  const float* xb[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = r0 + q * 32;
+    xa[q] = a.X + (size_t)min(m0 + r, a.M - 1) * a.ldx + c4;
+    xb[q] = a.W + (size_t)(n0 + r) * a.K + c4;
+  }
+  auto fetch = [&](int c, int slot) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int r = r0 + q * 32;
-      const int gm = min(m0 + r, a.M - 1);
-      va[q] = *reinterpret_cast<const f32x4*>(a.X + (size_t)gm * a.ldx + k0 + c4);
-      vb[q] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + r) * a.K + k0 + c4);
+      va[slot][q] = *reinterpret_cast<const f32x4*>(xa[q] + c * GT_K);
+      vb[slot][q] = *reinterpret_cast<const f32x4*>(xb[q] + c * GT_K);
     }
-    __syncthreads();
+  };
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      *reinterpret_cast<f32x4*>(sA + (r0 + q * 32) * GT_LD + c4) = va[q];
-      *reinterpret_cast<f32x4*>(sB + (r0 + q * 32) * GT_LD + c4) = vb[q];
-    }
-    __syncthreads();
-    const float* pa = sA + (wm * 32 + col) * GT_LD + half * 16;
-    const float* pb = sB + (wn * 32 + col) * GT_LD + half * 16;
+  for (int u = 0; u < GT_PF; ++u) if (u < nchunks) fetch(u, u);
+  for (int c0 = 0; c0 < nchunks; c0 += GT_PF) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(pa + s4 * 4);
-      const f32x4 w = *reinterpret_cast<const f32x4*>(pb + s4 * 4);
+    for (int u = 0; u < GT_PF; ++u) {
+      const int c = c0 + u;
+      if (c >= nchunks) break;
+      float* bA = sA[c & 1];
+      float* bB = sB[c & 1];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], w[s], acc, 0, 0, 0);
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<f32x4*>(bA + (r0 + q * 32) * GT_LD + c4) = va[u][q];
+        *reinterpret_cast<f32x4*>(bB + (r0 + q * 32) * GT_LD + c4) = vb[u][q];
+      }
+      __syncthreads();
+      if (c + GT_PF < nchunks) fetch(c + GT_PF, u);
+      const float* pa = bA + (wm * 32 + col) * GT_LD + half * 16;
+      const float* pb = bB + (wn * 32 + col) * GT_LD + half * 16;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(pa + s4 * 4);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(pb + s4 * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], w[s], acc, 0, 0, 0);
+      }
     }
   }
   // epilogue: lane owns column n0 + wn*32 + col, rows (r & 3) + 8 (r >> 2) + 4 half
@@ -1018,6 +1040,8 @@ inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, 
       hipLaunchKernelGGL((gemm_split_kernel<1>), dim3(npad / 64, ((M + 127) / 128 + 7) / 8 * 8), dim3(256), 0, st, a);
     return GLAMR_OK;
   }
+  // (measured and dropped, round 4: the K loop of a tile over two groups of four waves for grids of a handful of workgroups -- 13.3 against 12.4 us
+  // per call at M = 50: these calls are launch + latency, not the chain of fp32 MFMAs)
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M), dim3(256), 0, st, a);
   return GLAMR_OK;
 }
