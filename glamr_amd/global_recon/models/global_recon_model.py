@@ -1200,7 +1200,8 @@ class GlobalReconOptimizer:
         # tools/stream_yield_probe.py).  While the stream runs, everything alive at its start sits in the permanent generation (gc.freeze):
         # collections still run, over the objects created since.  GLAMR_STREAM_GC_FREEZE=0 leaves the collector alone.
         import gc
-        frozen = gc.isenabled() and os.environ.get('GLAMR_STREAM_GC_FREEZE', '1') != '0'
+        # (a caller that keeps a frozen set of its own -- gc.get_freeze_count() > 0 -- manages the collector itself: gc.unfreeze() would release ITS set too)
+        frozen = gc.isenabled() and gc.get_freeze_count() == 0 and os.environ.get('GLAMR_STREAM_GC_FREEZE', '1') != '0'
         if frozen:
             gc.collect()
             gc.freeze()
