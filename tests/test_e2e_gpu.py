@@ -367,6 +367,46 @@ def test_person_entering_late_and_leaving_early_matches_the_oracle(make_model, a
     assert int(data['person_data'][1]['fr_start']) == seen[0] == 17 and int(data['person_data'][1]['fr_end']) == seen[-1] + 1 < 100
 
 
+def test_nine_person_scene_with_ragged_existence_matches_the_oracle(make_model, asset_root):
+    """A scene that needs the wide instances of the stage kernel (csrc/grecon_wide.hip: more than 8 persons) AND the frame bookkeeping of persons
+    that enter late, leave early or go undetected for a while, in one batch with a short single-person sequence (person slots and frames padded).
+    Device path against the CPU restatement (oracle/port, pinned to the reference on the fixture cases): init_data, then 4 iterations per stage."""
+    import copy
+    from oracle.port import build
+    from glamr_amd.global_recon.configs import get_config
+    md = synth.make_smpl_model()
+    in_dict = synth.make_in_dict(seed=21, num_frames=64, num_persons=9, smpl_model=md, gap=(20, 30))
+    synth.trim_person(in_dict, 2, 9, 50)
+    synth.trim_person(in_dict, 5, 0, 41)
+    synth.trim_person(in_dict, 8, 23, 64)
+    other = synth.make_in_dict(seed=22, num_frames=40, num_persons=1, smpl_model=md)
+    lat, lat_o = mg.latents_for(in_dict, 21), mg.latents_for(other, 22)
+    K = 4
+    cfg = get_config('glamr_dynamic_multi')
+    for spec in cfg['opt_stage_specs'].values():
+        spec['opt_niters'] = K
+    ora = build.load_optimizer(asset_root, cfg)
+    ref = ora.optimize(copy.deepcopy(in_dict), latents=lat)
+    model = make_model('glamr_dynamic_multi')
+    out = model.optimize_batch([in_dict, other], latents=[lat, lat_o], max_iters=K)[0]
+    alone = model.optimize(in_dict, latents=lat, max_iters=K)
+    worst = [0.0, 0.0, 0.0]
+    for pi in range(9):
+        a, b = out['person_data'][pi], ref['person_data'][pi]
+        assert int(a['fr_start']) == int(b['fr_start']) and int(a['fr_end']) == int(b['fr_end'])
+        for key in ('visible', 'exist_frames', 'vis_frames'):
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]).astype(np.asarray(a[key]).dtype)), key
+        vis = np.asarray(b['vis_frames']).astype(bool) & np.asarray(ref['person_data'][0]['vis_frames']).astype(bool)
+        worst[0] = max(worst[0], kp_err(a['kp_2d_pred'], np.asarray(b['kp_2d_pred']), vis))
+        worst[1] = max(worst[1], float(np.abs(np.asarray(a['root_trans_world'], np.float64) - np.asarray(b['root_trans_world'])).max()))
+        worst[2] = max(worst[2], _rot_err(a['smpl_orient_world'], np.asarray(b['smpl_orient_world'])))
+        # padding the batch (a second, shorter sequence with one person) changes nothing
+        assert np.array_equal(np.asarray(a['kp_2d_pred']), np.asarray(alone['person_data'][pi]['kp_2d_pred']))
+    print('9 persons, ragged existence, %d iterations per stage, against the CPU restatement: kp %.4f px, root_trans_world %.2e m, smpl_orient_world %.2e' % (K, *worst))
+    assert worst[0] < 0.1 and worst[1] < 1e-3 and worst[2] < 5e-3
+    assert [int(out['person_data'][i]['fr_start']) for i in (2, 5, 8)] == [9, 0, 23]
+
+
 def test_ragged_batch_equals_single_runs(make_model):
     """optimize_batch pads sequences to the longest one and person slots to the largest count: every sequence of a mixed batch must
     come out as when it is run alone (up to the rounding of the different kernel instances: single-person scenes run a
