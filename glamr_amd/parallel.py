@@ -216,7 +216,7 @@ class PersonShardedSchedule:
             for it in range(n):
                 keep = packing.FLAG_KEEP_CAM_PARAMS if it > 0 else 0
                 fwd = packing.stage_desc(spec, model_specs, has_wd, niters=0)
-                fwd.flags |= keep
+                fwd.flags |= keep | packing.FLAG_POSES_ONLY                         # (only the world poses are wanted: no residuals, no projections)
                 self.run_stage(packed, fwd, False)                                   # 1. own poses at the current parameters (+ camera parameters at it 0)
                 self._all_gather_poses(packed, own, block)                           # 2.
                 gd = packing.stage_desc(spec, model_specs, has_wd, niters=1)
