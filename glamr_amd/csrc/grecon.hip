@@ -123,6 +123,11 @@ extern "C" size_t glamr_grecon_workspace_bytes(int n_scenes, int max_persons, in
   if (n_scenes <= 0 || max_persons < 1 || max_persons > WIDE_MAX_PERSONS || max_len < 2) return 0;
 #ifndef GLAMR_GRECON_WIDE
   if (max_persons > MAXP) return glamr_grecon_workspace_bytes_wide_(n_scenes, max_persons, max_len);
+  {      // a stage with a flag only the wide instances know (GLAMR_FLAG_ABSOLUTE_HEADING) runs there with ITS workspace layout: the larger of the two
+    const size_t wide = glamr_grecon_workspace_bytes_wide_(n_scenes, max_persons, max_len);
+    const size_t own = GLAMR_GRECON_WS_HEADER + (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, layout_frames(max_persons, max_len)), 64) * sizeof(float);
+    return wide > own ? wide : own;
+  }
 #endif
   return GLAMR_GRECON_WS_HEADER + (size_t)n_scenes * align_up(scene_workspace_floats(max_persons, layout_frames(max_persons, max_len)), 64) * sizeof(float);
 }
@@ -133,7 +138,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   GLAMR_REQUIRE(batch->n_scenes > 0 && batch->max_persons >= 1 && batch->max_persons <= WIDE_MAX_PERSONS && batch->max_len >= 2,
                 "bad batch geometry: n_scenes=%d max_persons=%d (at most %d) max_len=%d", batch->n_scenes, batch->max_persons, WIDE_MAX_PERSONS, batch->max_len);
 #ifndef GLAMR_GRECON_WIDE
-  if (batch->max_persons > MAXP) {
+  if (batch->max_persons > MAXP || (stage && (stage->flags & GLAMR_FLAG_ABSOLUTE_HEADING))) {
     const int rc = glamr_grecon_run_stage_wide_(batch, stage, grads_out, workspace, stream_);
     if (rc == GLAMR_OK) record_launch(workspace, static_cast<hipStream_t>(stream_));
     return rc;

@@ -908,6 +908,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         }
         pv(p).theta[t] = v;
       }
+#ifdef GLAMR_GRECON_WIDE      // absolute_heading (:59,283,421): the per-frame headings are not summed up (traj_local2global_heading(local_heading=False))
+    if (st.flags & GLAMR_FLAG_ABSOLUTE_HEADING) rt.sync(); else
+#endif
     {
       float* ch[8];
       if constexpr (MAXP <= 8) {
@@ -1577,6 +1580,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             if (upd_dxy) a_dxy.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_dxy + e * 2, g2, ac);
           }
         }
+#ifdef GLAMR_GRECON_WIDE      // (absolute_heading: a frame's heading gradient is its own)
+      if (st.flags & GLAMR_FLAG_ABSOLUTE_HEADING) rt.sync(); else
+#endif
       {
         float* ch[8];
         if constexpr (MAXP <= 8) {

@@ -211,8 +211,13 @@ class GlobalReconOptimizer:
         self.flag_traj_from_cam = bool(g('flag_traj_from_cam', False))
         if self.flag_traj_from_cam and g('traj_interp_method', 'linear_interp') != 'linear_interp':
             raise NotImplementedError("flag_traj_from_cam with traj_interp_method other than 'linear_interp'")
+        # absolute_heading (:59,283,421): the heading entries of the local trajectory are absolute -- packing.stage_desc passes
+        # GLAMR_FLAG_ABSOLUTE_HEADING, and every launch of the stage kernel (the 'init' forward passes included) then runs on the instances of
+        # csrc/grecon_wide.hip.  (In latent mode the reference also converts the PREDICTED headings before opt_latent_start_iter, :441-444: refused.)
+        if g('absolute_heading', False) and (g('flag_opt_motion_latent', False) or g('flag_opt_traj_latent', False)):
+            raise NotImplementedError('absolute_heading together with the latent-optimisation mode')
         for flag in ('flag_opt_person2cam_rot',
-                     'flag_opt_person2cam_trans', 'flag_use_pen_loss', 'absolute_heading'):
+                     'flag_opt_person2cam_trans', 'flag_use_pen_loss'):
             if g(flag, False):
                 raise NotImplementedError('%s is not supported by the MI355X path' % flag)
         if g('heading_type', 'scalar') != 'scalar' or not g('flag_cam_inv_trans_res_all', True) or not g('flag_opt_cam', True):

@@ -17,6 +17,7 @@ VAR_BITS = {'cam': 1, 'local_xy': 2, 'local_heading': 4, 'world_dheading': 8, 'l
 FLAG_FIXED_CAM, FLAG_CAM_FROM_PERSON, FLAG_HAS_WORLD_DHEADING = 1, 2, 4
 FLAG_KEEP_CAM_PARAMS, FLAG_NO_CAMERA_TERMS = 8, 16          # launch-by-launch stages (glamr_amd/parallel.py PersonShardedSchedule)
 FLAG_POSES_ONLY = 32                                       # a forward-only launch that stops after the world poses
+FLAG_ABSOLUTE_HEADING = 64                                 # specs absolute_heading: per-frame headings are absolute (csrc/grecon_wide.hip instances)
 
 
 def param_layout_py(max_persons, max_len):
@@ -48,6 +49,8 @@ def stage_desc(stage_specs, model_specs, has_world_dheading=False, niters=None):
         flags |= FLAG_CAM_FROM_PERSON
     if has_world_dheading:
         flags |= FLAG_HAS_WORLD_DHEADING
+    if model_specs.get('absolute_heading', False):
+        flags |= FLAG_ABSOLUTE_HEADING
     sd.flags = flags
     sd.niters = stage_specs['opt_niters'] if niters is None else niters
     sd.lr = stage_specs['opt_lr']

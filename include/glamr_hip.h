@@ -232,6 +232,10 @@ int glamr_traj_local_to_global(int n_seq, int T, const float* local_traj, float*
                                                       projections, no loss values.  init_data's forward pass before init_cam_pose(all_frames=True)
                                                       (global_recon_model.py:243-246) is followed by a full one whenever its outputs are used */
 
+#define GLAMR_FLAG_ABSOLUTE_HEADING (1u << 6)      /* absolute_heading (global_recon_model.py:59,283,421; no shipped config): the heading entries of the local
+                                                      trajectory are absolute, not increments.  Runs on the instances of csrc/grecon_wide.hip whatever the
+                                                      number of persons (the instances with the on-chip arena are compiled without it) */
+
 /* loss ids (loss_func_dict, loss_func.py:314-340) -- order of glamr_stage_desc.loss_weight[] */
 enum {
   GLAMR_LOSS_KP_2D = 0, GLAMR_LOSS_KP_2D_DIST, GLAMR_LOSS_REL_TRANSFORM, GLAMR_LOSS_CAM_TRAJ_ROT,

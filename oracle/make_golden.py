@@ -437,8 +437,11 @@ def gen_grecon_family(cases=(('glamr_3dpw', 120, 1, 15),), members=KSTEP_FAMILY)
 # model flags no shipped config sets (global_recon_model.py:45): (tag, cfg, T, P, K, spec overrides, detection gap)
 FLAG_CASES = [('vis_local_rot', 'glamr_dynamic', 120, 1, 12, {'flag_opt_vis_local_rot': True}, (40, 70), None),
               # person 1 exists in frames [17, 83) of 100 only: flag_traj_from_cam decides the base pose of the frames outside that range
-              ('traj_from_cam', 'glamr_dynamic_multi', 100, 2, 8, {'flag_traj_from_cam': True}, None, (1, 17, 83))]
-FLAG_SEED = {'vis_local_rot': 3, 'traj_from_cam': 11}
+              ('traj_from_cam', 'glamr_dynamic_multi', 100, 2, 8, {'flag_traj_from_cam': True}, None, (1, 17, 83)),
+              # the heading entries of the local trajectory read as absolute angles (the shipped predictor emits increments: a different motion, same code path)
+              ('absolute_heading', 'glamr_dynamic', 90, 1, 10, {'absolute_heading': True}, None, None),
+              ('absolute_heading', 'glamr_static_multi', 80, 2, 8, {'absolute_heading': True}, (30, 40), None)]
+FLAG_SEED = {'vis_local_rot': 3, 'traj_from_cam': 11, 'absolute_heading': 5}
 
 
 def gen_grecon_flags(cases=FLAG_CASES):
@@ -456,6 +459,20 @@ def gen_grecon_flags(cases=FLAG_CASES):
         in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=md, gap=gap)
         if trim:
             synth.trim_person(in_dict, *trim)
+        if flags.get('absolute_heading'):
+            # run_reference switches the latent-optimisation flags on around init_data -- the only way to hand the reference GIVEN latent draws -- and
+            # with those flags forward() also rewrites the predicted headings (cumsum, :441-444) when absolute_heading is set.  A user of the plain
+            # mode never has them on: forward() runs with the flags as such a user has them
+            orig = model.forward
+
+            def fwd(data_, opt_variables, opt_meta, orig=orig, model=model):
+                keep = (model.flag_opt_motion_latent, model.flag_opt_traj_latent)
+                model.flag_opt_motion_latent = model.flag_opt_traj_latent = False
+                try:
+                    return orig(data_, opt_variables, opt_meta)
+                finally:
+                    model.flag_opt_motion_latent, model.flag_opt_traj_latent = keep
+            model.forward = fwd
         data, init_state = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, seed), niters=K)
         out = {'init_' + k: v for k, v in init_state.items()}
         out.update({'opt_' + k: v for k, v in _flatten_state(data, PERSON_KEYS_OPT, TOP_KEYS).items()})

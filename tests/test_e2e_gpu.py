@@ -152,6 +152,43 @@ def test_flag_traj_from_cam_matches_the_reference(make_model, golden):
         model.optimize_resident(model.stage_inputs([in_dict]))
 
 
+@pytest.mark.parametrize('case', [c for c in mg.FLAG_CASES if c[0] == 'absolute_heading'], ids=lambda c: '%s-%d-%d' % (c[1], c[2], c[3]))
+def test_absolute_heading_matches_the_reference(make_model, golden, case):
+    """absolute_heading (global_recon_model.py:59,283,421; no shipped config): the heading entries of the local trajectory are absolute angles, so
+    traj_local2global_heading sums nothing up.  Fixtures: the unmodified reference with the flag on (the shipped trajectory predictor emits
+    INCREMENTS, so this is another motion than the default's -- the same code path).  Every launch of the stage kernel, the 'init' forward passes
+    included, then runs on the instances of csrc/grecon_wide.hip (GLAMR_FLAG_ABSOLUTE_HEADING)."""
+    from glamr_amd.global_recon.models import model_dict
+    from glamr_amd.global_recon.configs import get_config
+    tag, cfg_id, T, P, K, flags, gap, _ = case
+    g = golden('grecon_%s_T%d_P%d_%s' % (cfg_id, T, P, tag))
+    base = make_model(cfg_id)
+    cfg = get_config(cfg_id)
+    cfg['grecon_model_specs'].update(flags)
+    model = model_dict['global_recon_model'](cfg, base.device, None, smpl=base.smpl, mt_model=base.mt_model)
+    seed = mg.FLAG_SEED[tag]
+    in_dict = synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model(), gap=gap)
+    lat = mg.latents_for(in_dict, seed)
+    data = model.init_data(in_dict, latents=lat)
+    plain = base.init_data(in_dict, latents=lat)
+    for pi in range(P):
+        pd = data['person_data'][pi]
+        assert _rot_err(pd['smpl_orient_world'], g['init_p%d_smpl_orient_world' % pi]) < 5e-4
+        assert np.abs(np.asarray(pd['root_trans_world'], np.float64) - g['init_p%d_root_trans_world' % pi]).max() < 5e-4
+    # the flag matters: the default reading of the same predictor output is another trajectory
+    assert np.abs(np.asarray(plain['person_data'][0]['root_trans_world'], np.float64) - g['init_p0_root_trans_world']).max() > 1e-2
+    out = model.optimize(in_dict, latents=lat, max_iters=K)
+    worst = [0.0, 0.0, 0.0]
+    for pi in range(P):
+        pd = out['person_data'][pi]
+        vis = g['init_p%d_vis_frames' % pi] & g['init_p0_vis_frames']
+        worst[0] = max(worst[0], kp_err(pd['kp_2d_pred'], g['opt_p%d_kp_2d_pred' % pi], vis))
+        worst[1] = max(worst[1], float(np.abs(pd['root_trans_world'] - g['opt_p%d_root_trans_world' % pi]).max()))
+        worst[2] = max(worst[2], _rot_err(pd['smpl_orient_world'], g['opt_p%d_smpl_orient_world' % pi]))
+    print('absolute_heading %s T=%d P=%d, %d iterations per stage: kp %.4f px, root_trans_world %.2e m, smpl_orient_world %.2e' % (cfg_id, T, P, K, *worst))
+    assert worst[0] < 0.05 and worst[1] < 1e-5 and worst[2] < 7e-3          # achieved 0.014 / 0.0004 px, 5e-7 / 7e-7 m, 2.2e-3 / 2.9e-4
+
+
 def _full_schedule(make_model, golden, tag, gap, host_init=False):
     g = golden('full_glamr_dynamic_T300' + tag)
     md = synth.make_smpl_model()
