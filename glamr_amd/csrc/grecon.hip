@@ -323,7 +323,8 @@ extern "C" int glamr_adam_step(int n, float* params, float* exp_avg, float* exp_
   if (n == 0) return GLAMR_OK;
   float tab[2];
   adam_coef_host(lr, step, tab);
-  AdamCoef c{tab[0], tab[1]};
+  AdamCoef c{tab[0], tab[1], 0.0f};
+  c.inv_bc2_sqrt = 1.0f / tab[1];            // (host: IEEE division)
   hipLaunchKernelGGL(adam_step_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), n, params, exp_avg, exp_avg_sq, grad, c);
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
@@ -334,7 +335,8 @@ extern "C" int glamr_adam_step(int n, float* params, float* exp_avg, float* exp_
 __global__ void adam_step_indexed_kernel(int n, float* p, float* m, float* v, const float* g, const float* coef, const int32_t* step_index) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = *step_index;
-  const glamr::grecon::AdamCoef c{coef[2 * k], coef[2 * k + 1]};
+  glamr::grecon::AdamCoef c{coef[2 * k], coef[2 * k + 1], 0.0f};
+  c.finish();
   if (i < n) glamr::grecon::adam(p[i], m[i], v[i], g[i], c);
 }
 __global__ void counter_add_kernel(int32_t* c, int value) { *c += value; }

@@ -194,7 +194,11 @@ struct SceneView {
 GLAMR_HD float gmof(float x, float sigma2) { return sigma2 * x * x / (sigma2 + x * x); }
 GLAMR_HD float gmof_d(float x, float sigma2) { const float r = rm::rcp_(sigma2 + x * x); return 2.0f * sigma2 * sigma2 * x * r * r; }
 
-struct AdamCoef { float neg_step; float bc2_sqrt; };   // -lr / (1 - beta1^t),  sqrt(1 - beta2^t)   (both formed in double, as Python does)
+struct AdamCoef {
+  float neg_step; float bc2_sqrt;    // -lr / (1 - beta1^t),  sqrt(1 - beta2^t)   (both formed in double, as Python does)
+  float inv_bc2_sqrt;                // RN(1 / bc2_sqrt): see adam()
+  GLAMR_HD void finish() { inv_bc2_sqrt = rm::div_(1.0f, bc2_sqrt); }
+};
 constexpr int ADAM_TAB_MAX = 4096;
 // torch/optim/adam.py: bias_correction = 1 - beta ** step (Python float pow), step_size = lr / bias_correction1,
 // bias_correction2_sqrt = bias_correction2 ** 0.5; both reach the fp32 kernels as scalars rounded from double.  Host only (libm pow).
@@ -213,7 +217,13 @@ inline void adam_coef_host(double lr, int step, float out[2]) {
 GLAMR_HD void adam(float& p, float& m, float& v, float g, const AdamCoef& c) {
   m = rm::fma_(0.1f, g - m, m);
   v = rm::fma_(0.001f * g, g, v * 0.999f);
-  const float denom = rm::div_(rm::sqrt_rn_(v), c.bc2_sqrt) + 1e-8f;
+  // sqrt(v) / bc2_sqrt: the divisor is the same for every parameter of an iteration, so its correctly rounded reciprocal y is formed once
+  // (AdamCoef::finish) and the correctly rounded quotient costs three operations per parameter instead of a reciprocal and seven:
+  //     q = RN(a y),  r = a - b q (exact in an fma),  RN(q + r y) = RN(a / b)       (Markstein 1990; no overflow / underflow here: a is 0
+  // or >= 3.7e-23, 0.03 < b <= 1).  Checked against IEEE division bit for bit (tests/test_adam_exact.py: host runtime and device).
+  const float a = rm::sqrt_rn_(v);
+  const float q = a * c.inv_bc2_sqrt;
+  const float denom = rm::fma_(rm::fma_(-c.bc2_sqrt, q, a), c.inv_bc2_sqrt, q) + 1e-8f;
   p = p + rm::div_(c.neg_step * m, denom);
 }
 
@@ -887,6 +897,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       ac.neg_step = (float)(-(st.lr / (1.0 - b1p)));
       ac.bc2_sqrt = (float)sqrt(1.0 - b2p);
     }
+    ac.finish();
     ++n_done;
     float lsum[GLAMR_NUM_LOSSES];
     for (int i = 0; i < GLAMR_NUM_LOSSES; ++i) lsum[i] = 0.f;

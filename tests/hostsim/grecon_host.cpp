@@ -140,6 +140,7 @@ extern "C" int hostsim_grecon_run_stage_arena_grads(const glamr_scene_batch* b, 
 extern "C" void hostsim_adam_step(int n, float* p, float* m, float* v, const float* g, double lr, int step) {
   float tab[2];
   adam_coef_host(lr, step, tab);
-  const AdamCoef c{tab[0], tab[1]};
+  AdamCoef c{tab[0], tab[1], 0.0f};
+  c.finish();
   for (int i = 0; i < n; ++i) adam(p[i], m[i], v[i], g[i], c);
 }

@@ -90,6 +90,60 @@ def test_host_runtime_update_is_the_restatement_bit_for_bit(lr):
         assert np.array_equal(M, m) and np.array_equal(V, v) and np.array_equal(P, p), 'step %d' % (k + 1)
 
 
+def _states(n, seed):
+    """Moments of every size an optimisation meets (second moments down to the smallest normal numbers and exact zeros)."""
+    rng = np.random.default_rng(seed)
+    g = (rng.normal(size=n) * 10.0 ** rng.uniform(-12, 11, size=n)).astype(f32)
+    m = (rng.normal(size=n) * 10.0 ** rng.uniform(-12, 11, size=n)).astype(f32)
+    v = (10.0 ** rng.uniform(-37, 22, size=n)).astype(f32)
+    g[::97] = 0.0
+    v[::53] = 0.0
+    m[::53] = 0.0
+    p = rng.normal(size=n).astype(f32)
+    return p, m, v, g
+
+
+STEPS_ANY = [1, 2, 3, 7, 10, 31, 100, 199, 200, 499, 500, 699, 700, 1000, 2048, 4095, 4096]
+
+
+def test_host_runtime_division_by_the_step_constant_is_ieee_at_every_step():
+    """adam() divides sqrt(v) by sqrt(1 - beta2^t) through the constant's correctly rounded reciprocal (q = a y, r = a - b q, q + r y: three
+    operations instead of a division per parameter).  Against the IEEE quotient of the restatement, for step numbers over the whole table
+    (every t is another divisor) and moments of every size."""
+    from tests import hostsim
+    lib = hostsim.build('grecon_host')
+    fn = lib.hostsim_adam_step
+    fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_int]
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n = 20000
+    for step in STEPS_ANY:
+        p, m, v, g = _states(n, step)
+        wp, wm, wv = adam_reference_bits(p.copy(), m.copy(), v.copy(), g, 1e-3, step)
+        P, M, V = p.copy(), m.copy(), v.copy()
+        fn(n, ptr(P), ptr(M), ptr(V), ptr(g), 1e-3, step)
+        assert np.array_equal(M, wm) and np.array_equal(V, wv), step
+        bad = np.where(P != wp)[0]
+        assert bad.size == 0, 'step %d: %d of %d parameters differ, e.g. v=%r m=%r got %r want %r' % (step, bad.size, n, wv[bad[0]], wm[bad[0]], P[bad[0]], wp[bad[0]])
+
+
+@pytest.mark.gpu
+def test_device_division_by_the_step_constant_is_ieee_at_every_step():
+    from glamr_amd import _lib
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    n = 1 << 17
+    for step in STEPS_ANY:
+        p, m, v, g = _states(n, 100 + step)
+        wp, wm, wv = adam_reference_bits(p.copy(), m.copy(), v.copy(), g, 1e-3, step)
+        P, M, V, G = (torch.tensor(a, device=dev) for a in (p, m, v, g))
+        _lib.check(L.glamr_adam_step(n, _lib.ptr(P), _lib.ptr(M), _lib.ptr(V), _lib.ptr(G), 1e-3, step, _lib.current_stream()))
+        torch.cuda.synchronize()
+        for name, a, b in (('exp_avg', M, wm), ('exp_avg_sq', V, wv), ('param', P, wp)):
+            got = a.cpu().numpy()
+            bad = np.where(got != b)[0]
+            assert bad.size == 0, 'step %d %s: %d of %d differ, e.g. got %r want %r (v=%r)' % (step, name, bad.size, n, got[bad[0]], b[bad[0]], wv[bad[0]])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('lr', [1e-3, 1e-4, 1e-1])
 def test_device_update_is_the_restatement_bit_for_bit(lr):
