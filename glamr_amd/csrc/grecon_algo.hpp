@@ -1398,9 +1398,15 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     GLAMR_MARK(rt, 4);
     if (update && var_cam && fixed_cam) {
       rt.reduce_sum_n(gfix);                             // all 9 sums with one exchange (nine separate block reductions were 18 barriers per iteration)
-      if (rt.tid() == 0) {
-        for (int k = 0; k < 6; ++k) { const int i = lo.cam_rot6d + k; if (sh.store_grad) sh.cg[i] = gfix[k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[k], ac); }
-        for (int k = 0; k < 3; ++k) { const int i = lo.cam_trans + k; if (sh.store_grad) sh.cg[i] = gfix[6 + k]; adam(sh.cp[i], sh.cm[i], sh.cv[i], gfix[6 + k], ac); }
+      // one LANE per parameter (every thread holds all nine sums): thread 0 doing them one after the other was nine dependent round trips to the
+      // parameter block -- global memory for scenes of several persons: 11 us of a 93 us iteration of BASELINE configs[3]
+      for (int k = rt.tid(); k < 9; k += rt.nthreads()) {
+        float gk = gfix[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) gk = (k == q) ? gfix[q] : gk;
+        const int i = k < 6 ? lo.cam_rot6d + k : lo.cam_trans + (k - 6);
+        if (sh.store_grad) sh.cg[i] = gk;
+        adam(sh.cp[i], sh.cm[i], sh.cv[i], gk, ac);
       }
     } else if (update && cam_from_person) {
       // ---- G (camera derived from the persons): gradient of every frame's averaged transform, folded onto its source frame ----

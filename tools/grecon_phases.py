@@ -21,14 +21,15 @@ dev = torch.device('cuda:0')
 root = build.ensure_synthetic_assets('/tmp/glamr_bench_assets')
 cfg_id = sys.argv[2] if len(sys.argv) > 2 else 'glamr_dynamic'
 cfg = get_config(cfg_id)
-in_dict = synth.make_in_dict(seed=0, num_frames=300, num_persons=1, smpl_model=synth.make_smpl_model())
+NP = int(os.environ.get('GLAMR_PH_PERSONS', '1'))
+in_dict = synth.make_in_dict(seed=0, num_frames=int(os.environ.get('GLAMR_PH_FRAMES', '300')), num_persons=NP, smpl_model=synth.make_smpl_model())
 ora = build.load_optimizer(root, cfg)
 data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 0))
 jl = j_local_from_oracle(ora.smpl, data)
 L = _lib.lib()
 fn = L.glamr_debug_phase_ticks
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-spec = next(iter(cfg['opt_stage_specs'].values()))
+spec = cfg['opt_stage_specs'][os.environ['GLAMR_PH_STAGE']] if 'GLAMR_PH_STAGE' in os.environ else next(iter(cfg['opt_stage_specs'].values()))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 packed = packing.PackedScenes([data] * S, [jl] * S, dev)
 sd = packing.stage_desc(spec, cfg['grecon_model_specs'], False)
