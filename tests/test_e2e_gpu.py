@@ -442,6 +442,15 @@ def test_nine_person_scene_with_ragged_existence_matches_the_oracle(make_model, 
     print('9 persons, ragged existence, %d iterations per stage, against the CPU restatement: kp %.4f px, root_trans_world %.2e m, smpl_orient_world %.2e' % (K, *worst))
     assert worst[0] < 0.1 and worst[1] < 1e-3 and worst[2] < 5e-3
     assert [int(out['person_data'][i]['fr_start']) for i in (2, 5, 8)] == [9, 0, 23]
+    # and the whole step as a replayed HIP graph (capture_resident: the entry bench.py uses) gives the plain launches' numbers for such a scene too
+    rin = model.stage_inputs([in_dict, other], [lat, lat_o])
+    graph = model.capture_resident(rin, max_iters=K, check=True)
+    graph.replay()
+    import torch
+    torch.cuda.synchronize()
+    res = model.collect(graph.datas, graph.packed)[0]
+    for pi in range(9):
+        assert np.array_equal(np.asarray(res['person_data'][pi]['kp_2d_pred']), np.asarray(out['person_data'][pi]['kp_2d_pred']))
 
 
 def test_ragged_batch_equals_single_runs(make_model):
