@@ -449,7 +449,9 @@ int ln(hipStream_t st, const float* X, const float* R, const LN& n, float* Y, in
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, R, n.g, n.b, Y, rows, D);
   return GLAMR_OK;
 }
-constexpr int FUSE_MIN_ROWS = 2048;
+// rows from which the fused row-block / fused attention kernels (and, beside a stage, the co-schedulable ones) are used; below it the separate
+// small-M fp32 kernels.  GLAMR_NETS_FUSE_MIN_ROWS overrides it (development aid / A-B runs; read once)
+static const int FUSE_MIN_ROWS = [] { const char* e = std::getenv("GLAMR_NETS_FUSE_MIN_ROWS"); return e ? std::atoi(e) : 2048; }();
 inline bool fuse_attention(int M) {
   static const bool no_fuse = std::getenv("GLAMR_NETS_NO_FUSE_ATTN") != nullptr || std::getenv("GLAMR_NETS_NO_FUSE") != nullptr;      // development aid
   return !no_fuse && !tl_fp32 && !tl_free && M >= FUSE_MIN_ROWS;
