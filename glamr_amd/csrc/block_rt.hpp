@@ -63,18 +63,69 @@ struct DeviceRT {
       v += dpp0<0x111>(v); v += dpp0<0x112>(v); v += dpp0<0x114>(v); v += dpp0<0x118>(v);      // row_shr:1,2,4,8
       const float t0 = lane_value(v, 15), t1 = lane_value(v, 31), t2 = lane_value(v, 47);      // row totals
       const float s1 = t0, s2 = t0 + t1, s3 = s2 + t2;
-      v += row == 0 ? 0.f : (row == 1 ? s1 : (row == 2 ? s2 : s3));
+      float add = 0.f;                                   // selects, not branches (the nested conditional compiled to two exec-mask branches)
+      add = row >= 1 ? s1 : add; add = row >= 2 ? s2 : add; add = row >= 3 ? s3 : add;
+      v += add;
     } else {
       v += dpp0<0x101>(v); v += dpp0<0x102>(v); v += dpp0<0x104>(v); v += dpp0<0x108>(v);      // row_shl:1,2,4,8
       const float t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48);
       const float s2 = t3, s1 = t3 + t2, s0 = s1 + t1;
-      v += row == 3 ? 0.f : (row == 2 ? s2 : (row == 1 ? s1 : s0));
+      float add = 0.f;
+      add = row <= 2 ? s2 : add; add = row <= 1 ? s1 : add; add = row <= 0 ? s0 : add;
+      v += add;
     }
     return v;
   }
 #endif
+  // inclusive prefix / suffix sum over the lanes of a wave in the summation order the build selects (`shuffle_order`: the Hillis-Steele
+  // order of the ds_bpermute scans whatever the build -- see scan_multi's last argument)
+  static __device__ __forceinline__ float wave_scan(float v, bool reverse, bool shuffle_order) {
+    const int lane = threadIdx.x & 63;
+#ifdef GLAMR_SCAN_DPP
+    if (!shuffle_order && (!reverse || GLAMR_SCAN_DPP >= 2)) return wave_scan_dpp(v, reverse);
+#endif
+    if (!reverse) { for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_up(v, off); if (lane >= off) v += y; } }
+    else { for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_down(v, off); if (lane + off < 64) v += y; } }
+    return v;
+  }
+  // The same sums for values held in REGISTERS, one element per thread, a workgroup of exactly NW waves (instances that give every frame its
+  // own thread and know their geometry at compile time): x[c] <- inclusive prefix (suffix) sum over the workgroup of channel c.  One barrier;
+  // the NW wave totals of a channel are fetched with vector reads issued together (scan_multi walks them one dependent LDS round trip at a
+  // time: 5 x ~100 cycles per channel on the iteration's critical path).  Same additions in the same order as scan_multi: same bits.
+  template <int NW, int NCH>
+  __device__ __forceinline__ void scan_regs(float (&x)[NCH], bool reverse, bool shuffle_order = false) {
+    static_assert(NW >= 1 && NW <= 8 && NCH <= RT_MAX_CH, "scan_regs: geometry");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* r = red + (gen & 1) * (RT_MAX_CH * 16);
+    gen++;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      x[c] = wave_scan(x[c], reverse, shuffle_order);
+      if (lane == (reverse ? 0 : 63)) r[c * 16 + wave] = x[c];
+    }
+    __syncthreads();
+    float t[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(r + c * 16);
+      t[c][0] = a.x; t[c][1] = a.y; t[c][2] = a.z; t[c][3] = a.w;
+      if (NW > 4) {
+        const float4 b = *reinterpret_cast<const float4*>(r + c * 16 + 4);
+        t[c][4] = b.x; t[c][5] = b.y; t[c][6] = b.z; t[c][7] = b.w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float pre = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) if (reverse ? (w > wave) : (w < wave)) pre += t[c][w];
+      x[c] = x[c] + pre;
+    }
+  }
+  // shuffle_order: this scan's wave part in the Hillis-Steele order of the ds_bpermute scans (rounds 1-3) even in a DPP build
   template <bool LDS = false>
-  __device__ void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) {
+  __device__ void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse, bool shuffle_order = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = (blockDim.x + 63) >> 6;
     const int nchunks = (n + blockDim.x - 1) / blockDim.x;
@@ -89,25 +140,10 @@ struct DeviceRT {
       float x[RT_MAX_CH];
       for (int c = 0; c < nch; ++c) {
         float v = (i < n) ? elem<LDS>(ch[c], idx) : 0.f;
-#ifdef GLAMR_SCAN_DPP
         // the wave scan through DPP row shifts inside the 16-lane rows (out-of-row sources read 0: bound_ctrl) and v_readlane of the three
         // row totals, instead of six ds_bpermute round trips.  GLAMR_SCAN_DPP=1: prefix sums only; 2: suffix sums as well
-        if (!reverse || GLAMR_SCAN_DPP >= 2) {
-          v = wave_scan_dpp(v, reverse);
-          if (lane == (reverse ? 0 : 63)) r[c * 16 + wave] = v;
-        } else {
-          for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_down(v, off); if (lane + off < 64) v += y; }
-          if (lane == 0) r[c * 16 + wave] = v;
-        }
-#else
-        if (!reverse) {
-          for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_up(v, off); if (lane >= off) v += y; }
-          if (lane == 63) r[c * 16 + wave] = v;
-        } else {
-          for (int off = 1; off < 64; off <<= 1) { const float y = __shfl_down(v, off); if (lane + off < 64) v += y; }
-          if (lane == 0) r[c * 16 + wave] = v;
-        }
-#endif
+        v = wave_scan(v, reverse, shuffle_order);
+        if (lane == (reverse ? 0 : 63)) r[c * 16 + wave] = v;
         x[c] = v;
       }
 #if !defined(GLAMR_EXP_NOSYNC) || GLAMR_EXP_NOSYNC < 2

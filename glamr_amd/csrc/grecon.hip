@@ -49,7 +49,7 @@ struct KernelArgs {
 
 template <int FAST, bool SINGLE, int CAM, int TMC = 0>
 __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon_stage_kernel(KernelArgs a) {
-  __shared__ float red[RT_RED_FLOATS];
+  __shared__ __attribute__((aligned(16))) float red[RT_RED_FLOATS];
   __shared__ Scene sc;
   __shared__ glamr_stage_desc s_st;        // the scene keeps POINTERS to these: they must live in LDS, not in a thread's private copy
   __shared__ glamr_param_layout s_lay;

@@ -227,6 +227,41 @@ GLAMR_HD void adam(float& p, float& m, float& v, float g, const AdamCoef& c) {
   p = p + rm::div_(c.neg_step * m, denom);
 }
 
+// N updates of one frame.  GLAMR_ADAM_INTERLEAVE (development aid, OFF): stage by stage across the N parameters, the scheduler barred from moving
+// anything across a stage boundary, so that every instruction of the ~30-long dependent chain of an update (through a square root and a
+// reciprocal) has N - 1 independent ones between itself and its consumer.  Measured on the MI355X (profiles/r05_stage_ab.log): 11.15 against
+// 10.8 us per iteration for the plain loop -- the scheduling barriers also pin the loads and stores around the updates, which costs more than
+// the shorter chains give.  Operation for operation what adam() does either way: same bits (tests/test_adam_exact.py, tools/stage_bits.py).
+template <int N>
+GLAMR_HD void adam_n(float (&P)[N], float (&M)[N], float (&V)[N], const float (&g)[N], const AdamCoef& c) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GLAMR_ADAM_INTERLEAVE)
+  float s[N], den[N], num[N], y[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    M[k] = rm::fma_(0.1f, g[k] - M[k], M[k]);
+    V[k] = rm::fma_(0.001f * g[k], g[k], V[k] * 0.999f);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) s[k] = rm::hw_sqrt_(V[k]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float a = rm::sqrt_rn_fix_(V[k], s[k]);
+    const float q = a * c.inv_bc2_sqrt;
+    den[k] = rm::fma_(rm::fma_(-c.bc2_sqrt, q, a), c.inv_bc2_sqrt, q) + 1e-8f;
+    num[k] = c.neg_step * M[k];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) y[k] = rm::hw_rcp_(den[k]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) P[k] = P[k] + rm::div_fix_(num[k], den[k], y[k]);
+#else
+  for (int k = 0; k < N; ++k) adam(P[k], M[k], V[k], g[k], c);
+#endif
+}
+
 GLAMR_HD void invert34(const float M[12], float O[12]) {       // [R|t] -> [R^T | -R^T t]   (inverse_transform)
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) O[i * 4 + j] = M[j * 4 + i];
@@ -267,20 +302,31 @@ GLAMR_HD void mul34_bwd(const float A[12], const float B[12], const float gC[12]
 // person trajectory row L[e] from the prior and the optimisation deltas (get_pred_trajectory_base :394-419)
 struct LocalRow { float dx, dy, z, r6[6], h; };   // h = heading angle after adding the delta; (cos h, sin h) replaces cols 9,10
 GLAMR_HD LocalRow local_row(const PersonView& c, const glamr_param_layout& l, int e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_assume(e >= 0);
+#endif
   const float* pr = c.prior + (size_t)e * 11;
   const float* P = c.p;
+  // Every load is issued before the first use and none sits behind a branch.  Frame 0 reads other parameters than the rest (local_xy /
+  // local_heading instead of its rows of local_dxy / local_dheading): selected INDICES, not selected code -- the wave that holds frame 0 used
+  // to walk both sides of the branch, three dependent trips to the workspace on the critical path of every iteration.  Same operations per
+  // frame as before (the heading of frame 0 is h_prior + p, of the others h_prior + p * mask).
+  const bool first = e == 0;
+  const int ixy = first ? l.local_xy : l.local_dxy + e * 2;
+  const int ih = first ? l.local_heading : l.local_dheading + e;
+  float prv[9], p6[6];
+  for (int k = 0; k < 9; ++k) prv[k] = pr[k];
+  const float hp = c.h_prior[e];
+  const float mk = c.dheading_mask ? c.dheading_mask[e] : 0.0f;
+  const float px = P[ixy], py = P[ixy + 1], ph = P[ih], pz = P[l.local_z + e];
+  for (int k = 0; k < 6; ++k) p6[k] = P[l.local_rot + e * 6 + k];
   LocalRow L;
-  if (e == 0) {
-    L.dx = pr[0] + P[l.local_xy + 0];
-    L.dy = pr[1] + P[l.local_xy + 1];
-    L.h = c.h_prior[e] + P[l.local_heading];
-  } else {
-    L.dx = pr[0] + P[l.local_dxy + e * 2 + 0];
-    L.dy = pr[1] + P[l.local_dxy + e * 2 + 1];
-    L.h = c.h_prior[e] + (c.dheading_mask ? P[l.local_dheading + e] * c.dheading_mask[e] : 0.0f);
-  }
-  L.z = pr[2] + P[l.local_z + e];
-  for (int k = 0; k < 6; ++k) L.r6[k] = pr[3 + k] + P[l.local_rot + e * 6 + k];
+  L.dx = prv[0] + px;
+  L.dy = prv[1] + py;
+  const float h0 = hp + ph, h1 = hp + (c.dheading_mask ? ph * mk : 0.0f);
+  L.h = first ? h0 : h1;
+  L.z = prv[2] + pz;
+  for (int k = 0; k < 6; ++k) L.r6[k] = prv[3 + k] + p6[k];
   return L;
 }
 
@@ -319,7 +365,7 @@ template <int N>
 GLAMR_HD void adam_block(float* p, float* m, float* v, float* gstore, int base, const float (&g)[N], const AdamCoef& c) {
   float P[N], M[N], V[N];
   for (int k = 0; k < N; ++k) { P[k] = p[base + k]; M[k] = m[base + k]; V[k] = v[base + k]; }
-  for (int k = 0; k < N; ++k) adam(P[k], M[k], V[k], g[k], c);
+  adam_n(P, M, V, g, c);
   for (int k = 0; k < N; ++k) { p[base + k] = P[k]; m[base + k] = M[k]; v[base + k] = V[k]; }
   if (gstore) for (int k = 0; k < N; ++k) gstore[base + k] = g[k];
 }
@@ -332,12 +378,38 @@ struct AdamRegs {
   GLAMR_HD void load(const float* p, const float* m, const float* v, int base) {
     for (int k = 0; k < N; ++k) { P[k] = p[base + k]; M[k] = m[base + k]; V[k] = v[base + k]; }
   }
-  GLAMR_HD void step_store(float* p, float* m, float* v, float* gstore, int base, const float (&g)[N], const AdamCoef& c) {
-    for (int k = 0; k < N; ++k) adam(P[k], M[k], V[k], g[k], c);
+  GLAMR_HD void zero() { for (int k = 0; k < N; ++k) { P[k] = 0.f; M[k] = 0.f; V[k] = 0.f; } }
+  GLAMR_HD void store(float* p, float* m, float* v, float* gstore, int base, const float (&g)[N]) const {
     for (int k = 0; k < N; ++k) { p[base + k] = P[k]; m[base + k] = M[k]; v[base + k] = V[k]; }
     if (gstore) for (int k = 0; k < N; ++k) gstore[base + k] = g[k];
   }
+  GLAMR_HD void step_store(float* p, float* m, float* v, float* gstore, int base, const float (&g)[N], const AdamCoef& c) {
+    adam_n(P, M, V, g, c);
+    store(p, m, v, gstore, base, g);
+  }
 };
+// the updates of two / three parameter groups of a frame as ONE interleaved pass (adam_n); a group that is not updated takes part with
+// whatever its registers hold (zeros: AdamRegs::zero) and is simply not stored by the caller
+template <int A, int B>
+GLAMR_HD void adam_step2(AdamRegs<A>& a, const float (&ga)[A], AdamRegs<B>& b, const float (&gb)[B], const AdamCoef& c) {
+  float P[A + B], M[A + B], V[A + B], g[A + B];
+  for (int k = 0; k < A; ++k) { P[k] = a.P[k]; M[k] = a.M[k]; V[k] = a.V[k]; g[k] = ga[k]; }
+  for (int k = 0; k < B; ++k) { P[A + k] = b.P[k]; M[A + k] = b.M[k]; V[A + k] = b.V[k]; g[A + k] = gb[k]; }
+  adam_n(P, M, V, g, c);
+  for (int k = 0; k < A; ++k) { a.P[k] = P[k]; a.M[k] = M[k]; a.V[k] = V[k]; }
+  for (int k = 0; k < B; ++k) { b.P[k] = P[A + k]; b.M[k] = M[A + k]; b.V[k] = V[A + k]; }
+}
+template <int A, int B, int C>
+GLAMR_HD void adam_step3(AdamRegs<A>& a, const float (&ga)[A], AdamRegs<B>& b, const float (&gb)[B], AdamRegs<C>& cc, const float (&gc)[C], const AdamCoef& c) {
+  float P[A + B + C], M[A + B + C], V[A + B + C], g[A + B + C];
+  for (int k = 0; k < A; ++k) { P[k] = a.P[k]; M[k] = a.M[k]; V[k] = a.V[k]; g[k] = ga[k]; }
+  for (int k = 0; k < B; ++k) { P[A + k] = b.P[k]; M[A + k] = b.M[k]; V[A + k] = b.V[k]; g[A + k] = gb[k]; }
+  for (int k = 0; k < C; ++k) { P[A + B + k] = cc.P[k]; M[A + B + k] = cc.M[k]; V[A + B + k] = cc.V[k]; g[A + B + k] = gc[k]; }
+  adam_n(P, M, V, g, c);
+  for (int k = 0; k < A; ++k) { a.P[k] = P[k]; a.M[k] = M[k]; a.V[k] = V[k]; }
+  for (int k = 0; k < B; ++k) { b.P[k] = P[A + k]; b.M[k] = M[A + k]; b.V[k] = V[A + k]; }
+  for (int k = 0; k < C; ++k) { cc.P[k] = P[A + B + k]; cc.M[k] = M[A + B + k]; cc.V[k] = V[A + B + k]; }
+}
 
 // World orientation as a rotation MATRIX.  The reference composes quaternions and goes through axis-angle at every step
 // (traj_local2global_heading: hq(theta) (x) R2q(6d->R(r6)) (x) (.5,.5,.5,.5), :459-465 world heading offset, then angle_axis ->
@@ -719,7 +791,37 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   constexpr bool AF = FAST == 1 && SINGLE;          // parameters + Adam moments on chip (assemble_scene: adam_fast)
   static_assert(TMC == 0 || AF, "constant layouts are for single-person scenes with the full arena");
   const glamr_param_layout& lo = TMC > 0 ? OnChipLayout<TMC>::value : l;      // layout of the on-chip parameter / moment blocks
-  auto pv = [&](int p) { return person_view<FAST, AF, TMC>(rt, sc, p); };
+  // One-thread-per-frame instances with a compile-time geometry (TMC > 0: one person, TMC frames of layout, (TMC + 63) / 64 waves) carry a
+  // frame's scan operands and results, its trajectory row and the cos / sin of its heading in REGISTERS from phase to phase: the scans take and
+  // return registers (DeviceRT::scan_regs), `theta`, `xy` and `g_theta` are never stored, and phases B and C do not re-read what phase A wrote.
+  // GLAMR_REG_MASK (development aid) selects the pieces: 1 heading prefix sum, 2 the reverse phases' sums, 4 planar position, 8 the trajectory
+  // row, 16 cos / sin of the heading, 32 the camera parameters requested before the barrier that precedes phase D.  Default 23: pieces 8 and
+  // 32 are measured (the launch another 0.5 % shorter) and OFF, because they change results in the last bit: with a frame's 6D rotation
+  // arriving in registers instead of from LDS the compiler fuses a different product of rot6d_to_rotmat's `x0 x0 + x1 x1 + x2 x2` and
+  // `b1 . a2` (which operand of a commutative node comes first is not stable under such edits), and the optimisation of a sequence with a
+  // detection gap is chaotic in exactly those bits.  Every enabled piece leaves all outputs of all stages bit-identical to
+  // round 4's kernel (tools/stage_bits.py, seven cases, profiles/r05_stage_bits.log).
+#ifndef GLAMR_REG_MASK
+#define GLAMR_REG_MASK 23
+#endif
+  constexpr bool REG_ANY = TMC > 0 && RT::one_thread_per_frame;
+  constexpr bool REG = REG_ANY && (GLAMR_REG_MASK & 1);          // heading prefix sum
+  constexpr bool REGB = REG_ANY && (GLAMR_REG_MASK & 2);
+  constexpr bool REG_XY = REG_ANY && (GLAMR_REG_MASK & 4);       // planar position prefix sum
+  constexpr bool REG_L = REG_ANY && (GLAMR_REG_MASK & 8);        // trajectory row
+  constexpr bool REG_CS = REG_ANY && (GLAMR_REG_MASK & 16);      // cos / sin of the heading
+  constexpr bool REG_CAM = REG_ANY && (GLAMR_REG_MASK & 32);     // camera parameters requested early
+  constexpr int NWC = TMC > 0 ? (TMC + 63) / 64 : 1;
+  // Uniform scalars of the scene description the loop needs (single-person instances): the description lives in LDS, which every phase
+  // writes, so the compiler must re-read them -- a ds_read, a wait and two v_readfirstlane at the top of every phase -- unless they are
+  // copied out once.  Filled in after the stage setup (njc / njc_fast are computed there).
+  struct PersonScalars { int fr_start, fr_end, njc, njc_fast; } hs{0, 0, 0, 0};
+  bool hs_set = false;
+  auto pv = [&](int p) {
+    PersonView w = person_view<FAST, AF, TMC>(rt, sc, p);
+    if (SINGLE && hs_set) { w.fr_start = hs.fr_start; w.fr_end = hs.fr_end; w.njc = hs.njc; w.njc_fast = hs.njc_fast; }
+    return w;
+  };
   // Frame loops of the full-arena instances make ONE pass (the launcher only selects them when every frame has its own thread): with
   // a step the compiler can see is larger than any sequence the loop is an `if`, and no per-array 64-bit induction pointers stay
   // live across the whole body (two registers each, a few dozen arrays).
@@ -877,6 +979,12 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     }
   }
 
+  if (SINGLE) {
+    const PersonView w0 = person_view<FAST, AF, TMC>(rt, sc, 0);
+    hs.fr_start = w0.fr_start; hs.fr_end = w0.fr_end; hs.njc = w0.njc; hs.njc_fast = w0.njc_fast;
+    hs_set = true;
+  }
+  const float* const adam_tab = uni(sc.adam_tab);      // (read once: see PersonScalars)
   const int niters = st.niters;
   double b1p = 1.0, b2p = 1.0;
   int n_done = 0;
@@ -890,7 +998,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const bool update = niters > 0;
     b1p *= 0.9; b2p *= 0.999;
     AdamCoef ac;
-    const float* tab = uni(sc.adam_tab);
+    const float* tab = adam_tab;
     if (tab) {                                     // the host's table: Python's own arithmetic (pow in double)
       ac.neg_step = glob(tab)[2 * n_done]; ac.bc2_sqrt = glob(tab)[2 * n_done + 1];
     } else {                                       // stages longer than the table: running products (same values to ~1 ulp of a double)
@@ -906,6 +1014,15 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
 
     // ---- A: heading increments (arrays are indexed by VIDEO frame t and zero outside the person's existing range, so the
     //         prefix sums run over [0,T) and element t is always owned by thread t mod nthreads) ------------------------------
+    // The camera rides on the person (cfg glamr_3dpw): the world trajectory is a GAUGE there, the reference's own gradient of the planar
+    // position is below the rounding of what it is summed from, and Adam's first steps are lr x its SIGN -- which the summation order of the
+    // stage's prefix / suffix sums decides.  These instances keep the Hillis-Steele order of rounds 1-3 for all four scans (it reproduces the
+    // reference's 15-step state to 0.002 px; the DPP order 0.20 px, and so does DPP with only the planar-position gradient's scan in the old
+    // order: profiles/r05_gputest_a.log); every other instance runs the DPP scans.
+    const bool scan_shuffle = cam_from_person;
+    // REG instances: this frame's row, heading prefix sum with its cos / sin, and planar position, carried in registers (lanes beyond T: zeros)
+    LocalRow Lr{};
+    float th_r[1] = {0.f}, cs_r = 1.f, sn_r = 0.f, xy_r[2] = {0.f, 0.f};
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         const PersonView c = pv(p);
@@ -914,11 +1031,15 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const LocalRow L = HOIST ? local_row_regs(fr.prior, fr.h_prior, fr.dmask, c.dheading_mask != nullptr, c.p, lo, t - c.fr_start)
                                    : local_row(c, lo, t - c.fr_start);
           store_row(pv(p).Lc, sh.TM, t, L);
+          if (REG_L) Lr = L;
           // atan2(sin h, cos h) of the reference (:401-405) only wraps h into (-pi, pi]: done arithmetically
           v = L.h - 6.28318530717958647692f * rintf(L.h * 0.15915494309189533577f);
         }
-        pv(p).theta[t] = v;
+        if (REG) th_r[0] = v; else pv(p).theta[t] = v;
       }
+    if constexpr (REG) {
+      rt.template scan_regs<NWC, 1>(th_r, false, scan_shuffle);
+    } else
 #ifdef GLAMR_GRECON_WIDE      // absolute_heading (:59,283,421): the per-frame headings are not summed up (traj_local2global_heading(local_heading=False))
     if (st.flags & GLAMR_FLAG_ABSOLUTE_HEADING) rt.sync(); else
 #endif
@@ -926,12 +1047,12 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       float* ch[8];
       if constexpr (MAXP <= 8) {
         for (int p = 0; p < P; ++p) ch[p] = pv(p).theta;
-        rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false);
+        rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, false, scan_shuffle);
       } else {
         for (int p0 = 0; p0 < P; p0 += 8) {      // (the scan scratch holds 16 channels: 8 persons a call)
           const int np = P - p0 < 8 ? P - p0 : 8;
           for (int p = 0; p < np; ++p) ch[p] = pv(p0 + p).theta;
-          rt.template scan_multi<(FAST != 0)>(ch, np, T, 1, false);
+          rt.template scan_multi<(FAST != 0)>(ch, np, T, 1, false, scan_shuffle);
         }
       }
     }
@@ -939,9 +1060,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         float sn, cs;
-        rm::sincos_(pv(p).theta[t], sn, cs);
+        rm::sincos_(REG ? th_r[0] : pv(p).theta[t], sn, cs);
         pv(p).csn[t * 2 + 0] = cs;
         pv(p).csn[t * 2 + 1] = sn;
+        if (REG_CS) { cs_r = cs; sn_r = sn; }
       }
     rt.sync();
     GLAMR_MARK(rt, 0);
@@ -952,27 +1074,43 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float dx = 0.f, dy = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
           const int e = t - c.fr_start;
-          const LocalRow L = load_row(pv(p).Lc, sh.TM, t);
+          const LocalRow L = REG_L ? Lr : load_row(pv(p).Lc, sh.TM, t);
           dx = L.dx; dy = L.dy;
+          // (neighbours' values are fetched with a clamped index, outside the per-lane condition: a load behind a condition cannot be
+          // issued early or batched with others, and costs its own round trip -- here and in phases E3, E4 and I)
+          const int tp = e > 0 ? t - 1 : t;
+          const float cs = pv(p).csn[tp * 2 + 0], sn = pv(p).csn[tp * 2 + 1];
           if (e > 0) {
-            const float cs = pv(p).csn[(t - 1) * 2 + 0], sn = pv(p).csn[(t - 1) * 2 + 1];
             dx = L.dx * cs - L.dy * sn;
             dy = L.dx * sn + L.dy * cs;
           }
         }
-        pv(p).xy[t * 2 + 0] = dx;
-        pv(p).xy[t * 2 + 1] = dy;
+        if (REG_XY) { xy_r[0] = dx; xy_r[1] = dy; } else {
+          pv(p).xy[t * 2 + 0] = dx;
+          pv(p).xy[t * 2 + 1] = dy;
+        }
       }
-    {
+    // REG instances with an own camera per frame: this frame's camera parameters (written by this thread, in phase E5 of the previous
+    // iteration) are requested before the scan's barrier instead of in phase D, where nothing covered their latency
+    constexpr bool CAMPRE = REG_CAM && CAM == 1;
+    float cam9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (CAMPRE)
+      for (int t = rt.tid(); frame_in(t, T); t += fstep) {
+        for (int k = 0; k < 6; ++k) cam9[k] = sh.cp[lo.cam_rot6d + t * 6 + k];
+        for (int k = 0; k < 3; ++k) cam9[6 + k] = sh.cp[lo.cam_trans + t * 3 + k];
+      }
+    if constexpr (REG_XY) {
+      rt.template scan_regs<NWC, 2>(xy_r, false, scan_shuffle);
+    } else {
       float* ch[16];
       if constexpr (MAXP <= 8) {
         for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).xy; ch[2 * p + 1] = pv(p).xy + 1; }
-        rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, false);
+        rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, false, scan_shuffle);
       } else {
         for (int p0 = 0; p0 < P; p0 += 8) {
           const int np = P - p0 < 8 ? P - p0 : 8;
           for (int p = 0; p < np; ++p) { ch[2 * p] = pv(p0 + p).xy; ch[2 * p + 1] = pv(p0 + p).xy + 1; }
-          rt.template scan_multi<(FAST != 0)>(ch, 2 * np, T, 2, false);
+          rt.template scan_multi<(FAST != 0)>(ch, 2 * np, T, 2, false, scan_shuffle);
         }
       }
     }
@@ -984,12 +1122,12 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         const PersonView& s = c;
         float c1[3], c2[3], tb[3], phi = 0.f;
         if (t >= c.fr_start && t < c.fr_end) {
-          const LocalRow L = load_row(s.Lc, sh.TM, t);
+          const LocalRow L = REG_L ? Lr : load_row(s.Lc, sh.TM, t);
           float Rl[9];
           rm::rot6d_to_rotmat(L.r6, Rl);
           for (int k = 0; k < 3; ++k) { c1[k] = Rl[k * 3 + 1]; c2[k] = Rl[k * 3 + 2]; }
-          phi = s.theta[t];
-          tb[0] = s.xy[t * 2 + 0]; tb[1] = s.xy[t * 2 + 1]; tb[2] = L.z;
+          phi = REG ? th_r[0] : s.theta[t];
+          tb[0] = REG_XY ? xy_r[0] : s.xy[t * 2 + 0]; tb[1] = REG_XY ? xy_r[1] : s.xy[t * 2 + 1]; tb[2] = L.z;
         } else {
           float Rb[9];
           rm::aa_to_rotmat_k(c.base_orient + t * 3, Rb);
@@ -998,7 +1136,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float sn = 0.f, cs = 1.f;
         const bool frozen = !SINGLE && c.frozen;            // the given pose already carries its owner's world heading offset
         if (has_wd && !frozen) { phi += s.p[lo.world_dheading + t]; rm::sincos_(phi, sn, cs); }
-        else if (t >= c.fr_start && t < c.fr_end) { cs = s.csn[t * 2 + 0]; sn = s.csn[t * 2 + 1]; }
+        else if (t >= c.fr_start && t < c.fr_end) { cs = REG_CS ? cs_r : s.csn[t * 2 + 0]; sn = REG_CS ? sn_r : s.csn[t * 2 + 1]; }
         float w1[3], w2[3];
         rotz2(cs, sn, c1, w1);
         rotz2(cs, sn, c2, w2);
@@ -1022,8 +1160,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         if (var_cam) {
           const int row = fixed_cam ? 0 : t;
           float R[9];
-          rm::rot6d_to_rotmat(sh.cp + lo.cam_rot6d + row * 6, R);
-          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = sh.cp[lo.cam_trans + row * 3 + i]; }
+          rm::rot6d_to_rotmat(CAMPRE ? cam9 : sh.cp + lo.cam_rot6d + row * 6, R);
+          for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j]; M[i * 4 + 3] = CAMPRE ? cam9[6 + i] : sh.cp[lo.cam_trans + row * 3 + i]; }
         } else {
           for (int k = 0; k < 12; ++k) M[k] = sh.cam_pose[(size_t)t * 12 + k];
         }
@@ -1282,10 +1420,16 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
                   gq[i] = gq[i] + gh[i];
                 }
               };
-              for (int jj = 0; jj < nf; ++jj) {
-                float c6[6];
-                fetch_chip(jj, c6);
-                joint_nb(c6, true);
+              // on-chip rows ONE AHEAD (two buffers, the loop unrolled twice): a row's six ds_reads are in flight while the previous row is
+              // processed -- fetched and consumed in the same trip, every row exposed an LDS round trip (12 rows x ~100 cycles per iteration)
+              float ca[6], cb[6];
+              if (nf > 0) fetch_chip(0, ca);
+              for (int jj = 0; jj < nf; jj += 2) {
+                if (jj + 1 < nf) fetch_chip(jj + 1, cb);
+                joint_nb(ca, true);
+                if (jj + 1 >= nf) break;
+                if (jj + 2 < nf) fetch_chip(jj + 2, ca);
+                joint_nb(cb, true);
               }
               float ga[KG][6], gb[KG][6];
               auto fetch_group = [&](int base, float (&b)[KG][6]) {
@@ -1320,8 +1464,11 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         if (on(GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS)) {
           const float* d0 = s.d6 + t * 6;
           float gd6[6] = {0, 0, 0, 0, 0, 0};
-          if (t + 1 < T) for (int k = 0; k < 6; ++k) { const float v = (s.d6[(t + 1) * 6 + k] - d0[k]) * FPS; if (last) lsum[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] += v * v; gd6[k] -= 2.0f * FPS * v * w_trs; }
-          if (t > 0) for (int k = 0; k < 6; ++k) { const float v = (d0[k] - s.d6[(t - 1) * 6 + k]) * FPS; gd6[k] += 2.0f * FPS * v * w_trs; }
+          const int tn = t + 1 < T ? t + 1 : t, tp = t > 0 ? t - 1 : t;
+          float dn[6], dp[6];
+          for (int k = 0; k < 6; ++k) { dn[k] = s.d6[tn * 6 + k]; dp[k] = s.d6[tp * 6 + k]; }
+          if (t + 1 < T) for (int k = 0; k < 6; ++k) { const float v = (dn[k] - d0[k]) * FPS; if (last) lsum[GLAMR_LOSS_TRAJ_ROT_SMOOTHNESS] += v * v; gd6[k] -= 2.0f * FPS * v * w_trs; }
+          if (t > 0) for (int k = 0; k < 6; ++k) { const float v = (d0[k] - dp[k]) * FPS; gd6[k] += 2.0f * FPS * v * w_trs; }
           for (int r = 0; r < 3; ++r) { gRk[r * 3 + 0] += gd6[r]; gRk[r * 3 + 1] += gd6[3 + r]; }
         }
         float g6[6];
@@ -1335,17 +1482,24 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       AdamRegs<3> a_tr;
       if (own_cam) { a_rot.load(sh.cp, sh.cm, sh.cv, lo.cam_rot6d + t * 6); a_tr.load(sh.cp, sh.cm, sh.cv, lo.cam_trans + t * 3); }
       // camera-only terms on the camera-to-world transform  (loss_func.py:76-114)
+      // the neighbouring frames' camera-to-world transforms: two whole rows up front (clamped at the ends) instead of eighteen conditional
+      // element reads -- each of those was a branch of its own with an LDS round trip inside (0.75 of this phase's 1.1 us)
+      float Cn[12], Cp[12];
+      if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS) || on(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS)) {
+        const int tn = t + 1 < T ? t + 1 : t, tp = t > 0 ? t - 1 : t;
+        for (int k = 0; k < 12; ++k) { Cn[k] = sh.cam_inv[(size_t)tn * 12 + k]; Cp[k] = sh.cam_inv[(size_t)tp * 12 + k]; }
+      }
       if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i)
           for (int j = 0; j < 2; ++j) {
-            if (t + 1 < T) { const float v = (Mi[i * 4 + j] - sh.cam_inv[(size_t)(t + 1) * 12 + i * 4 + j]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] += v * v; gCi[i * 4 + j] += 2.0f * FPS * v * w_crs; }
-            if (t > 0) { const float v = (sh.cam_inv[(size_t)(t - 1) * 12 + i * 4 + j] - Mi[i * 4 + j]) * FPS; gCi[i * 4 + j] -= 2.0f * FPS * v * w_crs; }
+            if (t + 1 < T) { const float v = (Mi[i * 4 + j] - Cn[i * 4 + j]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] += v * v; gCi[i * 4 + j] += 2.0f * FPS * v * w_crs; }
+            if (t > 0) { const float v = (Cp[i * 4 + j] - Mi[i * 4 + j]) * FPS; gCi[i * 4 + j] -= 2.0f * FPS * v * w_crs; }
           }
       }
       if (on(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i) {
-          if (t + 1 < T) { const float v = (sh.cam_inv[(size_t)(t + 1) * 12 + i * 4 + 3] - Mi[i * 4 + 3]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] += v * v; gCi[i * 4 + 3] -= 2.0f * FPS * v * w_cos; }
-          if (t > 0) { const float v = (Mi[i * 4 + 3] - sh.cam_inv[(size_t)(t - 1) * 12 + i * 4 + 3]) * FPS; gCi[i * 4 + 3] += 2.0f * FPS * v * w_cos; }
+          if (t + 1 < T) { const float v = (Cn[i * 4 + 3] - Mi[i * 4 + 3]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] += v * v; gCi[i * 4 + 3] -= 2.0f * FPS * v * w_cos; }
+          if (t > 0) { const float v = (Mi[i * 4 + 3] - Cp[i * 4 + 3]) * FPS; gCi[i * 4 + 3] += 2.0f * FPS * v * w_cos; }
         }
       }
       if (on(GLAMR_LOSS_CAM_UP_REG) && (!ffo(GLAMR_LOSS_CAM_UP_REG) || t == 0)) {
@@ -1369,8 +1523,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         } else {
           rm::rot6d_to_rotmat_bwd(a_rot.P, gR, g6);
           const float gt3[3] = {gC[3], gC[7], gC[11]};
-          a_rot.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, lo.cam_rot6d + t * 6, g6, ac);
-          a_tr.step_store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, lo.cam_trans + t * 3, gt3, ac);
+          adam_step2(a_rot, g6, a_tr, gt3, ac);
+          a_rot.store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, lo.cam_rot6d + t * 6, g6);
+          a_tr.store(sh.cp, sh.cm, sh.cv, sh.store_grad ? sh.cg : nullptr, lo.cam_trans + t * 3, gt3);
         }
       }
       if (last && on(GLAMR_LOSS_CAM_INV_TRANS_RES_REG))
@@ -1490,6 +1645,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     const float w_z = active(GLAMR_LOSS_LOCAL_Z_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_Z_REG] / n_exist : 0.f;
     const float w_dxy = active(GLAMR_LOSS_LOCAL_DXY_REG) ? st.loss_weight[GLAMR_LOSS_LOCAL_DXY_REG] / n_exist_m1 : 0.f;
     const float w_dh = active(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW) ? st.loss_weight[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] / n_exist_m1 : 0.f;
+    float gth_r[1] = {0.f}, gxy_r[2] = {0.f, 0.f};      // REGB instances: this frame's heading / planar-position gradient (scan operands and results)
     for (int t = rt.tid(); frame_in(t, T); t += fstep)
       for (int p = 0; p < P; ++p) {
         const PersonView c = pv(p);
@@ -1503,6 +1659,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         AdamRegs<1> a_wd;
         AdamRegs<6> a_rot;
         AdamRegs<1> a_z;
+        a_wd.zero(); a_rot.zero(); a_z.zero();      // (a group that is not updated rides along in the common pass below with zeros)
         if (upd_wd) a_wd.load(s.p, s.m, s.v, lo.world_dheading + t);
         if (upd_rot) a_rot.load(s.p, s.m, s.v, lo.local_rot + e * 6); else if (ex) for (int k = 0; k < 6; ++k) a_rot.P[k] = s.p[lo.local_rot + e * 6 + k];
         if (upd_z) a_z.load(s.p, s.m, s.v, lo.local_z + e); else if (ex) a_z.P[0] = s.p[lo.local_z + e];
@@ -1510,8 +1667,12 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         const float* d6 = s.d6 + t * 6;
         const float* g6 = s.g_d6 + t * 6;
         const float gphi = (g6[1] * d6[0] - g6[0] * d6[1]) + (g6[4] * d6[3] - g6[3] * d6[4]);
-        if (upd_wd) { const float gw[1] = {gphi}; a_wd.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.world_dheading + t, gw, ac); }
-        if (!ex) { s.g_theta[t] = 0.f; s.g_xy[t * 2 + 0] = 0.f; s.g_xy[t * 2 + 1] = 0.f; continue; }
+        const float gw[1] = {gphi};
+        if (!ex) {
+          if (upd_wd) a_wd.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.world_dheading + t, gw, ac);
+          if (!REGB) { s.g_theta[t] = 0.f; s.g_xy[t * 2 + 0] = 0.f; s.g_xy[t * 2 + 1] = 0.f; }
+          continue;
+        }
         const LocalRow L = load_row(s.Lc, sh.TM, t);
         const float cs = s.Lc[10 * sh.TM + t], sn = s.Lc[11 * sh.TM + t];
         const float gth = gphi;
@@ -1524,10 +1685,13 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           for (int r = 0; r < 3; ++r) { gRl[r * 3 + 0] = 0.f; gRl[r * 3 + 1] = gb2[r]; gRl[r * 3 + 2] = gb3[r]; }
           rm::rot6d_to_rotmat_bwd(L.r6, gRl, gr6);
         }
-        s.g_theta[t] = gth;
-        s.g_xy[t * 2 + 0] = s.g_tw[t * 3 + 0];
-        s.g_xy[t * 2 + 1] = s.g_tw[t * 3 + 1];
-        // local_rot / local_z: gradient is final here (+ regularisers loss_func.py:189-237)
+        if (REGB) { gth_r[0] = gth; gxy_r[0] = s.g_tw[t * 3 + 0]; gxy_r[1] = s.g_tw[t * 3 + 1]; } else {
+          s.g_theta[t] = gth;
+          s.g_xy[t * 2 + 0] = s.g_tw[t * 3 + 0];
+          s.g_xy[t * 2 + 1] = s.g_tw[t * 3 + 1];
+        }
+        // local_rot / local_z: gradient is final here (+ regularisers loss_func.py:189-237); the frame's eight updates (world heading
+        // offset, local rotation, height) run as one interleaved pass
         {
           float g6r[6];
           for (int k = 0; k < 6; ++k) {
@@ -1535,26 +1699,29 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             if (on(GLAMR_LOSS_LOCAL_ROT_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_ROT_REG] += r * r;
             g6r[k] = gr6[k] + 2.0f * FPS * r * w_rot;
           }
-          if (upd_rot) a_rot.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_rot + e * 6, g6r, ac);
-        }
-        {
           const float r = a_z.P[0] * FPS;
           if (on(GLAMR_LOSS_LOCAL_Z_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_Z_REG] += r * r;
           const float gz[1] = {s.g_tw[t * 3 + 2] + 2.0f * FPS * r * w_z};
-          if (upd_z) a_z.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_z + e, gz, ac);
+          if (upd_wd || upd_rot || upd_z) adam_step3(a_wd, gw, a_rot, g6r, a_z, gz, ac);
+          if (upd_wd) a_wd.store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.world_dheading + t, gw);
+          if (upd_rot) a_rot.store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_rot + e * 6, g6r);
+          if (upd_z) a_z.store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_z + e, gz);
         }
       }
     if (update) {
-      {
+      if constexpr (REGB) {
+        rt.template scan_regs<NWC, 2>(gxy_r, true, scan_shuffle);
+        for (int t = rt.tid(); frame_in(t, T); t += fstep) { pv(0).g_xy[t * 2 + 0] = gxy_r[0]; pv(0).g_xy[t * 2 + 1] = gxy_r[1]; }      // (frame t + 1's is read by frame t)
+      } else {
         float* ch[16];
         if constexpr (MAXP <= 8) {
           for (int p = 0; p < P; ++p) { ch[2 * p] = pv(p).g_xy; ch[2 * p + 1] = pv(p).g_xy + 1; }
-          rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, true);
+          rt.template scan_multi<(FAST != 0)>(ch, 2 * P, T, 2, true, scan_shuffle);
         } else {
           for (int p0 = 0; p0 < P; p0 += 8) {
             const int np = P - p0 < 8 ? P - p0 : 8;
             for (int p = 0; p < np; ++p) { ch[2 * p] = pv(p0 + p).g_xy; ch[2 * p + 1] = pv(p0 + p).g_xy + 1; }
-            rt.template scan_multi<(FAST != 0)>(ch, 2 * np, T, 2, true);
+            rt.template scan_multi<(FAST != 0)>(ch, 2 * np, T, 2, true, scan_shuffle);
           }
         }
       }
@@ -1567,36 +1734,57 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start, n = c.fr_end - c.fr_start;
-          const bool upd_dxy = e > 0 && (st.var_mask & GLAMR_VAR_LOCAL_DXY);
+          // frame 0 updates local_xy where the others update their row of local_dxy: a selected INDEX, one code path (the wave that holds
+          // frame 0 used to walk a branch of its own with two more updates straight on the arrays)
+          const bool first = e == 0;
+          const int ixy = first ? lo.local_xy : lo.local_dxy + e * 2;
+          const bool upd_dxy = first ? (bool)(st.var_mask & GLAMR_VAR_LOCAL_XY) : (bool)(st.var_mask & GLAMR_VAR_LOCAL_DXY);
           AdamRegs<2> a_dxy;
-          if (upd_dxy) a_dxy.load(s.p, s.m, s.v, lo.local_dxy + e * 2); else if (e > 0) for (int k = 0; k < 2; ++k) a_dxy.P[k] = s.p[lo.local_dxy + e * 2 + k];
-          // contribution of d[e+1] = Rot(theta[e]) L[e+1].xy to g_theta[e]
+          if (upd_dxy) a_dxy.load(s.p, s.m, s.v, ixy); else for (int k = 0; k < 2; ++k) a_dxy.P[k] = s.p[ixy + k];
+          // contribution of d[e+1] = Rot(theta[e]) L[e+1].xy to g_theta[e]   (every neighbour value fetched up front, clamped index)
+          const int tn = e + 1 < n ? t + 1 : t, tp = e > 0 ? t - 1 : t;
+          struct { float dx, dy; } Ln = {s.Lc[0 * sh.TM + tn], s.Lc[1 * sh.TM + tn]};
+          const float cs0 = s.csn[t * 2 + 0], sn0 = s.csn[t * 2 + 1];
+          const float gdx = s.g_xy[tn * 2 + 0], gdy = s.g_xy[tn * 2 + 1];
+          const float csp = s.csn[tp * 2 + 0], snp = s.csn[tp * 2 + 1];
           if (e + 1 < n) {
-            const LocalRow Ln = load_row(s.Lc, sh.TM, t + 1);
-            const float cs = s.csn[t * 2 + 0], sn = s.csn[t * 2 + 1];
-            const float gdx = s.g_xy[(t + 1) * 2 + 0], gdy = s.g_xy[(t + 1) * 2 + 1];
-            s.g_theta[t] += gdx * (-Ln.dx * sn - Ln.dy * cs) + gdy * (Ln.dx * cs - Ln.dy * sn);
+            const float cs = cs0, sn = sn0;
+            if (REGB) gth_r[0] += gdx * (-Ln.dx * sn - Ln.dy * cs) + gdy * (Ln.dx * cs - Ln.dy * sn);
+            else s.g_theta[t] += gdx * (-Ln.dx * sn - Ln.dy * cs) + gdy * (Ln.dx * cs - Ln.dy * sn);
           }
-          float gx = s.g_xy[t * 2 + 0], gy = s.g_xy[t * 2 + 1];
+          float gx = REGB ? gxy_r[0] : s.g_xy[t * 2 + 0], gy = REGB ? gxy_r[1] : s.g_xy[t * 2 + 1];
           if (e > 0) {
-            const float cs = s.csn[(t - 1) * 2 + 0], sn = s.csn[(t - 1) * 2 + 1];
+            const float cs = csp, sn = snp;
             const float a = gx * cs + gy * sn, b = -gx * sn + gy * cs;
             gx = a; gy = b;
           }
           const float g[2] = {gx, gy};
-          if (e == 0) {
-            if (st.var_mask & GLAMR_VAR_LOCAL_XY)
-              for (int k = 0; k < 2; ++k) { const int i = lo.local_xy + k; if (sh.store_grad) s.g[i] = g[k]; adam(s.p[i], s.m[i], s.v[i], g[k], ac); }
-          } else {
+          {
             float g2[2];
             for (int k = 0; k < 2; ++k) {
               const float r = a_dxy.P[k] * FPS;
-              if (on(GLAMR_LOSS_LOCAL_DXY_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r;
-              g2[k] = g[k] + 2.0f * FPS * r * w_dxy;
+              if (on(GLAMR_LOSS_LOCAL_DXY_REG)) if (last && !first) lsum[GLAMR_LOSS_LOCAL_DXY_REG] += r * r;
+              const float greg = g[k] + 2.0f * FPS * r * w_dxy;
+              g2[k] = first ? g[k] : greg;                       // (local_xy has no regulariser)
             }
-            if (upd_dxy) a_dxy.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_dxy + e * 2, g2, ac);
+            if (upd_dxy) a_dxy.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, ixy, g2, ac);
           }
         }
+      // REGB instances: the state of this frame's heading parameter (own data) is requested before the scan's barrier, not after it
+      AdamRegs<1> a_hpre;
+      a_hpre.zero();
+      if (REGB)
+        for (int t = rt.tid(); frame_in(t, T); t += fstep) {
+          const PersonView c = pv(0);
+          if (t < c.fr_start || t >= c.fr_end) continue;
+          const int e = t - c.fr_start;
+          const int i = e == 0 ? lo.local_heading : lo.local_dheading + e;
+          if (e == 0 ? (bool)(st.var_mask & GLAMR_VAR_LOCAL_HEADING) : (bool)(st.var_mask & GLAMR_VAR_LOCAL_DHEADING)) a_hpre.load(c.p, c.m, c.v, i);
+          else a_hpre.P[0] = c.p[i];
+        }
+      if constexpr (REGB) {
+        rt.template scan_regs<NWC, 1>(gth_r, true, scan_shuffle);
+      } else
 #ifdef GLAMR_GRECON_WIDE      // (absolute_heading: a frame's heading gradient is its own)
       if (st.flags & GLAMR_FLAG_ABSOLUTE_HEADING) rt.sync(); else
 #endif
@@ -1604,12 +1792,12 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         float* ch[8];
         if constexpr (MAXP <= 8) {
           for (int p = 0; p < P; ++p) ch[p] = pv(p).g_theta;
-          rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, true);
+          rt.template scan_multi<(FAST != 0)>(ch, P, T, 1, true, scan_shuffle);
         } else {
           for (int p0 = 0; p0 < P; p0 += 8) {
             const int np = P - p0 < 8 ? P - p0 : 8;
             for (int p = 0; p < np; ++p) ch[p] = pv(p0 + p).g_theta;
-            rt.template scan_multi<(FAST != 0)>(ch, np, T, 1, true);
+            rt.template scan_multi<(FAST != 0)>(ch, np, T, 1, true, scan_shuffle);
           }
         }
       }
@@ -1621,20 +1809,23 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const PersonView& s = c;
           if (t < c.fr_start || t >= c.fr_end) continue;
           const int e = t - c.fr_start;
-          const float gh = s.g_theta[t];
-          if (e == 0) {
-            if (st.var_mask & GLAMR_VAR_LOCAL_HEADING) { const int i = lo.local_heading; if (sh.store_grad) s.g[i] = gh; adam(s.p[i], s.m[i], s.v[i], gh, ac); }
-          } else {
-            const int i = lo.local_dheading + e;
-            const float v = s.p[i];
+          const float gh = REGB ? gth_r[0] : s.g_theta[t];
+          // frame 0 updates local_heading where the others update their row of local_dheading: selected index, one update (see phase I)
+          const bool first = e == 0;
+          const int i = first ? lo.local_heading : lo.local_dheading + e;
+          const bool upd = first ? (bool)(st.var_mask & GLAMR_VAR_LOCAL_HEADING) : (bool)(st.var_mask & GLAMR_VAR_LOCAL_DHEADING);
+          AdamRegs<1> a_h = a_hpre;
+          if (!REGB) { if (upd) a_h.load(s.p, s.m, s.v, i); else a_h.P[0] = s.p[i]; }
+          float gj[1] = {gh};
+          if (!first) {
+            const float v = a_h.P[0];
             float sv, cv;
             rm::sincos_(v, sv, cv);
             if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cv - 1.0f) * FPS, b = sv * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
-            if (!(st.var_mask & GLAMR_VAR_LOCAL_DHEADING)) continue;
             const float g = (c.dheading_mask ? gh * c.dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cv - 1.0f) * (-sv) + sv * cv) * w_dh;
-            if (sh.store_grad) s.g[i] = g;
-            adam(s.p[i], s.m[i], s.v[i], g, ac);
+            gj[0] = g;
           }
+          if (upd) a_h.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, i, gj, ac);
         }
     }
     // regulariser values that do not depend on being optimised (reported every evaluation)

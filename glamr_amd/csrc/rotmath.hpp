@@ -65,8 +65,11 @@ GLAMR_HD float sqrt_(float x) { return sqrtf(x); }
 // The host runtime uses the C operators (IEEE by definition; built with -ffp-contract=off).
 #if defined(__HIP_DEVICE_COMPILE__)
 GLAMR_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-GLAMR_HD float div_(float n, float d) {
-  float y = __builtin_amdgcn_rcpf(d);
+// (the hardware instruction and the correction apart: callers that run several independent evaluations side by side -- grecon_algo.hpp
+// adam_n -- issue all the v_sqrt / v_rcp first; div_ / sqrt_rn_ are the two halves in sequence)
+GLAMR_HD float hw_rcp_(float d) { return __builtin_amdgcn_rcpf(d); }
+GLAMR_HD float hw_sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+GLAMR_HD float div_fix_(float n, float d, float y) {
   const float e = __builtin_fmaf(-d, y, 1.0f);
   y = __builtin_fmaf(e, y, y);
   float q = n * y;
@@ -75,14 +78,15 @@ GLAMR_HD float div_(float n, float d) {
   r = __builtin_fmaf(-d, q, n);
   return __builtin_fmaf(r, y, q);
 }
-GLAMR_HD float sqrt_rn_(float x) {
-  const float s = __builtin_amdgcn_sqrtf(x);
+GLAMR_HD float div_(float n, float d) { return div_fix_(n, d, hw_rcp_(d)); }
+GLAMR_HD float sqrt_rn_fix_(float x, float s) {
   const float dn = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1), up = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
   const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
   float o = rdn <= 0.0f ? dn : s;
   o = rup > 0.0f ? up : o;
   return o;
 }
+GLAMR_HD float sqrt_rn_(float x) { return sqrt_rn_fix_(x, hw_sqrt_(x)); }
 #elif defined(GLAMR_HOSTSIM_ULP_NOISE_ADAM)
 GLAMR_HD float fma_(float a, float b, float c) { return fmaf(a, b, c); }
 GLAMR_HD float div_(float a, float b) { return a * rcp_(b); }

@@ -166,11 +166,6 @@ def check_case(runner, asset_root, golden, cfg_id, T, P, K):
             worst[2] = max(worst[2], _rot_err(pd['smpl_orient_world'].numpy(), g['opt_p%d_smpl_orient_world' % pi]))
     print('K-step state %s T=%d P=%d K=%d: kp %.4f px, root_trans_world %.2e, smpl_orient_world %.2e' % (cfg_id, T, P, K, *worst))
     assert worst[0] < tol_kp, 'kp_2d_pred after optimisation: %g px' % worst[0]
-    if cfg_id == 'glamr_3dpw':      # (the gauge case: the bound on the largest difference is wide, so the typical one is bounded too)
-        pd0 = data['person_data'][0]
-        vis0 = g['init_p0_vis_frames']
-        mean = float(np.abs(pd0['kp_2d_pred'].numpy().astype(np.float64) - g['opt_p0_kp_2d_pred'])[vis0].mean())
-        assert mean < 0.06, 'kp_2d_pred after optimisation, mean over the visible frames: %g px' % mean
     assert worst[1] < tol_tr, 'root_trans_world: %g' % worst[1]
     assert worst[2] < tol_rot, 'smpl_orient_world (as rotation): %g' % worst[2]
 
@@ -183,11 +178,12 @@ KSTEP_TOL = {   # achieved (MI355X / CPU runtime):           kp px            ro
     ('glamr_dynamic_multi', 100, 2): (0.15, 6e-4, 5e-3),      # 0.043 / 0.046    1.6e-4 / 1.8e-4   1.6e-3 / 1.6e-3
     # glamr_3dpw: the camera rides on the person, so the world trajectory is a GAUGE: the fixture's own gradient of `traj_local_xy` is
     # (3.0e-4, 5.9e-5) beside terms of 1.6e3 -- below fp32 rounding of what it is summed from -- and Adam's first steps are lr x its SIGN.
-    # With the stage's prefix sums as ds_bpermute shuffles (rounds 1-3) or sequential (CPU runtime) that sign came out as the reference's:
-    # 0.002 px; as DPP row shifts (round 4, another order of the same exact-on-integers sums: tests/test_scan_gpu.py) it does not: after 15
-    # steps `traj_local_xy[1]` is 0.1 m elsewhere and the projections differ by 0.20 px at most, 0.02 px on average
-    # (profiles/r04_scan_dpp_ab.log); the full 3dpw schedules end 0.03 px from the reference either way (tests/test_e2e_gpu.py).
-    ('glamr_3dpw', 120, 1): (0.6, 1e-6, 1e-6),                # 0.20 (0.002 with shuffle scans) / 0.002    (the person's world pose is not compared)
+    # With the suffix sum of the planar-position gradient in the Hillis-Steele order (ds_bpermute shuffles, rounds 1-3) or sequential (CPU
+    # runtime) that sign comes out as the reference's: 0.002 px; in the DPP row-shift order (round 4: another order of the same
+    # exact-on-integers sums, tests/test_scan_gpu.py) it did not: 0.20 px, and round 4 widened this bound to 0.6.  Round 5: the instances that
+    # derive the camera from the person keep the Hillis-Steele order for that ONE scan (grecon_algo.hpp `gxy_shuffle`; the other instances
+    # and the other three scans stay on DPP), and the bound is back where it was.
+    ('glamr_3dpw', 120, 1): (0.01, 1e-6, 1e-6),               # 0.002 / 0.002    (the person's world pose is not compared)
     ('glamr_h36m', 100, 2): (0.55, 2e-5, 9e-4),               # 0.074 / 0.177    2.4e-6 / 5.0e-6   2.8e-4 / 2.6e-4
     ('glamr_static_multi', 300, 4): (0.05, 6e-5, 1.1e-3),     # 0.012 / 0.015    1.2e-5 / 1.9e-5   3.5e-4 / 3.3e-4
     # more than 8 persons (csrc/grecon_wide.hip; MI355X only).  Through optimize(): 0.009 px / 1.5e-5 / 1.9e-6 and 0.003 px / 5.5e-6 / 2.6e-6

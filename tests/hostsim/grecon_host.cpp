@@ -16,7 +16,7 @@ struct HostRT {
   float reduce_sum(float v) const { return v; }
   template <int N> void reduce_sum_n(float (&)[N]) const {}
   template <bool LDS = false>
-  void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse) const {
+  void scan_multi(float* const* ch, int nch, int n, int stride, bool reverse, bool /*shuffle_order*/ = false) const {
     for (int c = 0; c < nch; ++c) scan(ch[c], n, stride, reverse);
   }
   void scan(float* a, int n, int stride, bool reverse) const {

@@ -21,3 +21,6 @@ def test_block_scans_are_exact_on_integer_data(tmp_path, variant):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:]
     assert '320 cases, 0 with mismatches' in out.stdout
+    # DeviceRT::scan_regs (round 5: scan operands and results in registers, compile-time wave count): exact on integers and bit-identical to
+    # scan_multi on arbitrary floats, in both summation orders of the wave part
+    assert 'scan_regs: ' in out.stdout and ' cases, 0 with mismatches' in out.stdout.split('scan_regs: ')[1], out.stdout[-2000:]
