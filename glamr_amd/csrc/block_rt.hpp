@@ -43,7 +43,10 @@ struct DeviceRT {
   unsigned long long t_last = 0, acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __device__ void mark_begin() { t_last = wall_clock64(); }
   template <int K> __device__ void mark() { const unsigned long long n = wall_clock64(); acc[K] += n - t_last; t_last = n; }
-  __device__ void mark_end() { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k = 0; k < 16; ++k) g_phase_ticks[k] = acc[k]; }
+#ifndef GLAMR_PHASE_TIMING_THREAD
+#define GLAMR_PHASE_TIMING_THREAD 0      // whose clock is reported: thread 0's wave shares its SIMD with the fifth wave of a 300-frame scene, thread 64's has a SIMD to itself
+#endif
+  __device__ void mark_end() { if (blockIdx.x == 0 && threadIdx.x == GLAMR_PHASE_TIMING_THREAD) for (int k = 0; k < 16; ++k) g_phase_ticks[k] = acc[k]; }
 #endif  // scan_multi alternates between two halves of `red` so consecutive calls need no barrier in between
   // In-place inclusive prefix (reverse: suffix) sums of up to RT_MAX_CH arrays ch[c][i*stride], i in [0,n).  Element i is read and
   // written by thread i mod blockDim only, so a caller whose next phase touches only its own elements needs no barrier after it;

@@ -1484,22 +1484,22 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       // camera-only terms on the camera-to-world transform  (loss_func.py:76-114)
       // the neighbouring frames' camera-to-world transforms: two whole rows up front (clamped at the ends) instead of eighteen conditional
       // element reads -- each of those was a branch of its own with an LDS round trip inside (0.75 of this phase's 1.1 us)
-      float Cn[12], Cp[12];
+      float Cn[12], Cp[12], Mo[12];      // (Mo: this frame's own row, in registers -- `Mi[..]` inside a condition is again a load behind a branch)
       if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS) || on(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS)) {
         const int tn = t + 1 < T ? t + 1 : t, tp = t > 0 ? t - 1 : t;
-        for (int k = 0; k < 12; ++k) { Cn[k] = sh.cam_inv[(size_t)tn * 12 + k]; Cp[k] = sh.cam_inv[(size_t)tp * 12 + k]; }
+        for (int k = 0; k < 12; ++k) { Cn[k] = sh.cam_inv[(size_t)tn * 12 + k]; Cp[k] = sh.cam_inv[(size_t)tp * 12 + k]; Mo[k] = Mi[k]; }
       }
       if (on(GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i)
           for (int j = 0; j < 2; ++j) {
-            if (t + 1 < T) { const float v = (Mi[i * 4 + j] - Cn[i * 4 + j]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] += v * v; gCi[i * 4 + j] += 2.0f * FPS * v * w_crs; }
-            if (t > 0) { const float v = (Cp[i * 4 + j] - Mi[i * 4 + j]) * FPS; gCi[i * 4 + j] -= 2.0f * FPS * v * w_crs; }
+            if (t + 1 < T) { const float v = (Mo[i * 4 + j] - Cn[i * 4 + j]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_INV_ROT_SMOOTHNESS] += v * v; gCi[i * 4 + j] += 2.0f * FPS * v * w_crs; }
+            if (t > 0) { const float v = (Cp[i * 4 + j] - Mo[i * 4 + j]) * FPS; gCi[i * 4 + j] -= 2.0f * FPS * v * w_crs; }
           }
       }
       if (on(GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS)) {
         for (int i = 0; i < 3; ++i) {
-          if (t + 1 < T) { const float v = (Cn[i * 4 + 3] - Mi[i * 4 + 3]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] += v * v; gCi[i * 4 + 3] -= 2.0f * FPS * v * w_cos; }
-          if (t > 0) { const float v = (Mi[i * 4 + 3] - Cp[i * 4 + 3]) * FPS; gCi[i * 4 + 3] += 2.0f * FPS * v * w_cos; }
+          if (t + 1 < T) { const float v = (Cn[i * 4 + 3] - Mo[i * 4 + 3]) * FPS; if (last) lsum[GLAMR_LOSS_CAM_ORIGIN_SMOOTHNESS] += v * v; gCi[i * 4 + 3] -= 2.0f * FPS * v * w_cos; }
+          if (t > 0) { const float v = (Mo[i * 4 + 3] - Cp[i * 4 + 3]) * FPS; gCi[i * 4 + 3] += 2.0f * FPS * v * w_cos; }
         }
       }
       if (on(GLAMR_LOSS_CAM_UP_REG) && (!ffo(GLAMR_LOSS_CAM_UP_REG) || t == 0)) {
@@ -1773,6 +1773,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       // REGB instances: the state of this frame's heading parameter (own data) is requested before the scan's barrier, not after it
       AdamRegs<1> a_hpre;
       a_hpre.zero();
+      float dmask_pre = 0.f;      // (and its row of the heading mask: a load from the workspace that sat right in front of its use)
       if (REGB)
         for (int t = rt.tid(); frame_in(t, T); t += fstep) {
           const PersonView c = pv(0);
@@ -1781,6 +1782,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const int i = e == 0 ? lo.local_heading : lo.local_dheading + e;
           if (e == 0 ? (bool)(st.var_mask & GLAMR_VAR_LOCAL_HEADING) : (bool)(st.var_mask & GLAMR_VAR_LOCAL_DHEADING)) a_hpre.load(c.p, c.m, c.v, i);
           else a_hpre.P[0] = c.p[i];
+          if (c.dheading_mask) dmask_pre = c.dheading_mask[e];
         }
       if constexpr (REGB) {
         rt.template scan_regs<NWC, 1>(gth_r, true, scan_shuffle);
@@ -1822,7 +1824,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
             float sv, cv;
             rm::sincos_(v, sv, cv);
             if (on(GLAMR_LOSS_LOCAL_DHEADING_REG_NEW)) { const float a = (cv - 1.0f) * FPS, b = sv * FPS; if (last) lsum[GLAMR_LOSS_LOCAL_DHEADING_REG_NEW] += a * a + b * b; }
-            const float g = (c.dheading_mask ? gh * c.dheading_mask[e] : 0.0f) + 2.0f * FPS * FPS * ((cv - 1.0f) * (-sv) + sv * cv) * w_dh;
+            const float mk = REGB ? dmask_pre : (c.dheading_mask ? c.dheading_mask[e] : 0.0f);
+            const float g = (c.dheading_mask ? gh * mk : 0.0f) + 2.0f * FPS * FPS * ((cv - 1.0f) * (-sv) + sv * cv) * w_dh;
             gj[0] = g;
           }
           if (upd) a_h.step_store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, i, gj, ac);
