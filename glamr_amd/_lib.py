@@ -26,7 +26,7 @@ class SceneBatch(Structure):
                [(n, c_void_p) for n in ('n_persons', 'seq_len', 'fr_start', 'fr_end', 'vis', 'j_local', 'kp_2d', 'kp_score', 'cam_K',
                                         'traj_local_pred', 'orient_cam', 'base_orient', 'base_trans', 'person2cam', 'dheading_mask',
                                         'rel_transform_cam', 'cam_pose', 'params', 'losses', 'orient_world', 'trans_world',
-                                        'kp_2d_pred', 'orient_cam_in_world', 'frozen', 'g_j_local')]
+                                        'kp_2d_pred', 'orient_cam_in_world', 'frozen', 'g_j_local', 'loss_history')]
 
 
 class FilterOpts(Structure):

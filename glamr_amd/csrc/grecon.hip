@@ -223,7 +223,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // frame, the full arena of the 304-frame layout fits, and the caller does not ask for the gradient record
   const int lay_len = layout_frames(batch->max_persons, batch->max_len);
   const bool no_const_layout = std::getenv("GLAMR_GRECON_NO_CONST_LAYOUT") != nullptr;      // development aid / A-B tests (read per launch)
-  const bool const_layout = lay_len == GLAMR_CONST_LAYOUT_FRAMES && !grads_out && !no_const_layout && batch->max_len <= threads &&
+  const bool const_layout = lay_len == GLAMR_CONST_LAYOUT_FRAMES && !grads_out && !no_const_layout && batch->max_len <= threads && !(batch->loss_history && stage->niters > 0) &&
                             scene_fast_floats(1, lay_len, 1) * sizeof(float) <= LDS_BUDGET;
   ka.layout_len = const_layout ? lay_len : 0;
   const int arena_len = const_layout ? lay_len : batch->max_len;
@@ -233,6 +233,9 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // 0 everything in the workspace
   const bool per_frame = batch->max_len <= threads;
   ka.use_lds = (full <= LDS_BUDGET && per_frame) ? 1 : ((full_arena <= LDS_BUDGET && per_frame) ? 3 : (lite <= LDS_BUDGET ? 2 : 0));
+  // a launch that records the per-iteration loss history (glamr_scene_batch.loss_history) runs on the plain instance: the reporting evaluation
+  // every iteration is a diagnostic mode, and the arena instances' loops stay free of it
+  if (batch->loss_history && stage->niters > 0) ka.use_lds = 0;
   const size_t base = ka.use_lds == 1 ? full : (ka.use_lds == 3 ? full_arena : lite);
   const size_t want = base + (size_t)NJ * 6 * batch->max_persons * arena_len * sizeof(float);
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;

@@ -119,6 +119,7 @@ struct Scene {
   float* cp_g;                        // the batch array; cp is it, or (on-chip Adam state) a COMPACT 9 T copy: camera parameters when the
                                       // stage optimises them, else the camera residuals shifted down by 9 T
   float* losses;                      // [GLAMR_NUM_LOSSES]
+  float* loss_history;                // [niters][GLAMR_NUM_LOSSES] the reported values of every iteration, or null (glamr_scene_batch.loss_history)
   int store_grad;
   int rel_stride_p, rel_stride_t;     // padded person count / frame count of rel_cam
   float* fast_free; size_t fast_left; // unused tail of the on-chip arena (claimed by setup for kpc when it fits)
@@ -612,6 +613,7 @@ GLAMR_HD void assemble_scene(const glamr_scene_batch& b, const glamr_param_layou
   sc.cp_g = b.params + (size_t)si * l.scene_stride;
   sc.cp = o.adam_fast ? at(o.cp) : sc.cp_g;
   sc.losses = b.losses + (size_t)si * GLAMR_NUM_LOSSES;
+  sc.loss_history = (b.loss_history && st->niters > 0) ? b.loss_history + (size_t)si * st->niters * GLAMR_NUM_LOSSES : nullptr;
   sc.store_grad = grads_out != nullptr;
   sc.cm = at(o.cm); sc.cv = at(o.cv);
   sc.cg = grads_out ? grads_out + (size_t)si * l.scene_stride : at(o.cg_ws);
@@ -1864,8 +1866,19 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
     }
     GLAMR_MARK(rt, 8);
   };
-  for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::false_type{}); trace_hook(rt, it, sc, 0); }
+  // per-iteration loss log (write_logs, :564,646-659): every iteration runs the reporting evaluation and thread 0 copies the values it just
+  // wrote.  Only the plain instances carry this loop (the launcher sends a batch with a history there): the arena instances stay as they are.
+  float* const hist = FAST == 0 ? uni(sc.loss_history) : nullptr;
+  auto keep_losses = [&](int it) {
+    if (FAST == 0 && hist && rt.tid() == 0) for (int k = 0; k < GLAMR_NUM_LOSSES; ++k) glob(hist)[(size_t)it * GLAMR_NUM_LOSSES + k] = sh.losses[k];
+  };
+  if (FAST == 0 && hist) {
+    for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::true_type{}); keep_losses(it); trace_hook(rt, it, sc, 0); }
+  } else {
+    for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::false_type{}); trace_hook(rt, it, sc, 0); }
+  }
   evaluate(std::true_type{});
+  keep_losses(n_eval - 1);
   trace_hook(rt, n_eval - 1, sc, 0);
   rt.sync();
   if (AF) {      // the on-chip parameters go back to the batch array, once

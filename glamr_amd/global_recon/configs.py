@@ -83,7 +83,9 @@ CONFIGS = _build()
 
 
 def get_config(cfg_id):
-    return copy.deepcopy(CONFIGS[cfg_id])
+    cfg = copy.deepcopy(CONFIGS[cfg_id])
+    cfg.setdefault('id', cfg_id)          # Config.id of the reference (global_recon/utils/config.py): the name the per-iteration log line starts with
+    return cfg
 
 
 def load_yaml(path):

@@ -195,6 +195,14 @@ class GlobalReconOptimizer:
         _lib.lib()                                                     # fail early and loudly if the HIP library is missing
         self.pipeline_gate = None                                      # a PipelineGate when the caller alternates batches between two streams
         self._capture_split = None
+        # Per-iteration loss log (:564,646-659).  The reference calls write_logs after EVERY optimizer.step -- with `log` None it prints.  Here
+        # the iterations of a stage are one kernel launch: with a `log` (or keep_loss_history = True) the launch records the unweighted value of
+        # every term at every iteration (glamr_scene_batch.loss_history; the plain instance with the reporting evaluation, about 2x the time),
+        # run_schedule hands them to `log.info` in the reference's line format once the stage is done, and `loss_history[stage]` keeps the
+        # (scenes, iterations, GLAMR_NUM_LOSSES) array.  Without a log nothing is recorded and nothing is printed: a batch of 1024 sequences
+        # would be half a million lines.
+        self.keep_loss_history = False
+        self.loss_history = {}
         g = self.specs.get
         if g('est_type', 'hybrik') != 'hybrik' or not g('flag_infer_motion_traj', False) or not g('flag_pred_traj', True) \
                 or not g('flag_opt_traj', True) or not g('flag_infill_motion', True):
@@ -667,6 +675,7 @@ class GlobalReconOptimizer:
                 gate.before(torch.cuda.current_stream(dev))
         packed = packing.PackedScenes.empty(S, P, T, dev)
         packed.person_ids = rin.ids
+        packed.seq_names = [str(m['seq_name']) for m in rin.meta]
         packed.t['cam_K'] = g['K']
         packed.t['n_persons'] = rin.n_persons
         packed.t['seq_len'] = rin.seq_len
@@ -693,11 +702,17 @@ class GlobalReconOptimizer:
         else:
             meps = rin.meps if rin.meps is not None else torch.randn((n_slots, nw, NZ), device=dev)
             teps = rin.teps if rin.teps is not None else torch.randn((n_slots, NZ), device=dev)
-        out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps, buffers=rs, coschedule=gate is not None)
-        if self._capture_split is not None:
-            self._capture_split()                                       # capture_resident under a gate: the graph is cut here
-        elif gate is not None and not torch.cuda.is_current_stream_capturing():
-            gate.after(torch.cuda.current_stream(dev))
+        def open_gate():
+            if self._capture_split is not None:
+                self._capture_split()                                   # capture_resident under a gate: the graph is cut here
+            elif gate is not None and not torch.cuda.is_current_stream_capturing():
+                gate.after(torch.cuda.current_stream(dev))
+        # the next batch may start when this batch's priors are done -- or (GLAMR_GATE_AFTER=infiller) already when its infiller is
+        early = gate is not None and os.environ.get('GLAMR_GATE_AFTER', 'priors') == 'infiller'
+        out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps, buffers=rs, coschedule=gate is not None,
+                                         between=open_gate if early else None)
+        if not early:
+            open_gate()
         packed.latents = (meps, teps)                                  # the draws this batch was initialised with (parameters in latent-optimisation mode)
         _lib.check(L.glamr_init_scenes(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
                                        _lib.ptr(out['orient']), _lib.ptr(ws), st))
@@ -888,16 +903,41 @@ class GlobalReconOptimizer:
         if self.flag_opt_vis_local_rot:
             return self._run_schedule_masked(packed, max_iters, has_wd)
         events = []
+        want_hist = (self.log is not None or self.keep_loss_history) and not torch.cuda.is_current_stream_capturing()
         for stage, spec in self.opt_stage_specs.items():
             sd = packing.stage_desc(spec, self.specs, has_world_dheading=has_wd,
                                     niters=None if max_iters is None else min(max_iters, spec['opt_niters']))
+            if want_hist and sd.niters > 0:
+                packed.t['loss_history'] = torch.zeros((packed.S, int(sd.niters), len(packing.LOSS_IDS)), dtype=torch.float32, device=self.device)
             events.append(self._run(packed, sd))               # the launch's workspace: its header carries the kernel's own clock stamps
+            if 'loss_history' in packed.t:
+                self._report_stage(packed, stage, spec, packed.t.pop('loss_history'), events[-1])
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
         packed.has_world_dheading = has_wd
         packed.stage_ws = events
         return packed
+
+    def _report_stage(self, packed, stage, spec, hist, ws):
+        """write_logs (:646-659) for every iteration of a finished stage launch: `cfg id - sequence - stage | it/niters | TE: .. ETA: .. | LR: .. |
+        term: value | ...` with the UNWEIGHTED values (loss_uw_dict, :564) of the stage's terms in the order of its loss_cfg.  The time per
+        iteration is the launch's duration divided by its iterations."""
+        import datetime
+        h = hist.cpu().numpy()                                          # (waits for the launch)
+        self.loss_history[stage] = h
+        if self.log is None:
+            return
+        n_it = h.shape[1]
+        it_secs = self.launch_ms(ws) * 1e-3 / max(1, n_it)
+        hms = lambda secs: str(datetime.timedelta(seconds=round(secs)))
+        names = [n for n in spec['loss_cfg'] if n in packing.LOSS_IDS]
+        seqs = getattr(packed, 'seq_names', None) or ['seq%d' % si for si in range(packed.S)]
+        for si in range(packed.S):
+            head = '%s - %s - %s' % (self.cfg_id, seqs[si], stage)
+            for it in range(n_it):
+                loss_str = ' | '.join('%s: %7.3f' % (n, h[si, it, packing.LOSS_IDS[n]]) for n in names)
+                self.log.info('%s | %4d/%d | TE: %s ETA: %s | LR: %.0e | %s' % (head, it, n_it, hms(it_secs), hms(it_secs * (n_it - it - 1)), spec['opt_lr'], loss_str))
 
     def _run_schedule_masked(self, packed, max_iters, has_wd):
         """flag_opt_vis_local_rot: the schedule launch by launch (parallel.PersonShardedSchedule on ONE rank without collectives: a gradient launch

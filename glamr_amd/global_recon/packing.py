@@ -217,6 +217,7 @@ class PackedScenes:
                     jl_host[si * P + pi, :int(d['seq_len'])] = cpu(j_locals[si][idx]).float()
             self.t['j_local'] = jl_host.contiguous().to(device)
         self.has_world_dheading = any('world_dheading' in pd for d in datas for pd in d['person_data'].values())
+        self.seq_names = [str(d.get('seq_name', 'seq%d' % si)) for si, d in enumerate(datas)]      # (the per-iteration log names its sequence)
 
     def struct(self):
         sb = _lib.SceneBatch()

@@ -511,9 +511,16 @@ class MotionTrajJointModel:
     def get_traj_latent(self, seq_len):
         return self.traj_predictor.get_latent(seq_len)
 
-    def infer_padded(self, body_pose, visible, lens, motion_eps, traj_eps, buffers=None, coschedule=False):
-        """Batched entry used by GlobalReconOptimizer: ragged sequences padded to a common length."""
-        return self.handle.infer(body_pose, visible, lens, motion_eps=motion_eps, traj_eps=traj_eps, buffers=buffers, coschedule=coschedule)
+    def infer_padded(self, body_pose, visible, lens, motion_eps, traj_eps, buffers=None, coschedule=False, between=None):
+        """Batched entry used by GlobalReconOptimizer: ragged sequences padded to a common length.  `between`: called after the motion infiller
+        has been enqueued and before the trajectory predictor is (two library calls instead of one) -- where a pipelined caller lets the next
+        batch start (GlobalReconOptimizer.pipeline_gate)."""
+        if between is None:
+            return self.handle.infer(body_pose, visible, lens, motion_eps=motion_eps, traj_eps=traj_eps, buffers=buffers, coschedule=coschedule)
+        out = self.handle.infer(body_pose, visible, lens, motion_eps=motion_eps, traj=False, buffers=buffers, coschedule=coschedule)
+        between()
+        out.update(self.handle.infer(out['pose'], None, lens, traj_eps=traj_eps, infill=False, buffers=buffers, coschedule=coschedule))
+        return out
 
     def pred_trajectory(self, data, sample_num, recon=False, multi_step=False):
         """motion_traj_joint_model.py:73-133 (in_joint_pos_only False, model_type 'angle'): the infiller's motion through the trajectory

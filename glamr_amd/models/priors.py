@@ -1,6 +1,9 @@
 """Device handle of the two motion priors (glamr_nets_* in include/glamr_hip.h): weight hand-over and the batched inference call.
 All arithmetic is in the HIP kernels (glamr_amd/csrc/nets.hip, nn_kernels.hpp); this module only marshals tensors."""
 import ctypes
+import logging
+import os
+import sys
 
 import numpy as np
 import torch
@@ -49,6 +52,18 @@ class MotionPriorsHandle:
                                            _lib.ptr(np.ascontiguousarray(rest_joints, dtype=np.float32)),
                                            _lib.ptr(np.ascontiguousarray(parents, dtype=np.int32))))
         self.h = h
+        # Which kernel family this checkpoint runs on is decided from its weights (glamr_nets_precision): said out loud, once per handle -- a
+        # trained checkpoint that falls out of the fp16 planes' range is slower, not wrong, and the user should know which one they have.
+        wc = (ctypes.c_double * 2)()
+        self.fp32_only = bool(L.glamr_nets_precision(h, wc))
+        self.precision_bound, self.largest_weight = float(wc[0]), float(wc[1])
+        msg = ('motion priors on %s: %s (worst-case magnitude the fp16 operand planes would have to hold %.4g, largest weight %.4g; limit 3e4)'
+               % (device, 'plain fp32 kernels (fp32 MFMA GEMMs, fp32 attention, small-batch LSTM; no fused blocks)' if self.fp32_only
+                  else 'fp32-grade products on the fp16 matrix cores (two fp16 planes per operand, three MFMAs per k step)',
+                  self.precision_bound, self.largest_weight))
+        logging.getLogger('glamr_amd').log(logging.WARNING if self.fp32_only else logging.INFO, msg)
+        if self.fp32_only or os.environ.get('GLAMR_VERBOSE'):
+            print('[glamr_amd] ' + msg, file=sys.stderr)
 
     def close(self):
         """Releases the device weights and the captured launch graphs of this handle (glamr_nets_destroy).  Pending work must have

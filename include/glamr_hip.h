@@ -299,6 +299,12 @@ typedef struct glamr_scene_batch {
    * glamr_smpl_backward when the body pose itself depends on optimisation variables (latent-optimisation mode, global_recon_model.py:434-437).
    * Only the reprojection term reaches the joints; rows of joints without weight and of invisible frames are zero. */
   float* g_j_local;                      /* (slots, max_len, n_joints, 3) or NULL */
+  /* out, optional: the unweighted value of every loss term at EVERY iteration of the launch -- what the reference hands to write_logs after
+   * each optimizer.step (global_recon_model.py:564, 646-659: one log line per iteration).  Row it of a scene = the terms evaluated at the
+   * parameters iteration it started from (the closure's forward pass), in the order of the GLAMR_LOSS_* ids, like `losses`.  A launch that
+   * records the history runs every iteration on the plain (workspace) instance with the reporting evaluation: about 2x the time of a launch
+   * without it, same update arithmetic.  NULL = not recorded. */
+  float* loss_history;                   /* (n_scenes, stage->niters, GLAMR_NUM_LOSSES) or NULL */
 } glamr_scene_batch;
 
 /* Offsets (in floats) of each variable block inside one scene's parameter vector; see glamr_grecon_param_layout().

@@ -841,6 +841,102 @@ def gen_seed_traj_family(seeds=WIDE_FAMILY_SEEDS, members=TRAJ_FAMILY):
         np.savez_compressed(path, **out)
 
 
+DIV_K = 64                       # iterations of the divergence study
+DIV_FRAMES = (90, 170)           # camera parameters of these frames are kept per iteration (the detection gap [100, 160) and its edges)
+DIV_MEMBERS = [('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-7_seed1', dict(eps=1e-7, seed=1))] + SEED_FAMILY
+SEED1_MORE = [('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-7_seed1', dict(eps=1e-7, seed=1)),
+              ('eps1e-6_seed3', dict(eps=1e-6, seed=3)), ('eps1e-6_seed4', dict(eps=1e-6, seed=4))]
+
+
+def _traced_reference(seed, opt, niters, md):
+    """One run of the unmodified reference on BASELINE configs[1] (seed, detection gap) with its initial cam_pose perturbed as `opt` says;
+    returns (data, trajectory): the camera parameters (cam_rot_6d (T,6), cam_trans (T,3)) AFTER every Adam step, (niters, T, 9)."""
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    trace = {'p': []}
+
+    class Log(rh.QuietLog):
+        def info(self, *a, **k):
+            if 'params' in trace and a and ' | ' in str(a[0]):
+                ps = trace['params']
+                trace['p'].append(np.concatenate([ps[0].detach().numpy().reshape(-1, 6), ps[1].detach().numpy().reshape(-1, 3)], axis=1).copy())
+
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(opt.get('threads', keep_threads))
+    try:
+        model, cfg = rh.reference_optimizer('glamr_dynamic', log=Log())
+        in_dict = synth.make_in_dict(seed=seed, num_frames=300, num_persons=1, smpl_model=md)
+        keep = model.init_opt
+
+        def init_opt(data, opt_variables, opt_lr, keep=keep, opt=opt):
+            if opt.get('eps'):
+                rng = np.random.RandomState(opt['seed'])
+                cp = data['cam_pose']
+                cp.mul_(torch.from_numpy((1 + opt['eps'] * rng.uniform(-1, 1, tuple(cp.shape))).astype(np.float32)))
+            optimizer, param_list = keep(data, opt_variables, opt_lr)
+            assert _param_names(model, data, opt_variables)[:2] == ['cam_rot_6d', 'cam_trans']
+            trace['params'] = param_list
+            return optimizer, param_list
+        model.init_opt = init_opt
+        data, _ = run_reference(model, cfg.opt_stage_specs, in_dict, latents_for(in_dict, seed), niters=niters)
+    finally:
+        torch.set_num_threads(keep_threads)
+    return data, np.stack(trace['p'])
+
+
+def first_divergence(traj, ref, tol=1e-4):
+    """First iteration (1-based: after that many Adam steps) at which a camera-parameter trajectory (K, frames, 9) is more than `tol` away from
+    the reference's; K + 1 if it never is."""
+    d = np.abs(np.asarray(traj, np.float64) - np.asarray(ref, np.float64)).reshape(len(ref), -1).max(axis=1)
+    over = np.nonzero(d > tol)[0]
+    return int(over[0]) + 1 if len(over) else len(ref) + 1
+
+
+def gen_seed_divergence(seeds=(1, 4, 6), K=DIV_K):
+    """VERDICT r4 item 3a.  Seeds 1, 4 and 6 of the benchmark's workload are the ones where a run started from the reference's OWN initial state
+    ends pixels away from the reference's result -- and so do the reference's re-runs with the initial cameras perturbed in the 6th / 7th digit.
+    This records WHEN: the unmodified reference's camera parameters after each of its first K Adam steps (frames DIV_FRAMES: the detection gap
+    and its edges) -> `div_ref_cam`, and for five perturbed re-runs the first step at which they are more than 1e-4 away from that trajectory
+    -> `div_iter_<member>`.  tests/test_e2e_gpu.py holds the device kernel's own first divergence to that range.  (Short runs: K iterations.)"""
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    a, b = DIV_FRAMES
+    for seed in seeds:
+        path = os.path.join(GOLD, seed_name(seed) + '.npz')
+        out = dict(np.load(path))
+        _, ref = _traced_reference(seed, {}, K, md)
+        out['div_ref_cam'] = ref[:, a:b].astype(np.float32)
+        out['div_frames'] = np.array([a, b])
+        for name, opt in DIV_MEMBERS:
+            _, tr = _traced_reference(seed, opt, K, md)
+            it = first_divergence(tr[:, a:b], ref[:, a:b])
+            out['div_iter_%s' % name] = np.array(it)
+            print('seed %d: re-run %-14s leaves the reference trajectory (1e-4) after step %d; all frames: %d' % (seed, name, it, first_divergence(tr, ref)), flush=True)
+        np.savez_compressed(path, **out)
+
+
+def gen_seed1_more(members=SEED1_MORE, seed=1):
+    """seed 1's family of re-runs of the unmodified reference from 3 to 8 members (full 500-iteration schedules)."""
+    import time
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    path = os.path.join(GOLD, seed_name(seed) + '.npz')
+    for name, opt in members:
+        out = dict(np.load(path))
+        if 'fam_%s_kp_2d_pred' % name in out:
+            continue
+        t0 = time.time()
+        data, _ = _traced_reference(seed, opt, None, md)
+        st = _flatten_state(data, ['kp_2d_pred', 'root_trans_world'], ['cam_pose'])
+        out['fam_%s_kp_2d_pred' % name] = st['p0_kp_2d_pred']
+        out['fam_%s_cam_pose' % name] = st['cam_pose']
+        out['fam_%s_root_trans_world' % name] = st['p0_root_trans_world']
+        d = np.abs(st['p0_kp_2d_pred'] - out['p0_kp_2d_pred'])[out['p0_vis_frames']].max(axis=(1, 2))
+        print('seed %d family member %-14s %.0f s: max %.3f px, frames > 1 px %d' % (seed, name, time.time() - t0, d.max(), int((d > 1).sum())), flush=True)
+        np.savez_compressed(path, **out)          # (after every member: the runs take minutes each)
+
+
 FAMILY_CFG = [('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-6_seed0', dict(eps=1e-6, seed=0)), ('eps1e-6_seed1', dict(eps=1e-6, seed=1))]
 
 
@@ -940,7 +1036,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'grecon_family': gen_grecon_family, 'grecon_flags': gen_grecon_flags, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'grecon_family': gen_grecon_family, 'grecon_flags': gen_grecon_flags, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'seed_divergence': gen_seed_divergence, 'seed1_more': gen_seed1_more, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

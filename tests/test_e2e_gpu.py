@@ -336,6 +336,31 @@ def test_full_schedule_detection_gap_multi_seed(make_model, golden, seed):
         r['where'] = ('reference' if r['kp'] < 0.25 else 'member' if r['nearest'][0] < 0.25 else
                       'envelope' if (spread and r['kp'] <= 1.5 * env_px + 0.5 and r['over1'] <= env_n + 10) else 'outside')
     _MULTI[seed] = res
+    # a run that is only INSIDE THE ENVELOPE of the reference's family (not on a member) must at least not have left the
+    # reference's trajectory before the reference's own perturbed re-runs do.  The fixture holds the unmodified reference's camera parameters
+    # after each of its first 64 Adam steps and the step at which each of five re-runs (initial cameras x (1 + 1e-7 / 1e-6 U)) is more than
+    # 1e-4 away from them (oracle/make_golden.py gen_seed_divergence); the kernel's own state after k steps comes from a k-iteration launch.
+    if 'div_ref_cam' in g and any(res[leg]['where'] == 'envelope' for leg in ('host', 'device')):
+        a, b = [int(x) for x in g['div_frames']]
+        ref_traj = g['div_ref_cam']
+        member_steps = sorted(int(g[k]) for k in g.files if k.startswith('div_iter_'))
+        for leg in ('host', 'device'):
+            if res[leg]['where'] != 'envelope':
+                continue
+            model = make_model('glamr_dynamic')
+            if leg == 'host':
+                model.init_data_batch = model.init_data_batch_host
+            first = len(ref_traj) + 1
+            for k in range(1, len(ref_traj) + 1):
+                o = model.optimize(in_dict, latents=lat, max_iters=k)
+                cam = np.concatenate([np.asarray(o['cam_rot_6d']), np.asarray(o['cam_trans'])], axis=1)[a:b]
+                if float(np.abs(cam.astype(np.float64) - ref_traj[k - 1]).max()) > 1e-4:
+                    first = k
+                    break
+            res[leg]['first_divergence'] = first
+            print('seed %d, %s init: leaves the reference trajectory (camera parameters of frames [%d, %d), 1e-4) after step %d; the reference\'s own re-runs after steps %s'
+                  % (seed, leg, a, b, first, member_steps))
+            assert first >= member_steps[0], 'left the reference trajectory at step %d, before any of its own re-runs (%s)' % (first, member_steps)
     for leg in ('host', 'device'):
         r = res[leg]
         assert r['where'] != 'outside', ('%s init: %.3f px from the reference, %d frames > 1 px, nearest member %s at %.3f px; family envelope %.3f px, %d frames'

@@ -384,8 +384,19 @@ def test_range_analysis_selects_the_fp32_kernels_for_a_checkpoint_outside_fp16(a
     rest = (md['J_regressor'].astype(np.float64) @ md['v_template'].astype(np.float64)).astype(np.float32)
     big = {k: v.clone() for k, v in sd['inf'].items()}
     big['context_encoder.temporal_net.layers.0.norm1.weight'] *= 3.0e4           # rows of ~1e5 enter the first feed-forward block: beyond fp16
-    hb = MotionPriorsHandle(big, sd['trj'], rest, synth.SMPL_PARENTS, dev)
+    import logging
+    seen = []
+    handler = logging.Handler()
+    handler.emit = lambda record: seen.append((record.levelno, record.getMessage()))
+    logging.getLogger('glamr_amd').addHandler(handler)
+    try:
+        hb = MotionPriorsHandle(big, sd['trj'], rest, synth.SMPL_PARENTS, dev)
+    finally:
+        logging.getLogger('glamr_amd').removeHandler(handler)
     assert _lib.lib().glamr_nets_precision(hb.h, wc) == 1 and wc[0] > 3e4
+    # the selection is SAID: a warning names the fp32 family and the bound that ruled the fp16 planes out
+    assert hb.fp32_only and hb.precision_bound > 3e4 and not priors.fp32_only
+    assert any(lvl == logging.WARNING and 'plain fp32 kernels' in msg for lvl, msg in seen), seen
     T = 120
     b = {k: torch.tensor(v, device=dev) for k, v in mg.net_inputs(T).items()}
     B = 48                                                                            # 48 x 50 rows >= 2048: the shapes the split kernels would take
