@@ -57,8 +57,11 @@ __global__ __launch_bounds__(MAX_THREADS, GLAMR_GRECON_WAVES_PER_EU) void grecon
   const int si = blockIdx.x;
   // The stage is the pipeline's critical path; the priors' co-schedulable kernels of the other stream (nn_free.hpp) share these SIMDs
   // and have slack: this kernel's waves win the issue arbitration against them (user priority 0..3, the others stay at 0)
-#ifndef GLAMR_GRECON_NO_SETPRIO
-  __builtin_amdgcn_s_setprio(3);
+#ifndef GLAMR_GRECON_PRIO
+#define GLAMR_GRECON_PRIO 3
+#endif
+#if !defined(GLAMR_GRECON_NO_SETPRIO) && GLAMR_GRECON_PRIO > 0
+  __builtin_amdgcn_s_setprio(GLAMR_GRECON_PRIO);
 #endif
   if (threadIdx.x == 0) {
     atomicMin(a.stamps, (unsigned long long)wall_clock64());
@@ -212,7 +215,10 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // mode 1, needs 113 instead of 53 floats per frame and is what a scene that has its CU to itself gets)
   const size_t full_arena = scene_fast_floats(batch->max_persons, batch->max_len, 3) * sizeof(float);
   if (wgs_per_cu > 1 && batch->n_scenes > n_cus) {
-    const size_t share = (size_t)160 * 1024 / wgs_per_cu - 6400;      // 6.2 KB of static LDS per workgroup (scene description, scan scratch)
+    // static LDS per workgroup: the scene description (8 persons ~4 KB, 32 persons ~25 KB in the wide build), the scan scratch, the
+    // stage descriptor and the layout -- taken from the types, so the share is right for both builds
+    const size_t static_lds = sizeof(Scene) + RT_RED_FLOATS * sizeof(float) + sizeof(glamr_stage_desc) + sizeof(glamr_param_layout) + 256;
+    const size_t share = (size_t)160 * 1024 / wgs_per_cu - static_lds;
     if (full_arena <= share && batch->max_len <= threads) LDS_BUDGET = share;
   }
   if (const char* e = std::getenv("GLAMR_GRECON_LDS_KB_RT")) {      // development aid (tools/overlap_probe.py)
@@ -379,18 +385,30 @@ extern "C" int glamr_grecon_last_launch_ns(const void* workspace, double* ns) {
   unsigned long long st[2];
   // the stamps are read on the stream the launch ran on: this waits for the work of THAT stream, not for the device (a pipelined caller
   // keeps its other streams running).  A workspace this library has not seen a launch on falls back to a device-wide wait.
-  hipEvent_t ev = nullptr;
+  // The launch's own completion event: waits for that launch, not for the device.  The table's mutex is HELD across the wait: another thread's
+  // launch on the same workspace (record_launch) or the table's clean-up may destroy the event otherwise, while this thread still waits on it.
+  // (Launches on other workspaces queue behind the mutex for the duration of the wait; the stamps are asked for by measuring code.)
+  bool waited = false;
   {
     std::lock_guard<std::mutex> lock(g_ws_mu);
     auto it = g_ws_event.find(workspace);
-    if (it != g_ws_event.end()) ev = it->second;
+    if (it != g_ws_event.end()) waited = hipEventSynchronize(it->second) == hipSuccess;
   }
-  // the launch's own completion event: waits for that launch, not for the device (a pipelined caller keeps its other streams running)
-  if (!(ev && hipEventSynchronize(ev) == hipSuccess)) {
+  if (!waited) {
     (void)hipGetLastError();
     GLAMR_HIP_CHECK(hipDeviceSynchronize());
   }
-  GLAMR_HIP_CHECK(hipMemcpy(st, workspace, sizeof(st), hipMemcpyDeviceToHost));
+  // the 16 bytes come back on a stream of their own (non-blocking: a plain hipMemcpy goes through the null stream and would wait for every
+  // blocking stream of the process)
+  {
+    static std::mutex cmu;
+    static std::map<int, hipStream_t> copy_streams;
+    std::lock_guard<std::mutex> lock(cmu);
+    hipStream_t& cs = copy_streams[current_device()];
+    if (!cs) GLAMR_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    GLAMR_HIP_CHECK(hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, cs));
+    GLAMR_HIP_CHECK(hipStreamSynchronize(cs));
+  }
   GLAMR_REQUIRE(st[0] != ~0ull, "no stage launch has completed on this workspace");
   *ns = st[1] > st[0] ? (double)(st[1] - st[0]) * 10.0 : 0.0;
   return GLAMR_OK;

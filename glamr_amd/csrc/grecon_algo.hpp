@@ -1704,12 +1704,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
           const float r = a_z.P[0] * FPS;
           if (on(GLAMR_LOSS_LOCAL_Z_REG)) if (last) lsum[GLAMR_LOSS_LOCAL_Z_REG] += r * r;
           const float gz[1] = {s.g_tw[t * 3 + 2] + 2.0f * FPS * r * w_z};
+          GLAMR_MARK(rt, 13);
           if (upd_wd || upd_rot || upd_z) adam_step3(a_wd, gw, a_rot, g6r, a_z, gz, ac);
           if (upd_wd) a_wd.store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.world_dheading + t, gw);
           if (upd_rot) a_rot.store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_rot + e * 6, g6r);
           if (upd_z) a_z.store(s.p, s.m, s.v, sh.store_grad ? s.g : nullptr, lo.local_z + e, gz);
         }
       }
+    GLAMR_MARK(rt, 14);
     if (update) {
       if constexpr (REGB) {
         rt.template scan_regs<NWC, 2>(gxy_r, true, scan_shuffle);

@@ -222,6 +222,7 @@ struct SceneInitArgs {
   float* smpl_pose;            // (slots, T, 69)
   const float* n_pose; const float* n_local; const float* n_trans; const float* n_orient;   // prior outputs, rows [0, n)
   float* scratch;              // (slots, T, 8 + 16)
+  int flags;                   // GLAMR_INIT_* (glamr_init_scenes_ex)
 };
 
 __device__ void person_transform(const float aa[3], const float tr[3], float M[12]) {
@@ -373,6 +374,19 @@ __global__ __launch_bounds__(256) void init_scene_kernel(SceneInitArgs a) {
       rm::quat_mul(q1, base, qi);
       rm::quat_mul(qi, basec, qb);                  // traj_global2local_heading removes the base orientation again
       hh[t] = 2.0f * rm::atan2s(qb[3], qb[0]);
+      // flag_traj_from_cam (get_traj_from_cam :325-351, traj_interp_method 'linear_interp'): the base pose is read off the initial camera --
+      // translation of cam_pose_inv . person_transform_cam, orientation = the interpolated quaternion above.  The frames of the person's
+      // existence range keep the trajectory predictor's pose (written at the top of this kernel; init_traj_heading_from_cam :283-289 overwrites
+      // them in the reference as well), so the flag decides the frames OUTSIDE that range.
+      if ((a.flags & GLAMR_INIT_TRAJ_FROM_CAM) && (t < fs || t >= fs + n)) {
+        float Tc[12], W[12], aa[3];
+        person_transform(b.orient_cam + (o1 + t) * 3, a.trans_cam + (o1 + t) * 3, Tc);
+        mul34(s_caminv, Tc, W);
+        rm::quat_to_aa(qi, aa);
+        float* bo = const_cast<float*>(b.base_orient) + o1 * 3;
+        float* bt = const_cast<float*>(b.base_trans) + o1 * 3;
+        for (int k = 0; k < 3; ++k) { bo[t * 3 + k] = aa[k]; bt[t * 3 + k] = W[k * 4 + 3]; }
+      }
     }
     __syncthreads();
     float* prior = const_cast<float*>(b.traj_local_pred) + o1 * 11;
@@ -482,9 +496,15 @@ extern "C" int glamr_check_inputs(const glamr_raw_batch* raw, const float* cam_K
 
 extern "C" int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
                                  const float* nets_local_traj, const float* nets_trans, const float* nets_orient, void* workspace, void* stream_) {
+  return glamr_init_scenes_ex(batch, pa, nets_pose_out, nets_local_traj, nets_trans, nets_orient, 0, workspace, stream_);
+}
+
+extern "C" int glamr_init_scenes_ex(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
+                                    const float* nets_local_traj, const float* nets_trans, const float* nets_orient, int flags, void* workspace, void* stream_) {
   GLAMR_REQUIRE(batch && pa && nets_pose_out && nets_local_traj && nets_trans && nets_orient && workspace, "null argument");
+  GLAMR_REQUIRE((flags & ~GLAMR_INIT_TRAJ_FROM_CAM) == 0, "unknown flags %d", flags);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  SceneInitArgs a{*batch, pa->trans_cam, pa->smpl_pose, nets_pose_out, nets_local_traj, nets_trans, nets_orient, static_cast<float*>(workspace)};
+  SceneInitArgs a{*batch, pa->trans_cam, pa->smpl_pose, nets_pose_out, nets_local_traj, nets_trans, nets_orient, static_cast<float*>(workspace), flags};
   hipLaunchKernelGGL(init_scene_kernel, dim3(batch->n_scenes), dim3(256), 0, stream, a);
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;

@@ -158,7 +158,10 @@ inline int launch_gemm_free_t(hipStream_t st, const GemmArgs& a) {
 inline int launch_gemm_free(hipStream_t st, const GemmArgs& a) {
   if ((a.x_frag && a.ldx % 16 != 0) || (a.y_frag && (a.ldy % 16 != 0 || (a.R && a.ldr % 16 != 0) || a.ldy < (a.N + 3) / 4 * 4)))
     return fail(GLAMR_E_INVALID, "fragment-major GEMM: ldx=%d / ldy=%d / ldr=%d must be multiples of 16", a.ldx, a.ldy, a.ldr);
-  return launch_gemm_free_t<2, 1, 4>(st, a);
+#ifndef GLAMR_FREE_GEMM_CFG
+#define GLAMR_FREE_GEMM_CFG 2, 1, 4      // development aid: column tiles per wave, k steps of operands ahead, waves per SIMD the allocation aims at
+#endif
+  return launch_gemm_free_t<GLAMR_FREE_GEMM_CFG>(st, a);
 }
 
 // Y[row] = LayerNorm(X[row] (+ R[row])) over 256 columns (add_layernorm_kernel's two-pass arithmetic), all three fragment-major; one wave per

@@ -212,10 +212,13 @@ class GlobalReconOptimizer:
         # A residual that is never applied gets no gradient (its regulariser's is 2 w r = 0 at r = 0) and Adam leaves it at its initial zero: the
         # flag amounts to "no update of traj_local_rot at invisible frames" -- run_schedule then goes launch by launch with that gradient mask
         self.flag_opt_vis_local_rot = bool(g('flag_opt_vis_local_rot', False))
+        if self.flag_opt_vis_local_rot and (g('flag_opt_motion_latent', False) or g('flag_opt_traj_latent', False)):
+            # (run_latent_schedule makes its own iterations and does not apply the gradient mask: refused rather than silently ignored)
+            raise NotImplementedError('flag_opt_vis_local_rot together with the latent-optimisation mode')
         # flag_traj_from_cam (:55,237,325-351): the world trajectory is first read off the initial camera (orientation interpolated between the
         # frames a person is seen in, heading separately).  With a trajectory predictor -- the only mode this path runs -- init_traj_heading_from_cam
         # then overwrites every EXISTING frame (:283-289), so what the flag changes is the base pose of the frames outside a person's existence
-        # range.  Host initialisation only (init_data_batch_host).
+        # range.  Round 5: on the device as well (glamr_init_scenes_ex, GLAMR_INIT_TRAJ_FROM_CAM); init_data_batch_host keeps its numpy twin.
         self.flag_traj_from_cam = bool(g('flag_traj_from_cam', False))
         if self.flag_traj_from_cam and g('traj_interp_method', 'linear_interp') != 'linear_interp':
             raise NotImplementedError("flag_traj_from_cam with traj_interp_method other than 'linear_interp'")
@@ -662,8 +665,6 @@ class GlobalReconOptimizer:
         the 'init' forward pass -- kernel launches only, nothing crosses PCIe.  Returns (datas, packed): `datas` are light
         per-sequence dictionaries that collect() completes from the device arrays."""
         import ctypes
-        if getattr(self, 'flag_traj_from_cam', False):
-            raise NotImplementedError('flag_traj_from_cam is initialised on the host: use optimize() / optimize_batch() (init_data_batch_host)')
         t1 = time.time()
         dev, L = self.device, _lib.lib()
         S, P, T, g = rin.S, rin.P, rin.T, rin.g
@@ -714,8 +715,9 @@ class GlobalReconOptimizer:
         if not early:
             open_gate()
         packed.latents = (meps, teps)                                  # the draws this batch was initialised with (parameters in latent-optimisation mode)
-        _lib.check(L.glamr_init_scenes(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
-                                       _lib.ptr(out['orient']), _lib.ptr(ws), st))
+        # (flag_traj_from_cam :237,325-351: the base pose of the frames outside a person's existence range read off the initial camera)
+        _lib.check(L.glamr_init_scenes_ex(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
+                                          _lib.ptr(out['orient']), 1 if self.flag_traj_from_cam else 0, _lib.ptr(ws), st))
         # root-relative joints of every frame, cached for the whole optimisation
         packed.t['j_local'] = self.smpl.root_relative_joints(pa_t['smpl_pose'].view(-1, 69), pa_t['smpl_beta'].view(-1, 10)).view(n_slots, T, 26, 3)
         # with flag_init_cam_all_frames this pass is only there for the world poses the cameras are initialised from; whoever needs the 'init'
@@ -737,7 +739,7 @@ class GlobalReconOptimizer:
 
     def init_data_batch(self, in_dicts, latents=None, init_forward=True):
         """init_data (:76-248) for a batch of host dictionaries: stage_inputs + init_resident."""
-        if self.cam_fix_frames != [(0, None)] or self.flag_traj_from_cam:
+        if self.cam_fix_frames != [(0, None)]:
             return self.init_data_batch_host(in_dicts, latents)
         return self.init_resident(self.stage_inputs(in_dicts, latents), init_forward=init_forward)
 

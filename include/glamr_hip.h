@@ -418,6 +418,13 @@ int glamr_init_prepare(const glamr_raw_batch* raw, const glamr_scene_batch* batc
 /* After glamr_nets_infer: scatters its outputs, fills traj_local_pred, person2cam, rel_transform_cam, cam_pose of `batch`. */
 int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
                       const float* nets_local_traj, const float* nets_trans, const float* nets_orient, void* workspace, void* stream);
+/* The same with model flags that change the initialisation.  GLAMR_INIT_TRAJ_FROM_CAM = flag_traj_from_cam (global_recon_model.py:55,237,
+ * get_traj_from_cam :325-351 with traj_interp_method 'linear_interp'): the base pose of a person (smpl_orient_world_base / root_trans_world_base,
+ * what the frames outside its existence range keep) is read off the initial camera -- translation of cam_pose_inv . person_transform_cam,
+ * orientation interpolated between the frames the person is seen in, heading separately (interp_orient_q_sep_heading). */
+enum { GLAMR_INIT_TRAJ_FROM_CAM = 1 };
+int glamr_init_scenes_ex(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
+                         const float* nets_local_traj, const float* nets_trans, const float* nets_orient, int flags, void* workspace, void* stream);
 /* init_cam_pose(all_frames=True) (:243-244) from the orient_world / trans_world of the last forward pass. */
 int glamr_init_cam_all_frames(const glamr_scene_batch* batch, void* stream);
 

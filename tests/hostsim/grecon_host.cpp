@@ -37,6 +37,10 @@ struct TraceRT : HostRT {
   }
 };
 
+// absolute_heading is only compiled into the instances of csrc/grecon_wide.hip: this runtime would silently accumulate the headings -- every
+// entry point that takes a stage descriptor refuses it (return code 2; the callers assert 0)
+static bool unsupported(const glamr_stage_desc* st) { return (st->flags & GLAMR_FLAG_ABSOLUTE_HEADING) != 0; }
+
 template <class RT>
 static void run_one(RT& rt, const glamr_scene_batch* b, const glamr_stage_desc* st, const glamr_param_layout& l, Scene& sc, int si) {
   std::vector<float> tab(2 * (size_t)(st->niters > 0 ? st->niters : 1));
@@ -53,6 +57,7 @@ static void run_one(RT& rt, const glamr_scene_batch* b, const glamr_stage_desc* 
 
 // scene 0 only, with the trajectory recorded
 extern "C" int hostsim_grecon_trace_stage(const glamr_scene_batch* b, const glamr_stage_desc* st, float* grads_scratch, float* params_trace, float* grads_trace) {
+  if (unsupported(st)) return 2;
   glamr_param_layout l;
   param_layout(b->max_persons, b->max_len, l);
   std::vector<float> ws(scene_workspace_floats(b->max_persons, b->max_len));
@@ -70,6 +75,7 @@ extern "C" int hostsim_grecon_param_layout(int max_persons, int max_len, glamr_p
 }
 
 extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_stage_desc* st, float* grads_out) {
+  if (unsupported(st)) return 2;
   glamr_param_layout l;
   param_layout(b->max_persons, b->max_len, l);
   std::vector<float> ws(scene_workspace_floats(b->max_persons, b->max_len));
@@ -86,6 +92,7 @@ extern "C" int hostsim_grecon_run_stage(const glamr_scene_batch* b, const glamr_
 // constant-layout instance (arena / workspace laid out for GLAMR_CONST_LAYOUT_FRAMES frames, on-chip parameter blocks in that layout).
 // Must give the results of hostsim_grecon_run_stage to the bit: same arithmetic, different addresses.
 extern "C" int hostsim_grecon_run_stage_arena(const glamr_scene_batch* b, const glamr_stage_desc* st, int const_layout) {
+  if (unsupported(st)) return 2;
   if (b->max_persons != 1) return -1;
   constexpr int CL = GLAMR_CONST_LAYOUT_FRAMES;
   if (const_layout && layout_frames(1, b->max_len) != CL) return -2;
@@ -116,6 +123,7 @@ extern "C" int hostsim_grecon_run_stage_arena(const glamr_scene_batch* b, const 
 // The full-arena single-person instance (parameters + Adam moments in the "on-chip" arena) WITH the gradient record: what a stage driven
 // launch by launch from outside runs on the device for one-person scenes (latent-optimisation mode, GLAMR_FLAG_KEEP_CAM_PARAMS).
 extern "C" int hostsim_grecon_run_stage_arena_grads(const glamr_scene_batch* b, const glamr_stage_desc* st, float* grads_out) {
+  if (unsupported(st)) return 2;
   if (b->max_persons != 1) return -1;
   glamr_param_layout l;
   param_layout(1, b->max_len, l);

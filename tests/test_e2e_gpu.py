@@ -128,14 +128,18 @@ def test_flag_traj_from_cam_matches_the_reference(make_model, golden):
     seed = mg.FLAG_SEED[tag]
     in_dict = synth.trim_person(synth.make_in_dict(seed=seed, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model()), *trim)
     lat = mg.latents_for(in_dict, seed)
-    data = model.init_data(in_dict, latents=lat)
+    data = model.init_data(in_dict, latents=lat)                      # round 5: init_data on the DEVICE (glamr_init_scenes_ex)
+    host = model_dict['global_recon_model'](cfg, base.device, None, smpl=base.smpl, mt_model=base.mt_model)
+    host.init_data_batch = host.init_data_batch_host                  # ... and its numpy twin
+    data_host = host.init_data(in_dict, latents=lat)
     plain = base.init_data(in_dict, latents=lat)
     outside = ~g['init_p1_exist_frames']
     assert outside.sum() > 20
-    for pi in range(P):
-        pd = data['person_data'][pi]
-        assert _rot_err(pd['smpl_orient_world'], g['init_p%d_smpl_orient_world' % pi]) < 3e-4
-        assert np.abs(np.asarray(pd['root_trans_world'], np.float64) - g['init_p%d_root_trans_world' % pi]).max() < 3e-4
+    for d in (data, data_host):
+        for pi in range(P):
+            pd = d['person_data'][pi]
+            assert _rot_err(pd['smpl_orient_world'], g['init_p%d_smpl_orient_world' % pi]) < 3e-4
+            assert np.abs(np.asarray(pd['root_trans_world'], np.float64) - g['init_p%d_root_trans_world' % pi]).max() < 3e-4
     # the flag matters on this input: the default initialisation leaves other orientations outside the existence range
     assert _rot_err(np.asarray(plain['person_data'][1]['smpl_orient_world'])[outside], g['init_p1_smpl_orient_world'][outside]) > 1e-2
     out = model.optimize(in_dict, latents=lat, max_iters=K)
@@ -148,8 +152,11 @@ def test_flag_traj_from_cam_matches_the_reference(make_model, golden):
         worst[2] = max(worst[2], _rot_err(pd['smpl_orient_world'], g['opt_p%d_smpl_orient_world' % pi]))
     print('flag_traj_from_cam, %d iterations per stage: kp %.4f px, root_trans_world %.2e m, smpl_orient_world %.2e (all frames, those outside the existence range included)' % (K, *worst))
     assert worst[0] < 0.05 and worst[1] < 2e-4 and worst[2] < 1.5e-3          # achieved 0.013 px / 5.0e-5 m / 3.8e-4
-    with pytest.raises(NotImplementedError):
-        model.optimize_resident(model.stage_inputs([in_dict]))
+    # ... and HBM in -> HBM out (optimize_resident raised NotImplementedError for this flag until round 5)
+    datas, packed = model.optimize_resident(model.stage_inputs([in_dict], [lat]), max_iters=K)
+    res = model.collect(datas, packed)[0]
+    for pi in range(P):
+        assert float(np.abs(np.asarray(res['person_data'][pi]['kp_2d_pred']) - np.asarray(out['person_data'][pi]['kp_2d_pred'])).max()) == 0.0
 
 
 @pytest.mark.parametrize('case', [c for c in mg.FLAG_CASES if c[0] == 'absolute_heading'], ids=lambda c: '%s-%d-%d' % (c[1], c[2], c[3]))
@@ -343,7 +350,7 @@ def test_full_schedule_detection_gap_multi_seed(make_model, golden, seed):
     if 'div_ref_cam' in g and any(res[leg]['where'] == 'envelope' for leg in ('host', 'device')):
         a, b = [int(x) for x in g['div_frames']]
         ref_traj = g['div_ref_cam']
-        member_steps = sorted(int(g[k]) for k in g.files if k.startswith('div_iter_'))
+        member_steps = sorted(int(g[k]) for k in g if k.startswith('div_iter_'))
         for leg in ('host', 'device'):
             if res[leg]['where'] != 'envelope':
                 continue

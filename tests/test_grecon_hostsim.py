@@ -104,3 +104,31 @@ def test_full_schedules_of_the_other_configs_follow_the_reference(asset_root, go
         print('%s %s: kp %.4f px, root in camera %.2e m, world root %.2e m, orientation %.2e' % (cfg_id, stage, w['kp'], w['root_cam'], w['root_world'], w['orient']))
         tol_kp, tol_root = gc.FULL_TOL_CPU[(cfg_id, gap)]
         assert w['kp'] < tol_kp and w['root_cam'] < tol_root and w['frames_over_1px'] == 0, (stage, w)
+
+
+def test_cpu_runtime_refuses_the_absolute_heading_flag(asset_root):
+    """GLAMR_FLAG_ABSOLUTE_HEADING is only compiled into the instances of csrc/grecon_wide.hip (absolute_heading, global_recon_model.py:59,283,421):
+    the CPU test runtime must say so instead of silently accumulating the headings."""
+    import ctypes
+    import torch
+    from glamr_amd import _lib
+    from glamr_amd.global_recon import packing
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.utils import synth
+    from oracle.port import build
+    from oracle import make_golden as mg
+    from tests import hostsim
+    from tests.grecon_common import j_local_from_oracle
+    cfg = get_config('glamr_dynamic')
+    in_dict = synth.make_in_dict(seed=3, num_frames=60, num_persons=1, smpl_model=synth.make_smpl_model())
+    ora = build.load_optimizer(asset_root, cfg)
+    data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 3))
+    packed = packing.PackedScenes([data], [j_local_from_oracle(ora.smpl, data)], torch.device('cpu'))
+    sd = packing.stage_desc(next(iter(cfg['opt_stage_specs'].values())), cfg['grecon_model_specs'], False, niters=1)
+    lib = hostsim.build('grecon_host')
+    fn = lib.hostsim_grecon_run_stage
+    fn.argtypes = [ctypes.POINTER(_lib.SceneBatch), ctypes.POINTER(_lib.StageDesc), ctypes.c_void_p]
+    sb = packed.struct()
+    assert fn(ctypes.byref(sb), ctypes.byref(sd), None) == 0
+    sd.flags |= packing.FLAG_ABSOLUTE_HEADING
+    assert fn(ctypes.byref(sb), ctypes.byref(sd), None) == 2

@@ -16,7 +16,7 @@ from tests.grecon_common import j_local_from_oracle
 
 NAMES = ['A heading + scan + barrier', 'B displacement + scan', 'C/D world pose, camera + barrier', 'camera from persons', 'E5 own-camera backward + Adam',
          'G shared-camera gradients', 'H orientation reverse + scan + barrier', 'I displacement reverse + scan', 'J heading reverse (+ loss reduce)',
-         'E1 loads, camera-relative orientation', 'E2 keypoints', 'E3 smoothness, relative transforms, fold', 'E4 camera smoothness terms', '-', '-', '-']
+         'E1 loads, camera-relative orientation', 'E2 keypoints', 'E3 smoothness, relative transforms, fold', 'E4 camera smoothness terms', 'H1 loads, orientation reverse (up to the updates)', 'H2 eight Adam updates + stores', '-']
 dev = torch.device('cuda:0')
 root = build.ensure_synthetic_assets('/tmp/glamr_bench_assets')
 cfg_id = sys.argv[2] if len(sys.argv) > 2 else 'glamr_dynamic'
