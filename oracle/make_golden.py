@@ -512,6 +512,9 @@ def gen_full(which=('gap', 'nogap')):
 LATENT_CASES = [('glamr_dynamic', 100, 1, 12), ('glamr_static', 130, 1, 8), ('glamr_dynamic_multi', 90, 2, 5)]      # (two persons: ADVICE r3)
 # The two-person case has NO detection gap: with per-frame cameras the frames the first person is not seen in start as zero cameras, and there
 # not even the reference reproduces itself -- person 1's projections in those frames differed by 200 px after ten iterations.
+# Round 5 measured it (gen_grecon_latent_gapfamily -> grecon_latent_glamr_dynamic_multi_T90_P2_gapfamily.npz): the unmodified reference's own
+# re-runs on the input WITH the gap end 57 - 124 px from its result in 4 - 10 of those twenty frames and within 0.001 px everywhere else;
+# tests/test_latent_gpu.py::test_latent_mode_with_detection_gaps_stays_inside_the_reference_family holds the device to both regimes.
 LATENT_GAP = {('glamr_dynamic_multi', 90, 2): (0, 0)}
 
 
@@ -572,6 +575,66 @@ def gen_grecon_latent(cases=LATENT_CASES):
         out['niters'] = np.array(K)
         np.savez_compressed(os.path.join(GOLD, 'grecon_latent_%s_T%d_P%d.npz' % (cfg_id, T, P)), **out)
         print('wrote latent case', cfg_id, T, P, {k: float(np.abs(v).max()) for k, v in out.items() if '_grad_' in k})
+
+
+LATENT_GAP_FAMILY = [('threads3', dict(threads=3)), ('eps1e-7_seed0', dict(eps=1e-7, seed=0)), ('eps1e-7_seed1', dict(eps=1e-7, seed=1)),
+                     ('eps1e-6_seed0', dict(eps=1e-6, seed=0))]
+
+
+def gen_grecon_latent_gapfamily(case=('glamr_dynamic_multi', 90, 2, 5)):
+    """VERDICT r4 item 3c.  The two-person latent-mode fixture has no detection gap because WITH the gap (person 0 undetected in [40, 60),
+    person 1 in [77, 97) -> its frames there start as zero cameras) the first version of the test failed by 200 px -- and round 4 argued, by
+    analogy with the full schedules, that the reference does not reproduce itself there either.  This makes it a measurement: the unmodified
+    reference in latent mode on the input WITH the gap, K iterations per stage, and four re-runs of it (3 threads; initial cam_pose x
+    (1 + 1e-7 / 1e-6 U)).  tests/test_latent_gpu.py holds the device to the family's envelope."""
+    import time
+    from oracle import ref_harness as rh
+    from glamr_amd.utils import synth
+    md = synth.make_smpl_model()
+    cfg_id, T, P, K = case
+    out = {}
+    for name, opt in [('', {})] + LATENT_GAP_FAMILY:
+        keep_threads = torch.get_num_threads()
+        torch.set_num_threads(opt.get('threads', keep_threads))
+        t0 = time.time()
+        try:
+            model, cfg = rh.reference_optimizer(cfg_id, log=rh.QuietLog())
+            model.flag_opt_motion_latent = model.flag_opt_traj_latent = True
+            in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=md)          # default gaps
+            latents = latents_for(in_dict, 3)
+            mt = model.mt_model
+            order = iter(sorted(latents.keys()))
+            state = {}
+
+            def motion_latent(seq_len, order=order, state=state, latents=latents):
+                state['idx'] = next(order)
+                return torch.tensor(latents[state['idx']]['motion'])
+
+            def traj_latent(seq_len, state=state, latents=latents):
+                return torch.tensor(latents[state['idx']]['traj'])
+            mt.get_motion_latent, mt.get_traj_latent = motion_latent, traj_latent
+            data = model.init_data(in_dict)
+            if opt.get('eps'):
+                rng = np.random.RandomState(opt['seed'])
+                cp = data['cam_pose']
+                cp.mul_(torch.from_numpy((1 + opt['eps'] * rng.uniform(-1, 1, tuple(cp.shape))).astype(np.float32)))
+            for stage, spec in cfg.opt_stage_specs.items():
+                meta = {'stage': stage, 'opt_latent_start_iter': spec.get('opt_latent_start_iter', 0)}
+                model.optimize_main(data, spec['opt_variables'], spec['opt_lr'], min(K, spec['opt_niters']), spec['loss_cfg'], meta)
+        finally:
+            torch.set_num_threads(keep_threads)
+        st = _flatten_state(data, ['kp_2d_pred', 'motion_latent', 'vis_frames', 'root_trans_world'], [])
+        pre = 'fam_%s_' % name if name else ''
+        for k, v in st.items():
+            out[pre + k] = v
+        if name:
+            d = max(float(np.abs(st['p%d_kp_2d_pred' % pi] - out['p%d_kp_2d_pred' % pi])[out['p%d_vis_frames' % pi]].max()) for pi in range(P))
+            dl = max(float(np.abs(st['p%d_motion_latent' % pi] - out['p%d_motion_latent' % pi]).max()) for pi in range(P))
+            print('latent mode with the gap, re-run %-14s %.0f s: projections %.3f px, motion latent %.2e from the reference\'s own result' % (name, time.time() - t0, d, dl), flush=True)
+        else:
+            print('latent mode with the gap: reference %.0f s' % (time.time() - t0), flush=True)
+    out['niters'] = np.array(K)
+    np.savez_compressed(os.path.join(GOLD, 'grecon_latent_%s_T%d_P%d_gapfamily.npz' % (cfg_id, T, P)), **out)
 
 
 FULL_CASES = [('glamr_3dpw', 300, 1, 4), ('glamr_dynamic_multi', 300, 2, 3), ('glamr_static_multi', 300, 4, 38), ('glamr_static', 300, 1, 4),
@@ -1036,7 +1099,7 @@ def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     todo = argv or ['smpl', 'geom', 'nets', 'nets_train', 'grecon', 'full', 'eval']
     for name in todo:
-        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'grecon_family': gen_grecon_family, 'grecon_flags': gen_grecon_flags, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'seed_divergence': gen_seed_divergence, 'seed1_more': gen_seed1_more, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
+        {'smpl': gen_smpl, 'geom': gen_geom, 'nets': gen_nets, 'nets_train': gen_nets_train, 'nets_latent': gen_nets_latent, 'grecon_latent': gen_grecon_latent, 'grecon_latent_p2': lambda: gen_grecon_latent(LATENT_CASES[2:]), 'grecon': gen_grecon, 'grecon_c4': lambda: gen_grecon(GRECON_CASES[-1:]), 'grecon_wide': lambda: gen_grecon(GRECON_CASES_WIDE), 'grecon_family': gen_grecon_family, 'grecon_flags': gen_grecon_flags, 'full': gen_full, 'full_nogap': lambda: gen_full(('nogap',)), 'full_family': gen_full_family, 'full_seeds': gen_full_seeds, 'full_seeds_wide': lambda: gen_full_seeds(WIDE_FAMILY_SEEDS), 'full_seeds_traj': gen_seed_traj_family, 'seed_divergence': gen_seed_divergence, 'latent_gapfamily': gen_grecon_latent_gapfamily, 'seed1_more': gen_seed1_more, 'filter': gen_filter, 'full_cfg': gen_full_cfg, 'full_family_cfg': gen_full_family_cfg, 'full_family_h36m': lambda: gen_full_family_cfg('glamr_h36m', 300, 2, False, FAMILY_CFG[:2]), 'eval': gen_eval}[name]()
         print('done', name)
 
 

@@ -112,3 +112,46 @@ def test_shipped_configs_are_unaffected_and_flags_are_read(make_model):
     m = make_model('glamr_dynamic')
     assert not m.latent_mode
     assert make_model('glamr_dynamic', flag_opt_motion_latent=True).latent_mode and make_model('glamr_dynamic', flag_opt_traj_latent=True).latent_mode
+
+
+def test_latent_mode_with_detection_gaps_stays_inside_the_reference_family(make_model, golden):
+    """VERDICT r4 item 3c.  Two persons, per-frame cameras, latent mode, WITH the detection gaps: person 0 is undetected in [40, 60), and the
+    initial camera of a frame comes from person 0 alone (init_cam_pose :294-317), so those twenty frames start as ZERO cameras whose first Adam
+    steps are +-lr by the sign of 1e10-sized gradients and wake up one frame per iteration from both ends.  Person 1 IS seen in
+    them.  The unmodified reference re-run with 3 threads or with its initial cameras x (1 + 1e-7 / 1e-6 U) ends 57 - 124 px from its own
+    result there after five iterations per stage -- in 4 to 10 of the twenty frames -- and within 1 px everywhere else (oracle/make_golden.py
+    gen_grecon_latent_gapfamily).  Round 4 replaced this input by one without the gap; this case keeps it and separates the two regimes:
+    OUTSIDE the zero-camera frames the device is held to the usual bounds of the mode (0.1 px), INSIDE them to the scale of the reference's
+    own re-runs (twice the farthest one); the motion latent, which feels those frames through person 1's reprojection, to five times the
+    re-runs' spread (they differ in up to 10 of the 20 frames, the device -- whose rounding differs everywhere, not in the seventh digit of
+    the non-zero cameras only -- in all 20)."""
+    cfg_id, T, P, K = 'glamr_dynamic_multi', 90, 2, 5
+    g = golden('grecon_latent_%s_T%d_P%d_gapfamily' % (cfg_id, T, P))
+    members = sorted({k[4:].split('_p0_')[0] for k in g if k.startswith('fam_') and '_p0_kp_2d_pred' in k})
+    assert len(members) >= 4
+    in_dict = synth.make_in_dict(seed=3, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model())
+    lat = mg.latents_for(in_dict, 3)
+    model = make_model(cfg_id, flag_opt_motion_latent=True, flag_opt_traj_latent=True)
+    out = model.optimize(in_dict, latents=lat, max_iters=K)
+    zero_cam = ~g['p0_vis_frames']                                    # frames whose initial camera is a zero matrix
+    assert zero_cam.sum() == 20
+    rng = lambda m: (lambda idx: '%d..%d (%d)' % (idx[0], idx[-1], len(idx)) if len(idx) else '-')(np.nonzero(m)[0])
+    for pi in range(P):
+        vis = g['p%d_vis_frames' % pi]
+        ref_kp, ref_lat = g['p%d_kp_2d_pred' % pi], g['p%d_motion_latent' % pi]
+        per_frame = lambda kp: np.abs(np.asarray(kp, np.float64) - ref_kp).max(axis=(1, 2))
+        fam = np.stack([per_frame(g['fam_%s_p%d_kp_2d_pred' % (m, pi)]) for m in members])          # (members, frames)
+        fam_lat = max(float(np.abs(g['fam_%s_p%d_motion_latent' % (m, pi)] - ref_lat).max()) for m in members)
+        pd = out['person_data'][pi]
+        d = per_frame(pd['kp_2d_pred'])
+        e_lat = float(np.abs(pd['motion_latent'] - ref_lat).max())
+        calm, wild = vis & ~zero_cam, vis & zero_cam
+        print('latent mode with gaps, person %d: outside the zero-camera frames %.4f px from the reference (its re-runs: %s px); inside them %.1f px in %s '
+              '(re-runs: %s); motion latent %.2e (re-runs up to %.2e)'
+              % (pi, d[calm].max(), ', '.join('%.3f' % f[calm].max() for f in fam), d[wild].max() if wild.any() else 0.0, rng(wild & (d > 1)),
+                 ' | '.join('%.0f px in %s' % (f[wild].max() if wild.any() else 0.0, rng(wild & (f > 1))) for f in fam), e_lat, fam_lat))
+        assert fam[:, calm].max() < 1.0                               # the fixture itself: the reference agrees with its re-runs outside those frames
+        assert d[calm].max() < 0.1
+        if wild.any():
+            assert d[wild].max() <= 2.0 * fam[:, wild].max() + 0.5
+        assert e_lat <= 5.0 * fam_lat + 1e-5
