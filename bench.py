@@ -674,7 +674,10 @@ def run(argv=None):
                        'sequences_per_gpu': B, 'frames': NUM_FRAMES, 'persons': 1, 'parallelism': 'sequence-sharded x%d' % world,
                        'streams_per_gpu': len(streams), 'step_graph': bool(step_graphs), 'coscheduled_streams': bool(coschedule)},
             'roofline': {'kernel': 'grecon_stage_kernel<1,true,1,304>', 'bound': 'latency/issue',
-                         'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration, bound by the dependent chain of one wave (3, 4 or 5 waves per scene take the same time: profiles/r04_stage_iteration_vs_waves.log): neither HBM nor the matrix pipes limit it. '
+                         'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration; neither HBM nor the matrix pipes limit it.  Round 5 removed the exposed '
+                                       'memory waits of the dependent chain (13.3 -> 10.6 us per scene-iteration, profiles/r05_stage_ab.log); what bounds it now is ISSUE on the SIMD that '
+                                       'carries two of a 300-frame scene\'s five waves: the fifth wave leaves the keypoint phase 1.1 us after the other four, which wait for it at the '
+                                       'next barrier (profiles/r05_phase_times.log). '
                                        'achieved / peak / frac are SURVEY 8(d) K5\'s yardstick: microseconds per scene-iteration against the 1.45 us dependent-boundary floor '
                                        "(frac = floor / achieved).  The contract's hbm line is kept under `contract_notional` and is NOTIONAL",
                          'achieved': us_scene_iter, 'peak': DEPENDENT_BOUNDARY_US, 'unit': 'us per scene-iteration (lower is better; peak = dependent-boundary floor)',
@@ -698,6 +701,10 @@ def run(argv=None):
                          'note': 'traffic = memory-side bytes of one launch (rocprofv3 PMC passes on the shipped instance)'},
             'pipeline': None if not coschedule else {
                 'coscheduled_streams': True, 'stage_launch_ms_alone': k_avg, 'stage_launch_ms_beside_the_priors': beside,
+                'critical_cycle': 'round 5: with the stage launch at 27 ms beside the priors the step is no longer stage + gap: the gate serialises the PRIORS of '
+                                  'consecutive batches (a batch\'s infiller takes 29 ms beside the other batch\'s stage, its predictor 6 ms, then the scene assembly / skinning 3.5 ms: '
+                                  'profiles/r05_chain_trace.log), and that chain is the period.  Measured and without effect: stage priority 0 / 1 / 3, a third stream, the gate opened '
+                                  'after the infiller, more waves per SIMD for the LDS-free GEMM (profiles/r05_pipeline_experiments.log)',
                 'note': 'two streams, batches staggered by GlobalReconOptimizer.pipeline_gate: a batch starts when the previous one\'s priors are done, so its '
                         'motion infiller -- LDS-free one-wave kernels on fragment-major activations (csrc/nn_free.hpp) -- runs in the SIMD issue slots and '
                         'matrix pipes a resident stage workgroup leaves idle.  The stage launch is slower beside them than alone; the step is shorter '
