@@ -152,9 +152,19 @@ struct DeviceRT {
 #if !defined(GLAMR_EXP_NOSYNC) || GLAMR_EXP_NOSYNC < 2
       __syncthreads();
 #endif
+      // the wave totals of every channel are fetched with two vector reads per channel, all issued before the first is used (a workgroup has at
+      // most 8 waves): walking them one ds_read at a time was up to 8 dependent LDS round trips per channel.  Same additions in the same order.
       for (int c = 0; c < nch; ++c) {
+        const float4 ta = *reinterpret_cast<const float4*>(r + c * 16), tb = *reinterpret_cast<const float4*>(r + c * 16 + 4);
+        const float t8[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         float pre = carry[c], tot = 0.f;
-        for (int w = 0; w < nw; ++w) { const float t = r[c * 16 + w]; tot += t; if (reverse ? (w > wave) : (w < wave)) pre += t; }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          if (w >= nw) break;
+          const float t = t8[w];
+          tot += t;
+          if (reverse ? (w > wave) : (w < wave)) pre += t;
+        }
         if (i < n) elem<LDS>(ch[c], idx) = x[c] + pre;
         carry[c] += tot;
       }

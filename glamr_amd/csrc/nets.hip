@@ -319,7 +319,7 @@ __global__ void masked_mean_kernel(const float* ctx, int max_len, const int* len
 // local trajectory -> global translation / orientation for one sequence per workgroup (traj_utils.py:65-88 + quat->aa)
 __global__ __launch_bounds__(256) void traj_to_global_kernel(const float* raw, int ldraw, int max_len, const int* lens, float* local, float* trans,
                                                              float* orient, float* scratch) {
-  __shared__ float red[RT_RED_FLOATS];
+  __shared__ __attribute__((aligned(16))) float red[RT_RED_FLOATS];
   DeviceRT rt{red};
   const int b = blockIdx.x, n = lens[b];
   float* L = local + (size_t)b * max_len * 11;
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256) void traj_prepare_kernel(const float* trans, c
 // init_xy / local_traj_tp[0] in train and recon modes, zeros and (0, 1) in inference); also the quaternion output
 __global__ __launch_bounds__(256) void traj_to_global2_kernel(const float* raw, int ldraw, int max_len, const int* lens, const float* init, int ldinit, int fix_first,
                                                               float* local, float* trans, float* orient, float* orient_q, float* scratch) {
-  __shared__ float red[RT_RED_FLOATS];
+  __shared__ __attribute__((aligned(16))) float red[RT_RED_FLOATS];
   DeviceRT rt{red};
   const int b = blockIdx.x, n = lens[b];
   float* L = local + (size_t)b * max_len * 11;
