@@ -1102,6 +1102,13 @@ int enqueue_infer(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, int 
   // chain stops at the first LSTM launch until the other stream's stage has retired: everything BEFORE it stays co-schedulable (it runs in
   // the slack the infiller leaves beside the stage), everything from it on takes the LDS kernels, the faster ones on an empty GPU (traj_pass).
   struct Restore { int v; ~Restore() { tl_free = v; } } restore{tl_free};
+  // Round 5: the WHOLE predictor on the LDS kernels, also what precedes its first recurrence (forward kinematics, input MLP, first input
+  // projection: 1.9 ms on the LDS-free kernels, 1.2 on these).  Rounds 3 - 4 kept that prefix co-schedulable to use the slack beside the other
+  // stream's stage; with the stage launch (27 ms beside the priors) now shorter than the infiller beside it (29 ms) the prefix starts when the
+  // stage has just retired and finds an empty GPU: 37.9 -> 37.2 ms per step, alternated twice on one box (profiles/r05_pipeline_experiments.log).
+  // GLAMR_NETS_TRAJ_LDS=0 restores the co-schedulable prefix (for workloads whose stage outlasts the infiller).
+  static const bool traj_lds = [] { const char* e = std::getenv("GLAMR_NETS_TRAJ_LDS"); return !(e && e[0] == '0'); }();
+  if (traj_lds) tl_free = 0;
   if (tl_free) {
     hipLaunchKernelGGL(fk_joints_free_kernel, dim3(B, (max_len + 1) / 2), dim3(64), 0, st, w.pose, w.Tpad, max_len, w.lens, h->rest_joints, h->parents, w.tx);
     return traj_pass(h, st, w, B, max_len, w.lens, GLAMR_VAE_INFER, traj_eps, nullptr, nullptr, nullptr, 0, nullptr, out_local_traj, out_trans, out_orient, nullptr);
