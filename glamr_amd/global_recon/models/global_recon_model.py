@@ -709,17 +709,23 @@ class GlobalReconOptimizer:
             elif gate is not None and not torch.cuda.is_current_stream_capturing():
                 gate.after(torch.cuda.current_stream(dev))
         # the next batch may start when this batch's priors are done -- or (GLAMR_GATE_AFTER=infiller) already when its infiller is
-        early = gate is not None and os.environ.get('GLAMR_GATE_AFTER', 'priors') == 'infiller'
+        # (development aid GLAMR_GATE_AFTER: 'infiller' / 'priors' (default) / 'scene' / 'skin' / 'forward' -- later = the rest of this batch's
+        # preparation runs without the next batch's first kernels beside it, but that batch starts later: profiles/r05_pipeline_experiments.log)
+        gate_at = os.environ.get('GLAMR_GATE_AFTER', 'priors') if gate is not None else 'priors'
         out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps, buffers=rs, coschedule=gate is not None,
-                                         between=open_gate if early else None)
-        if not early:
+                                         between=open_gate if gate_at == 'infiller' else None)
+        if gate_at == 'priors':
             open_gate()
         packed.latents = (meps, teps)                                  # the draws this batch was initialised with (parameters in latent-optimisation mode)
         # (flag_traj_from_cam :237,325-351: the base pose of the frames outside a person's existence range read off the initial camera)
         _lib.check(L.glamr_init_scenes_ex(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
                                           _lib.ptr(out['orient']), 1 if self.flag_traj_from_cam else 0, _lib.ptr(ws), st))
+        if gate_at == 'scene':
+            open_gate()
         # root-relative joints of every frame, cached for the whole optimisation
         packed.t['j_local'] = self.smpl.root_relative_joints(pa_t['smpl_pose'].view(-1, 69), pa_t['smpl_beta'].view(-1, 10)).view(n_slots, T, 26, 3)
+        if gate_at == 'skin':
+            open_gate()
         # with flag_init_cam_all_frames this pass is only there for the world poses the cameras are initialised from; whoever needs the 'init'
         # outputs gets them from the second pass (init_forward), or from the first stage's last evaluation
         self._run(packed, self._forward_only_desc(poses_only=self.flag_init_cam_all_frames or not init_forward))
@@ -730,6 +736,8 @@ class GlobalReconOptimizer:
             # values); a caller that runs the schedule right away overwrites every one of them with the first stage's last evaluation
             if init_forward:
                 self._run(packed, self._forward_only_desc())
+        if gate_at == 'forward':
+            open_gate()
         packed.person_arrays = pa_t
         packed.exists = rin.exists
         packed.keepalive = (rin, ws, out)
