@@ -17,6 +17,7 @@
 //   Y^T = W X^T :  A = weight fragment (lane = output column), B = row fragment straight from global memory (lane = row),
 // so that a lane's accumulator registers are 4 CONSECUTIVE output columns of ONE row (16-byte stores, no transposition through LDS).
 #pragma once
+#include <type_traits>
 #include "nn_kernels.hpp"
 
 namespace glamr {
@@ -114,6 +115,9 @@ __global__ __launch_bounds__(64, MAXW) void gemm_free_kernel(GemmArgs a) {
   // epilogue: register q of tile j = output column n0 + 32 j + 8 (q >> 2) + 4 kg + (q & 3) of row m0 + c
   if (row >= a.M) return;
   const int rbrow = a.rowbias ? (a.rows_per_group > 0 ? row / a.rows_per_group : row % (-a.rows_per_group)) : 0;
+  // (Round 5 measured a straight-line copy of this epilogue per combination of the uniform options -- 183 branches and ~1 400 of the kernel's
+  // 2 270 instructions are epilogue: the infiller got faster and the STEP SLOWER, 36.6 -> 36.8 - 37.3 ms: a faster infiller takes more of the
+  // issue slots of the resident stage, and the stage's chain is the pipeline's critical one.  profiles/r05_pipeline_experiments.log.)
 #pragma unroll
   for (int j = 0; j < C; ++j)
 #pragma unroll

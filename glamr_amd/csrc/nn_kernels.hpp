@@ -217,7 +217,50 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
           for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[PA[term]][i], xb[PB[term]][j], acc[i][j], 0, 0, 0);
     }
   }
-  // epilogue: lane owns column n, rows (q & 3) + 8 (q >> 2) + 4 kh of each accumulator tile
+  // epilogue: lane owns column n, rows (q & 3) + 8 (q >> 2) + 4 kh of each accumulator tile.
+  // Round 5: a full 128-row tile leaves through straight-line code, one copy per combination of the three uniform options.  The general loop
+  // below decides four uniform conditions PER ELEMENT (64 elements per lane: ~250 scalar branches, an integer division per element for the
+  // per-row bias, 64-bit address chains -- ~6 000 of the kernel's 6 500 instructions against ~1 100 executed in the k loop: the matrix pipe sat
+  // at 14 - 22 %); it stays for the last, partial row block.  Same operations per element in the same order.
+  const bool full_tile = m0 + 128 <= a.M;
+  if (full_tile) {
+    // one straight-line copy per combination of the three uniform options (per-row bias, ReLU, residual), chosen once
+    auto emit = [&](auto has_rb, auto relu, auto has_r) {
+      const size_t ld = (size_t)a.ldy;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = n0 + (wn * WN + j) * 32 + r;
+        if (n >= a.N) continue;                      // (per lane, decided once per column tile)
+        const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int mb = m0 + (wm * 2 + i) * 32 + 4 * kh;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int m = mb + (q & 3) + 8 * (q >> 2);
+            float v = acc[i][j][q] + b;
+            if (decltype(has_rb)::value) v += a.rowbias[(size_t)(a.rows_per_group > 0 ? m / a.rows_per_group : m % (-a.rows_per_group)) * a.ldrb + n];
+            if (decltype(relu)::value) v = fmaxf(v, 0.0f);
+            if (decltype(has_r)::value) v += a.R[(size_t)m * a.ldr + n];
+            a.Y[(size_t)m * ld + n] = v;
+          }
+        }
+      }
+    };
+    using T = std::true_type; using F = std::false_type;
+    const int sel = (a.rowbias ? 4 : 0) | (a.act == ACT_RELU ? 2 : 0) | (a.R ? 1 : 0);
+    switch (sel) {
+      case 0: emit(F{}, F{}, F{}); break;
+      case 1: emit(F{}, F{}, T{}); break;
+      case 2: emit(F{}, T{}, F{}); break;
+      case 3: emit(F{}, T{}, T{}); break;
+      case 4: emit(T{}, F{}, F{}); break;
+      case 5: emit(T{}, F{}, T{}); break;
+      case 6: emit(T{}, T{}, F{}); break;
+      default: emit(T{}, T{}, T{}); break;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int n = n0 + (wn * WN + j) * 32 + r;
