@@ -837,10 +837,14 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   auto active = [&](int id) { return ((st.loss_mask >> id) & 1u) && !((st.monitor_mask >> id) & 1u); };
   auto ffo = [&](int id) { return (st.first_frame_only_mask >> id) & 1u; };
 
-  setup_tables(rt, sc);
+  // A forward pass that is only there for the world poses (GLAMR_FLAG_POSES_ONLY: init_data's pass before init_cam_pose(all_frames), the first
+  // launch of every iteration of the launch-by-launch schedules) stops after phase D: it needs neither the visibility tables nor the
+  // normalisers nor the per-joint score sums -- 0.40 -> 0.2 ms of a launch that sits on the pipeline's critical chain (round 5).
+  const bool poses_only = st.niters == 0 && (st.flags & GLAMR_FLAG_POSES_ONLY) && !cam_from_person;
+  if (!poses_only) setup_tables(rt, sc);
   // ---- stage setup: normalisers, Adam state, camera parameters from the current camera (get_parameter :596-606) ----------
   float n_vis_total = 0.f, n_exist = 0.f, n_exist_m1 = 0.f;
-  for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < P && !poses_only; ++p) {
     float c = 0.f;
     for (int t = rt.tid(); frame_in(t, T); t += fstep) c += sc.pc[p].vis[t];
     n_vis_total += rt.reduce_sum(c);
@@ -905,7 +909,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int r = 0; r < 3; ++r) { sc.ps[p].oc6[t * 6 + r] = Rb[r * 3 + 0]; sc.ps[p].oc6[t * 6 + 3 + r] = Rb[r * 3 + 1]; }
     }
   // per-joint sum over visible frames of thresholded score^2 (first_frame_only broadcasting of kp_2d, loss_func.py:27-33)
-  for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < P && !poses_only; ++p) {
     float cj[NJ];
     for (int j = 0; j < NJ; ++j) cj[j] = 0.f;
     for (int t = rt.tid(); frame_in(t, T); t += fstep) {
