@@ -312,7 +312,18 @@ __global__ void masked_mean_kernel(const float* ctx, int max_len, const int* len
   const int b = blockIdx.x, n = lens[b];
   for (int k = blockIdx.y * blockDim.x + threadIdx.x; k < D; k += blockDim.x * gridDim.y) {
     float s = 0.f;
-    for (int t = 0; t < n; ++t) s += ctx[frag ? x32_off(b * max_len + t, k, D) : ((size_t)b * max_len + t) * D + k];
+    int t = 0;
+    if (!frag) {      // eight rows requested together, added in the same order as one at a time (a wave is 300 dependent round trips otherwise)
+      const float* p = ctx + (size_t)b * max_len * D + k;
+      for (; t + 8 <= n; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(t + u) * D];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+    }
+    for (; t < n; ++t) s += ctx[frag ? x32_off(b * max_len + t, k, D) : ((size_t)b * max_len + t) * D + k];
     mean[(size_t)b * D + k] = s / (float)n;
   }
 }
@@ -1071,8 +1082,16 @@ int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const in
   else if (mode == GLAMR_VAE_TRAIN) hipLaunchKernelGGL(reparam_traj_kernel, dim3(B), dim3(64), 0, st, w.tqz, eps, w.z);
   else hipLaunchKernelGGL(mode_traj_kernel, dim3(B), dim3(NZ), 0, st, w.tqz, w.z);
   RC(lin(st, h->t_dz, w.z, NZ, w.trow, FF, B, ACT_NONE, nullptr, 0, nullptr, 1, 0, 0, 0));      // W_z z + b, one row per sequence
-  RC(lin(st, h->t_dctx, w.th, D, w.tg, FF, MT, ACT_RELU, nullptr, 0, w.trow, max_len, FF));
-  RC(lin(st, h->t_d2, w.tg, FF, w.tq, D, MT, ACT_RELU));
+  // decoder MLP: relu(W_ctx ctx + [W_z z + b] of the sequence) -> relu(W_2 .): as ONE row-block launch (the 512-wide hidden rows stay in LDS:
+  // 629 MB less written and read again per 1024 x 300 frames); GLAMR_NETS_NO_FUSE keeps the two GEMMs
+  static const bool no_fuse_dec = std::getenv("GLAMR_NETS_NO_FUSE") != nullptr || std::getenv("GLAMR_NETS_NO_FUSE_DEC") != nullptr;
+  if (!no_fuse_dec && !tl_free && !tl_fp32 && MT >= FUSE_MIN_ROWS && max_len >= 64 && h->t_dctx.Ws && h->t_d2.Ws && h->t_dctx.K == D && h->t_dctx.N == FF && h->t_d2.K == FF && h->t_d2.N == D) {
+    RC(launch_rows(st, w.th, D, MT, D, h->t_dctx.Ws, (size_t)FF * D, h->t_dctx.b, w.trow, max_len, FF, h->t_d2.Ws, (size_t)D * FF, FF, h->t_d2.b, ACT_RELU,
+                   nullptr, D, nullptr, nullptr, w.tq, D));
+  } else {
+    RC(lin(st, h->t_dctx, w.th, D, w.tg, FF, MT, ACT_RELU, nullptr, 0, w.trow, max_len, FF));
+    RC(lin(st, h->t_d2, w.tg, FF, w.tq, D, MT, ACT_RELU));
+  }
   RC(lin(st, h->t_dfc, w.tq, D, w.traw, 64, MT, ACT_NONE, nullptr, 0, nullptr, 1, 0, -1, 0));
   if (out_orig) hipLaunchKernelGGL(rows_out_kernel, dim3(MT), dim3(64), 0, st, w.traw, 64, MT, 11, out_orig);
   hipLaunchKernelGGL(traj_to_global2_kernel, dim3(B), dim3(256), 0, st, w.traw, 64, max_len, lens_run, init, ldinit, 1, out_local, out_trans, out_orient,

@@ -436,7 +436,10 @@ __global__ __launch_bounds__(512, RT == 1 ? 4 : 1) void rows_fused_kernel(RowsAr
         for (int j = 0; j < NJ; ++j) acc1[i][j] = (f32x16){0};
       phase(ks1_t{}, sX, XS, K1 / 16, a.W1s, a.w1_plane, K1 / 16, 0, hh * 8 + wave * NJ, acc1);
       if (hh) __syncthreads();                                    // everybody is done reading the previous hidden half
-      // hidden half -> planes: lane owns column n, rows (q & 3) + 8 (q >> 2) + 4 kg of each tile
+      // hidden half -> planes: lane owns column n, rows (q & 3) + 8 (q >> 2) + 4 kg of each tile.  (Row bias per group of rpg rows -- the decoder
+      // of the trajectory predictor, one row per sequence: a block of RB rows spans at most two groups when rpg >= RB, so a row's group is a
+      // comparison, not a division per element; launch_rows refuses a row bias with rpg < RB.)
+      const int rb_g0 = m0 / a.rpg, rb_next = (rb_g0 + 1) * a.rpg;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int nloc = (wave * NJ + j) * 32 + c, n = hh * 256 + nloc;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(512, RT == 1 ? 4 : 1) void rows_fused_kernel(RowsAr
           for (int q = 0; q < 16; ++q) {
             const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
             float v = acc1[i][j][q] + b;
-            if (a.rowbias) v += a.rowbias[(size_t)(min(m0 + row, a.M - 1) / a.rpg) * a.ldrb + n];
+            if (a.rowbias) v += a.rowbias[(size_t)(rb_g0 + (min(m0 + row, a.M - 1) >= rb_next ? 1 : 0)) * a.ldrb + n];
             v = fmaxf(v, 0.0f);
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);
@@ -1104,6 +1107,7 @@ inline int launch_rows(hipStream_t st, const float* X, int ldx, int M, int K1, c
   const int rt_sel = (!W1s && (rt_one == 1 || rt_one == 2)) ? rt_one : rt_env;
   const int rt = rt_sel == 1 || rt_sel == 2 ? rt_sel : 1;
   const int rb = 32 * rt;
+  if (rowbias && (rpg < rb || !W1s)) return fail(GLAMR_E_INVALID, "fused rows: a row bias needs two layers and groups of at least %d rows (got %d)", rb, rpg);
   const size_t lds = rows_fused_lds(K1, W1s != nullptr, rb);
   static bool attr_done = false;
   if (!attr_done) {

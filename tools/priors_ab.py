@@ -13,3 +13,10 @@ pose = (torch.randn(B, T, 69, generator=g) * 0.2).to(dev); vis = torch.ones(B, T
 meps, teps = torch.randn(B, num_windows(T), 128, generator=g).to(dev), torch.randn(B, 128, generator=g).to(dev)
 dt = bench._timed(lambda: m.mt_model.infer_padded(pose, vis, [T] * B, meps, teps), reps=5)
 print('priors %s: %.2f ms' % ('UNFUSED' if os.environ.get('GLAMR_NETS_NO_FUSE') else 'fused', dt * 1e3))
+# fingerprints of the outputs (first 16 hex digits of sha1 over the bytes): equal between two builds = bit-identical priors
+import hashlib
+out = m.mt_model.infer_padded(pose, vis, [T] * B, meps, teps)
+torch.cuda.synchronize()
+items = out.items() if isinstance(out, dict) else enumerate(out if isinstance(out, (tuple, list)) else [out])
+for k, v in items:
+    if torch.is_tensor(v): print('bits %s %s' % (k, hashlib.sha1(v.detach().cpu().numpy().tobytes()).hexdigest()[:16]))
