@@ -717,10 +717,11 @@ def run(argv=None):
                          'note': 'traffic = memory-side bytes of one launch (rocprofv3 PMC passes on the shipped instance)'},
             'pipeline': None if not coschedule else {
                 'coscheduled_streams': True, 'stage_launch_ms_alone': k_avg, 'stage_launch_ms_beside_the_priors': beside,
-                'critical_cycle': 'round 5: with the stage launch at 27 ms beside the priors the step is no longer stage + gap: the gate serialises the PRIORS of '
-                                  'consecutive batches (a batch\'s infiller takes 29 ms beside the other batch\'s stage, its predictor 6 ms, then the scene assembly / skinning 3.5 ms: '
-                                  'profiles/r05_chain_trace.log), and that chain is the period.  Measured and without effect: stage priority 0 / 1 / 3, a third stream, the gate opened '
-                                  'after the infiller, more waves per SIMD for the LDS-free GEMM (profiles/r05_pipeline_experiments.log)',
+                'critical_cycle': 'round 5: period T = max(S, prep + I - R) + P + R with S the stage launch beside the next batch\'s infiller (27 ms; 22.1 alone), I that infiller '
+                                  'beside the stage (29 ms), P the trajectory predictor (4.2 ms: LDS kernels, after the stage has retired), R scene assembly + skinning + forward-only '
+                                  'launch (3.5 ms), prep 1 ms: both sides of the max within a millisecond, only P enters undivided (profiles/r05_chain_trace.log, r05_gap_trace.log).  '
+                                  'Measured and without effect: stage priority 0 / 1 / 3, a third stream, the gate opened after the infiller, more waves per SIMD for the LDS-free GEMM '
+                                  '(profiles/r05_pipeline_experiments.log)',
                 'note': 'two streams, batches staggered by GlobalReconOptimizer.pipeline_gate: a batch starts when the previous one\'s priors are done, so its '
                         'motion infiller -- LDS-free one-wave kernels on fragment-major activations (csrc/nn_free.hpp) -- runs in the SIMD issue slots and '
                         'matrix pipes a resident stage workgroup leaves idle.  The stage launch is slower beside them than alone; the step is shorter '
