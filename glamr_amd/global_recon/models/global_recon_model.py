@@ -159,6 +159,7 @@ class PipelineGate:
             stream.wait_event(self.last)
 
     def after(self, stream):
+        # (an event created with hipEventReleaseToDevice instead of torch's system-scope one: measured, no difference -- profiles/r05_pipeline_experiments.log)
         ev = torch.cuda.Event()
         ev.record(stream)
         self.last = ev
@@ -168,11 +169,13 @@ class ResidentGraph:
     """A captured optimize_resident step (GlobalReconOptimizer.capture_resident): one HIP graph, or -- under a PipelineGate -- two, split
     where the gate's event is recorded (an event shared with another stream's graph cannot live inside a captured graph)."""
 
-    def __init__(self, graph, datas, packed, stream, tail=None, gate=None):
-        self.graph, self.datas, self.packed, self.stream, self.tail, self.gate = graph, datas, packed, stream, tail, gate
+    def __init__(self, graph, datas, packed, stream, tail=None, gate=None, head=None):
+        self.graph, self.datas, self.packed, self.stream, self.tail, self.gate, self.head = graph, datas, packed, stream, tail, gate, head
 
     def replay(self):
         with torch.cuda.stream(self.stream):
+            if self.head is not None:
+                self.head.replay()                                    # what precedes the priors does not wait for the gate (GLAMR_GATE_PREP)
             if self.gate is not None:
                 self.gate.before(self.stream)
             self.graph.replay()
@@ -195,6 +198,7 @@ class GlobalReconOptimizer:
         _lib.lib()                                                     # fail early and loudly if the HIP library is missing
         self.pipeline_gate = None                                      # a PipelineGate when the caller alternates batches between two streams
         self._capture_split = None
+        self._capture_head_split = None
         # Per-iteration loss log (:564,646-659).  The reference calls write_logs after EVERY optimizer.step -- with `log` None it prints.  Here
         # the iterations of a stage are one kernel launch: with a `log` (or keep_loss_history = True) the launch records the unweighted value of
         # every term at every iteration (glamr_scene_batch.loss_history; the plain instance with the reporting evaluation, about 2x the time),
@@ -670,9 +674,13 @@ class GlobalReconOptimizer:
         S, P, T, g = rin.S, rin.P, rin.T, rin.g
         n_slots = S * P
         gate = self.pipeline_gate
+        # GLAMR_GATE_PREP=early: the gate is waited for where the PRIORS start, not where the batch starts -- the arrays' zero fills and the
+        # per-person preparation (1.6 ms on the chain preparation -> infiller -> predictor) read the inputs only and may run beside the previous
+        # batch's priors (development knob, read per call; profiles/r05_pipeline_experiments.log)
+        prep_early = gate is not None and os.environ.get('GLAMR_GATE_PREP', 'early') == 'early'
         if not torch.cuda.is_current_stream_capturing():
             self.value_checks(rin)                                       # (first use of this batch only)
-            if gate is not None:
+            if gate is not None and not prep_early:
                 gate.before(torch.cuda.current_stream(dev))
         packed = packing.PackedScenes.empty(S, P, T, dev)
         packed.person_ids = rin.ids
@@ -691,6 +699,11 @@ class GlobalReconOptimizer:
         # the cached joints are produced in place by the skinning kernel: keep a placeholder until then
         packed.t['j_local'] = f32(1)
         pa, sb, ws, st = self._init_prepare(rin, packed, pa_t)
+        if prep_early:
+            if self._capture_head_split is not None:
+                self._capture_head_split()                             # capture_resident under a gate: the first cut (replay() waits for the gate there)
+            elif not torch.cuda.is_current_stream_capturing():
+                gate.before(torch.cuda.current_stream(dev))
         # motion priors on every person of every sequence in one call
         if rs:
             meps, teps = rs['meps'], rs['teps']
@@ -1015,29 +1028,39 @@ class GlobalReconOptimizer:
         else:
             # two graphs sharing one memory pool: everything up to and including the priors, and the rest; replay() records the gate's event between them
             tail = torch.cuda.CUDAGraph()
+            prep_early = os.environ.get('GLAMR_GATE_PREP', 'early') == 'early'
+            head = torch.cuda.CUDAGraph() if prep_early else None     # (three graphs then: preparation | priors | the rest)
             torch.cuda.synchronize(self.device)
             with torch.cuda.stream(st):
-                graph.capture_begin(capture_error_mode='thread_local')
+                first = head if head is not None else graph
+                first.capture_begin(capture_error_mode='thread_local')
+
+                def head_split():
+                    head.capture_end()
+                    graph.capture_begin(pool=head.pool(), capture_error_mode='thread_local')
 
                 def split():
                     graph.capture_end()
-                    tail.capture_begin(pool=graph.pool(), capture_error_mode='thread_local')
+                    tail.capture_begin(pool=first.pool(), capture_error_mode='thread_local')
                 self._capture_split = split
+                self._capture_head_split = head_split if head is not None else None
                 try:
                     datas, packed = self.optimize_resident(rin, max_iters)
                 except BaseException:
-                    # leave the stream out of capture mode whatever happened: whichever of the two graphs is capturing is ended and dropped
+                    # leave the stream out of capture mode whatever happened: whichever of the graphs is capturing is ended and dropped
                     # (a stream stuck in a broken capture fails every later launch -- bench.py's fall-back to plain launches included)
-                    for gph in (tail, graph):
+                    for gph in (tail, graph, head):
                         try:
-                            gph.capture_end()
+                            if gph is not None:
+                                gph.capture_end()
                         except Exception:      # noqa: BLE001 -- not capturing / already invalidated
                             pass
                     raise
                 finally:
                     self._capture_split = None
+                    self._capture_head_split = None
                 tail.capture_end()
-            rg = ResidentGraph(graph, datas, packed, st, tail=tail, gate=self.pipeline_gate)
+            rg = ResidentGraph(graph, datas, packed, st, tail=tail, gate=self.pipeline_gate, head=head)
         if check:
             torch.cuda.synchronize(self.device)
             with torch.random.fork_rng(devices=[self.device]):          # the caller's generators are left as they were

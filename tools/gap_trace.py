@@ -34,4 +34,7 @@ a, b, inside = gaps[len(gaps) // 2]
 print('one gap (%.2f ms), kernels by start time relative to the end of the stage launch:' % ((b['s'] - a['e']) / 1e6))
 for r in inside:
     if r['e'] - r['s'] > 20e3:
-        print('   %+9.1f us  %8.1f us  q%s  %s' % ((r['s'] - a['e']) / 1e3, (r['e'] - r['s']) / 1e3, r['Queue_Id'], short(r['Kernel_Name'])))
+        name = short(r['Kernel_Name'])
+        if name.startswith('at::'):      # torch's own kernels: which functor (fill / copy / ...) and how many threads
+            name = r['Kernel_Name'].replace('void ', '')[:150] + '  grid ' + str(r.get('Grid_Size', r.get('Grid_Size_X', '?')))
+        print('   %+9.1f us  %8.1f us  q%s  %s' % ((r['s'] - a['e']) / 1e3, (r['e'] - r['s']) / 1e3, r['Queue_Id'], name))
