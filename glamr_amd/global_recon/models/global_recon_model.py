@@ -175,7 +175,7 @@ class ResidentGraph:
     def replay(self):
         with torch.cuda.stream(self.stream):
             if self.head is not None:
-                self.head.replay()                                    # what precedes the priors does not wait for the gate (GLAMR_GATE_PREP)
+                self.head.replay()                                    # what precedes the priors does not wait for the gate (GLAMR_GATE_PREP=early)
             if self.gate is not None:
                 self.gate.before(self.stream)
             self.graph.replay()
@@ -674,10 +674,12 @@ class GlobalReconOptimizer:
         S, P, T, g = rin.S, rin.P, rin.T, rin.g
         n_slots = S * P
         gate = self.pipeline_gate
-        # GLAMR_GATE_PREP=early: the gate is waited for where the PRIORS start, not where the batch starts -- the arrays' zero fills and the
-        # per-person preparation (1.6 ms on the chain preparation -> infiller -> predictor) read the inputs only and may run beside the previous
-        # batch's priors (development knob, read per call; profiles/r05_pipeline_experiments.log)
-        prep_early = gate is not None and os.environ.get('GLAMR_GATE_PREP', 'early') == 'early'
+        # GLAMR_GATE_PREP=early (development knob, OFF): the gate is waited for where the PRIORS start, not where the batch starts -- the arrays' zero
+        # fills and the per-person preparation (1.6 ms on the chain preparation -> infiller -> predictor) read the inputs only and may run beside the
+        # previous batch's priors.  Measured: step -0.17 ms -- and the replayed three-graph step differed from the plain one in about one of ten runs of
+        # tests/test_e2e_gpu.py::test_gated_two_stream_step_graphs_use_the_coschedulable_kernels (a race between the two streams' replays that an extra
+        # kernel or event between the graphs does not remove; cause not found): not the default (profiles/r05_pipeline_experiments.log)
+        prep_early = gate is not None and os.environ.get('GLAMR_GATE_PREP', 'late') == 'early'
         if not torch.cuda.is_current_stream_capturing():
             self.value_checks(rin)                                       # (first use of this batch only)
             if gate is not None and not prep_early:
@@ -702,20 +704,25 @@ class GlobalReconOptimizer:
         if prep_early:
             if self._capture_head_split is not None:
                 self._capture_head_split()                             # capture_resident under a gate: the first cut (replay() waits for the gate there)
+                torch.zeros(1, device=dev)                             # (the new graph starts with a KERNEL node: see below)
             elif not torch.cuda.is_current_stream_capturing():
                 gate.before(torch.cuda.current_stream(dev))
-        # motion priors on every person of every sequence in one call
+        # the latent draws of the motion priors.  Given latents are copied by a KERNEL (x * 1.0), not by Tensor.copy_: under capture_resident this is
+        # where a graph starts, and a graph whose first node is a memcpy node was measured to start before the work enqueued ahead of it on the stream
+        # had finished (ROCm 7.0: the replayed step then differed from the plain one by up to 2 px, from run to run -- tests/test_e2e_gpu.py,
+        # test_gated_two_stream_step_graphs_use_the_coschedulable_kernels).  torch.randn is a kernel too.
         if rs:
             meps, teps = rs['meps'], rs['teps']
             if rin.meps is not None:
-                meps.copy_(rin.meps)
-                teps.copy_(rin.teps)
+                torch.mul(rin.meps, 1.0, out=meps)
+                torch.mul(rin.teps, 1.0, out=teps)
             else:
                 torch.randn(meps.shape, out=meps)
                 torch.randn(teps.shape, out=teps)
         else:
             meps = rin.meps if rin.meps is not None else torch.randn((n_slots, nw, NZ), device=dev)
             teps = rin.teps if rin.teps is not None else torch.randn((n_slots, NZ), device=dev)
+        # motion priors on every person of every sequence in one call
         def open_gate():
             if self._capture_split is not None:
                 self._capture_split()                                   # capture_resident under a gate: the graph is cut here
@@ -1028,7 +1035,7 @@ class GlobalReconOptimizer:
         else:
             # two graphs sharing one memory pool: everything up to and including the priors, and the rest; replay() records the gate's event between them
             tail = torch.cuda.CUDAGraph()
-            prep_early = os.environ.get('GLAMR_GATE_PREP', 'early') == 'early'
+            prep_early = os.environ.get('GLAMR_GATE_PREP', 'late') == 'early'
             head = torch.cuda.CUDAGraph() if prep_early else None     # (three graphs then: preparation | priors | the rest)
             torch.cuda.synchronize(self.device)
             with torch.cuda.stream(st):

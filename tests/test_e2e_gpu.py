@@ -850,7 +850,7 @@ def test_gated_two_stream_step_graphs_use_the_coschedulable_kernels(make_model, 
                     model.optimize_resident(rin, max_iters=6)
             torch.cuda.synchronize()
             graphs = [model.capture_resident(rin, max_iters=6, stream=st, check=True) for st in streams]
-            assert all(g.tail is not None and g.gate is model.pipeline_gate for g in graphs)
+            assert all(g.tail is not None and g.head is None and g.gate is model.pipeline_gate for g in graphs)
             for i in range(4):
                 graphs[i % 2].replay()
             torch.cuda.synchronize()
