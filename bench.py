@@ -550,6 +550,37 @@ def run(argv=None):
     if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
+    # What the timed region computed, checked after the clock has stopped: the two streams' graphs replayed alternately as in the timed loop,
+    # every replay with the SAME generator state (torch's graphs take seed and offset at replay time), must leave in each graph's arrays exactly
+    # what ONE plain step with that state leaves -- projections and every optimised parameter, bit for bit.  (capture_resident checks each graph
+    # alone; this checks them beside each other: a race between the streams' replays shows up here and nowhere in a timing.)
+    replay_check = None
+    if step_graphs and on_gpu:
+        try:
+            with torch.random.fork_rng(devices=[dev]):
+                seed = 20260927
+                torch.manual_seed(seed)
+                with torch.cuda.stream(streams[0]):
+                    _, ref = model.optimize_resident(rin)
+                sync()
+                want = {k: ref.t[k].clone() for k in ('kp_2d_pred', 'params')}
+                n_rep = 4 * len(step_graphs)
+                for i in range(n_rep):
+                    torch.manual_seed(seed)
+                    step_graphs[i % len(step_graphs)].replay()
+                sync()
+                worst, equal = 0.0, True
+                for g in step_graphs:
+                    for k, w in want.items():
+                        got = g.packed.t[k]
+                        equal = equal and bool(torch.isfinite(got).all()) and torch.equal(got, w)
+                    worst = max(worst, float((g.packed.t['kp_2d_pred'] - want['kp_2d_pred']).abs().max()))
+            replay_check = {'replays': n_rep, 'streams': len(step_graphs), 'bit_identical_to_one_plain_step': equal, 'max_projection_difference_px': worst}
+            if not equal:
+                sys.stderr.write('bench: the pipelined replays do NOT reproduce the plain step (max %.3g px): the value below is a timing of wrong results\n' % worst)
+            del ref, want
+        except Exception as e:      # noqa: BLE001
+            sys.stderr.write('bench: replay check not run (%s)\n' % e)
     beside = None
     if coschedule:
         # what a stage launch takes in THIS pipeline (beside the other stream's priors): four more gated steps as plain launches, whose
@@ -715,6 +746,7 @@ def run(argv=None):
                                       '2 single-stream plain steps right after the timed region: in the timed region the launches of the %d stream(s) '
                                       'share the CUs%s' % (len(streams), ' and are graph replays (one workspace per graph: no per-replay stamps)' if step_graphs else '')),
                          'note': 'traffic = memory-side bytes of one launch (rocprofv3 PMC passes on the shipped instance)'},
+            'replay_check': replay_check,
             'pipeline': None if not coschedule else {
                 'coscheduled_streams': True, 'stage_launch_ms_alone': k_avg, 'stage_launch_ms_beside_the_priors': beside,
                 'critical_cycle': 'round 5: period T = max(S, prep + I - R) + P + R with S the stage launch beside the next batch\'s infiller (27 ms; 22.1 alone), I that infiller '
