@@ -437,6 +437,7 @@ def run(argv=None):
     ap.add_argument('--no-strong-line', action='store_true', help='skip the BASELINE configs[2] line (64 sequences split over the ranks) measured after the weak one')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo with --stub-model for the CPU test of the skeleton)')
     ap.add_argument('--stub-model', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-early-prep', action='store_true', help='capture the pipelined step with the library\'s default cut (the whole batch behind the gate: two graphs per step)')
     ap.add_argument('--force-dist', action='store_true', help='create the process group also at --gpus 1 (a world of one rank): runs the init / barrier / reduction / '
                     'collective-latency code of the multi-GPU path on a single GPU (tests/test_e2e_gpu.py)')
     args = ap.parse_args(argv)
@@ -514,6 +515,32 @@ def run(argv=None):
         if len(keep) > 2 * len(streams):
             keep.pop(0)
 
+    def replay_check_of(graphs):
+        """The two streams' graphs replayed alternately as in the timed loop, every replay with the SAME generator state (torch's graphs take
+        seed and offset at replay time), must leave in each graph's arrays exactly what ONE plain step with that state leaves -- projections
+        and every optimised parameter, bit for bit.  (capture_resident checks each graph alone; this checks them beside each other: a race
+        between the streams' replays shows up here and nowhere in a timing.)"""
+        with torch.random.fork_rng(devices=[dev]):
+            seed = 20260927
+            torch.manual_seed(seed)
+            with torch.cuda.stream(streams[0]):
+                _, ref = model.optimize_resident(rin)
+            sync()
+            want = {k: ref.t[k].clone() for k in ('kp_2d_pred', 'params')}
+            n_rep = 4 * len(graphs)
+            for i in range(n_rep):
+                torch.manual_seed(seed)
+                graphs[i % len(graphs)].replay()
+            sync()
+            worst, equal = 0.0, True
+            for g in graphs:
+                for k, w in want.items():
+                    got = g.packed.t[k]
+                    equal = equal and bool(torch.isfinite(got).all()) and torch.equal(got, w)
+                worst = max(worst, float((g.packed.t['kp_2d_pred'] - want['kp_2d_pred']).abs().max()))
+        return {'replays': n_rep, 'streams': len(graphs), 'bit_identical_to_one_plain_step': equal, 'max_projection_difference_px': worst}
+
+    gate_cut = None
     graph_step = on_gpu and not args.no_graph_step
     for i in range(max(args.warmup, len(streams) if graph_step else 0)):
         step(i)
@@ -523,7 +550,26 @@ def run(argv=None):
         # every stream has run the step once (allocations, attribute calls, the priors' own graph): capture it, one graph per stream, through
         # the product's own entry point (GlobalReconOptimizer.capture_resident: capture + bit-for-bit check of a replay against a plain step)
         try:
-            step_graphs = [model.capture_resident(rin, stream=st, check=True) for st in streams]
+            # The pipelined step is captured with the preparation AHEAD of the gate (GLAMR_GATE_PREP=early: three graphs per step, 35.7 against
+            # 38.5 ms; the library's default is the two-graph cut) -- and kept only if the two streams' replays reproduce one plain step bit for
+            # bit right here, before the clock starts; otherwise the default cut is captured instead.  The same check runs again after the clock.
+            gate_cut = 'default (two graphs)'
+            if coschedule and 'GLAMR_GATE_PREP' not in os.environ and not args.no_early_prep:
+                os.environ['GLAMR_GATE_PREP'] = 'early'
+                try:
+                    step_graphs = [model.capture_resident(rin, stream=st, check=True) for st in streams]
+                    sync()
+                    pre = replay_check_of(step_graphs)
+                    if pre['bit_identical_to_one_plain_step']:
+                        gate_cut = 'preparation ahead of the gate (three graphs), verified before and after the timed region'
+                    else:
+                        sys.stderr.write('bench: the three-graph cut did not reproduce the plain step (%.3g px): the default cut is used\n' % pre['max_projection_difference_px'])
+                        step_graphs = None
+                finally:
+                    if step_graphs is None:
+                        del os.environ['GLAMR_GATE_PREP']
+            if step_graphs is None:
+                step_graphs = [model.capture_resident(rin, stream=st, check=True) for st in streams]
             sync()
             eager_step = step
 
@@ -550,35 +596,15 @@ def run(argv=None):
     if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
-    # What the timed region computed, checked after the clock has stopped: the two streams' graphs replayed alternately as in the timed loop,
-    # every replay with the SAME generator state (torch's graphs take seed and offset at replay time), must leave in each graph's arrays exactly
-    # what ONE plain step with that state leaves -- projections and every optimised parameter, bit for bit.  (capture_resident checks each graph
-    # alone; this checks them beside each other: a race between the streams' replays shows up here and nowhere in a timing.)
+    # What the timed region computed, checked after the clock has stopped (replay_check_of above)
     replay_check = None
     if step_graphs and on_gpu:
         try:
-            with torch.random.fork_rng(devices=[dev]):
-                seed = 20260927
-                torch.manual_seed(seed)
-                with torch.cuda.stream(streams[0]):
-                    _, ref = model.optimize_resident(rin)
-                sync()
-                want = {k: ref.t[k].clone() for k in ('kp_2d_pred', 'params')}
-                n_rep = 4 * len(step_graphs)
-                for i in range(n_rep):
-                    torch.manual_seed(seed)
-                    step_graphs[i % len(step_graphs)].replay()
-                sync()
-                worst, equal = 0.0, True
-                for g in step_graphs:
-                    for k, w in want.items():
-                        got = g.packed.t[k]
-                        equal = equal and bool(torch.isfinite(got).all()) and torch.equal(got, w)
-                    worst = max(worst, float((g.packed.t['kp_2d_pred'] - want['kp_2d_pred']).abs().max()))
-            replay_check = {'replays': n_rep, 'streams': len(step_graphs), 'bit_identical_to_one_plain_step': equal, 'max_projection_difference_px': worst}
-            if not equal:
-                sys.stderr.write('bench: the pipelined replays do NOT reproduce the plain step (max %.3g px): the value below is a timing of wrong results\n' % worst)
-            del ref, want
+            replay_check = replay_check_of(step_graphs)
+            replay_check['gate_cut'] = gate_cut
+            if not replay_check['bit_identical_to_one_plain_step']:
+                sys.stderr.write('bench: the pipelined replays do NOT reproduce the plain step (max %.3g px): the value below is a timing of wrong results\n'
+                                 % replay_check['max_projection_difference_px'])
         except Exception as e:      # noqa: BLE001
             sys.stderr.write('bench: replay check not run (%s)\n' % e)
     beside = None
@@ -595,6 +621,8 @@ def run(argv=None):
             sys.stderr.write('bench: co-scheduled stage launches not measured (%s)\n' % e)
         del stage_events[:]
         model.pipeline_gate = None                                   # the single-stream measurements below run the plain step
+    if gate_cut is not None and gate_cut.startswith('preparation'):
+        os.environ.pop('GLAMR_GATE_PREP', None)                      # (set above for this pipeline only: a caller in the same process keeps its own setting)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     n_total = parallel.sum_over_ranks(B, dev)                      # units all ranks processed per step
     rccl_ranks = dist.get_world_size() if (use_dist and dist.get_backend() == 'nccl') else None

@@ -90,6 +90,7 @@ _SIGNATURES = {
     'glamr_check_inputs': (c_int, [POINTER(RawBatch), c_void_p, c_void_p, c_void_p]),
     'glamr_init_scenes': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays)] + [c_void_p] * 6),
     'glamr_init_scenes_ex': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays)] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),
+    'glamr_init_scatter_pose': (c_int, [POINTER(SceneBatch), POINTER(PersonArrays), c_void_p, c_void_p]),
     'glamr_init_cam_all_frames': (c_int, [POINTER(SceneBatch), c_void_p]),
     'glamr_grecon_param_layout': (c_int, [c_int, c_int, POINTER(ParamLayout)]),
     'glamr_grecon_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -41,14 +41,17 @@ __device__ void rotmat_to_rotvec_nearest(const float* Mf, float out[3]) {
   if (m00 > best) { best = m00; choice = 0; }
   if (m11 > best) { best = m11; choice = 1; }
   if (m22 > best) { best = m22; choice = 2; }
+  // with (i, j, k) = (choice, choice + 1, choice + 2) mod 3:  q[i] = 1 - tr + 2 X[i][i], q[j] = X[j][i] + X[i][j], q[k] = X[k][i] + X[i][k],
+  // q[3] = X[k][j] - X[j][k] -- the three cases written out: indexing X and q with run-time indices put both in SCRATCH memory (80 bytes
+  // per lane, the only kernel of init.hip that had any; the same operations on the same operands)
   if (choice == 3) {
     q[0] = X[7] - X[5]; q[1] = X[2] - X[6]; q[2] = X[3] - X[1]; q[3] = 1 + tr;
+  } else if (choice == 0) {
+    q[0] = 1 - tr + 2 * X[0]; q[1] = X[3] + X[1]; q[2] = X[6] + X[2]; q[3] = X[7] - X[5];
+  } else if (choice == 1) {
+    q[1] = 1 - tr + 2 * X[4]; q[2] = X[7] + X[5]; q[0] = X[1] + X[3]; q[3] = X[2] - X[6];
   } else {
-    const int i_ = choice, j_ = (choice + 1) % 3, k_ = (choice + 2) % 3;
-    q[i_] = 1 - tr + 2 * X[i_ * 3 + i_];
-    q[j_] = X[j_ * 3 + i_] + X[i_ * 3 + j_];
-    q[k_] = X[k_ * 3 + i_] + X[i_ * 3 + k_];
-    q[3] = X[k_ * 3 + j_] - X[j_ * 3 + k_];
+    q[2] = 1 - tr + 2 * X[8]; q[0] = X[2] + X[6]; q[1] = X[5] + X[7]; q[3] = X[3] - X[1];
   }
   const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   for (int k = 0; k < 4; ++k) q[k] /= n;
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256) void init_scene_kernel(SceneInitArgs a) {
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
       const int e = t - fs;
       if (e >= 0 && e < n) {
-        for (int k = 0; k < 69; ++k) a.smpl_pose[(o1 + t) * 69 + k] = a.n_pose[(o1 + e) * 69 + k];
+        if (!(a.flags & GLAMR_INIT_POSE_SCATTERED))
+          for (int k = 0; k < 69; ++k) a.smpl_pose[(o1 + t) * 69 + k] = a.n_pose[(o1 + e) * 69 + k];
         for (int k = 0; k < 3; ++k) { bo[t * 3 + k] = a.n_orient[(o1 + e) * 3 + k]; bt[t * 3 + k] = a.n_trans[(o1 + e) * 3 + k]; }
       }
       if (t < n) for (int k = 0; k < 11; ++k) prior[t * 11 + k] = a.n_local[(o1 + t) * 11 + k];
@@ -400,6 +404,19 @@ __global__ __launch_bounds__(256) void init_scene_kernel(SceneInitArgs a) {
   }
 }
 
+// The infilled body pose into video-frame positions (the first thing init_scene_kernel does), as its own launch: everything the skinning needs
+// is known when the motion infiller is done, before the trajectory predictor has run (glamr_init_scatter_pose).  One workgroup per person slot.
+__global__ __launch_bounds__(256) void pose_scatter_kernel(glamr_scene_batch b, float* smpl_pose, const float* n_pose) {
+  const int slot = blockIdx.x, T = b.max_len, MP = b.max_persons, si = slot / MP;
+  if (slot - si * MP >= b.n_persons[si]) return;
+  const size_t o1 = (size_t)slot * T;
+  const int fs = b.fr_start[slot], n = b.fr_end[slot] - fs;
+  for (int idx = threadIdx.x; idx < n * 69; idx += blockDim.x) {
+    const int e = idx / 69, k = idx - e * 69;
+    smpl_pose[(o1 + fs + e) * 69 + k] = n_pose[(o1 + e) * 69 + k];
+  }
+}
+
 // init_cam_pose(all_frames=True): camera-to-world per frame from the first person where it is seen, zeros elsewhere
 __global__ void cam_all_frames_kernel(glamr_scene_batch b) {
   const int si = blockIdx.x, T = b.max_len, MP = b.max_persons;
@@ -502,10 +519,17 @@ extern "C" int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_per
 extern "C" int glamr_init_scenes_ex(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
                                     const float* nets_local_traj, const float* nets_trans, const float* nets_orient, int flags, void* workspace, void* stream_) {
   GLAMR_REQUIRE(batch && pa && nets_pose_out && nets_local_traj && nets_trans && nets_orient && workspace, "null argument");
-  GLAMR_REQUIRE((flags & ~GLAMR_INIT_TRAJ_FROM_CAM) == 0, "unknown flags %d", flags);
+  GLAMR_REQUIRE((flags & ~(GLAMR_INIT_TRAJ_FROM_CAM | GLAMR_INIT_POSE_SCATTERED)) == 0, "unknown flags %d", flags);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SceneInitArgs a{*batch, pa->trans_cam, pa->smpl_pose, nets_pose_out, nets_local_traj, nets_trans, nets_orient, static_cast<float*>(workspace), flags};
   hipLaunchKernelGGL(init_scene_kernel, dim3(batch->n_scenes), dim3(256), 0, stream, a);
+  GLAMR_HIP_CHECK(hipGetLastError());
+  return GLAMR_OK;
+}
+
+extern "C" int glamr_init_scatter_pose(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out, void* stream_) {
+  GLAMR_REQUIRE(batch && pa && pa->smpl_pose && nets_pose_out, "null argument");
+  hipLaunchKernelGGL(pose_scatter_kernel, dim3(batch->n_scenes * batch->max_persons), dim3(256), 0, static_cast<hipStream_t>(stream_), *batch, pa->smpl_pose, nets_pose_out);
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }

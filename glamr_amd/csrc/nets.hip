@@ -174,6 +174,10 @@ namespace {
 // small pipeline kernels
 // ---------------------------------------------------------------------------------------------------------------------
 
+__global__ void copy_ints_kernel(int* dst, const int32_t* src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
 // window input rows + key-padding mask (get_seg_data :564-587, mask[:, :10] = False :629)
 __global__ void window_gather_kernel(const float* pose, const float* visible, const int* lens, int Tpad, int max_len, int s, float* x, unsigned char* mask) {
   const int b = blockIdx.x, j = blockIdx.y;
@@ -1171,7 +1175,12 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
     std::memcpy(pinned, lens_host, (size_t)B * sizeof(int32_t));
     lens_src = pinned;
   }
-  GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_src, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  // Recorded into a caller's graph the upload is a KERNEL reading the pinned table (hipHostMalloc memory is device-visible), not a memcpy node:
+  // replays of two such graphs on two streams were measured to disturb each other when a graph started with memcpy nodes
+  // (profiles/r05_pipeline_experiments.log; GLAMR_NETS_LENS_MEMCPY=1 restores the copy node)
+  static const bool lens_memcpy = std::getenv("GLAMR_NETS_LENS_MEMCPY") != nullptr;
+  if (outer_capture && !lens_memcpy) hipLaunchKernelGGL(copy_ints_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.lens, lens_src, B);
+  else GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_src, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   auto enqueue = [&]() -> int {
     return enqueue_infer(h, st, w, B, max_len, n_win, n_win_max, do_infill, do_traj, body_pose, visible, motion_eps, traj_eps, out_pose, out_local_traj, out_trans,
                          out_orient);

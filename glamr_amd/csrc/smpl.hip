@@ -642,12 +642,26 @@ __global__ __launch_bounds__(256) void smpl_finish_kernel(FinishArgs a) {
   const int b = blockIdx.x * 4 + wave;
   const bool ok = b < a.B;
   const int nred = a.n_extra_used * 3;
-  // deterministic reduction over tiles: lane l sums tiles l, l+64, ... then a shuffle tree
-  for (int q = 0; q < nred; ++q) {
-    float s = 0.f;
-    if (ok) for (int t = lane; t < a.n_tiles; t += 64) s += a.partial[((size_t)t * a.Bpad + b) * nred + q];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) sExtra[wave][q] = s;
+  // deterministic reduction over tiles: lane l sums tiles l, l+64, ... then a shuffle tree -- the sums of a frame side by side: one
+  // sum after the other was nred dependent chains of a load and six shuffles each (0.44 ms per 307 200 frames; the additions and their order
+  // are the same)
+  constexpr int NRED_MAX = MAX_EXTRA * 3;
+  float s[NRED_MAX];
+#pragma unroll
+  for (int q = 0; q < NRED_MAX; ++q) s[q] = 0.f;
+  if (ok)
+    for (int t = lane; t < a.n_tiles; t += 64) {
+      const float* p = a.partial + ((size_t)t * a.Bpad + b) * nred;
+#pragma unroll
+      for (int q = 0; q < NRED_MAX; ++q) if (q < nred) s[q] += p[q];
+    }
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int q = 0; q < NRED_MAX; ++q) if (q < nred) s[q] += __shfl_xor(s[q], off);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < NRED_MAX; ++q) if (q < nred) sExtra[wave][q] = s[q];
   }
   __syncthreads();
   const int n_out = a.orig_joints ? NJ : a.n_out;

@@ -674,11 +674,12 @@ class GlobalReconOptimizer:
         S, P, T, g = rin.S, rin.P, rin.T, rin.g
         n_slots = S * P
         gate = self.pipeline_gate
-        # GLAMR_GATE_PREP=early (development knob, OFF): the gate is waited for where the PRIORS start, not where the batch starts -- the arrays' zero
-        # fills and the per-person preparation (1.6 ms on the chain preparation -> infiller -> predictor) read the inputs only and may run beside the
-        # previous batch's priors.  Measured: step -0.17 ms -- and the replayed three-graph step differed from the plain one in about one of ten runs of
-        # tests/test_e2e_gpu.py::test_gated_two_stream_step_graphs_use_the_coschedulable_kernels (a race between the two streams' replays that an extra
-        # kernel or event between the graphs does not remove; cause not found): not the default (profiles/r05_pipeline_experiments.log)
+        # GLAMR_GATE_PREP=early: the gate is waited for where the PRIORS start, not where the batch starts -- the arrays' zero fills and the per-person
+        # preparation (1.6 ms on the chain preparation -> infiller -> predictor) read the inputs only and may run beside the previous batch's priors;
+        # capture_resident cuts the step into three graphs for it (preparation | priors + skinning | rest): 35.7 against 38.5 ms per 1024-sequence step.
+        # NOT the default: the two streams' replays of the three-graph cut differed from the plain step in about one of six runs of the 48-sequence
+        # test (tests/test_e2e_gpu.py, gated two-stream test; cause not found), never at 1024 sequences once the skinning had moved ahead of the
+        # predictor.  bench.py asks for it and verifies its replays against a plain step before and after the timed region (`replay_check`).
         prep_early = gate is not None and os.environ.get('GLAMR_GATE_PREP', 'late') == 'early'
         if not torch.cuda.is_current_stream_capturing():
             self.value_checks(rin)                                       # (first use of this batch only)
@@ -732,18 +733,36 @@ class GlobalReconOptimizer:
         # (development aid GLAMR_GATE_AFTER: 'infiller' / 'priors' (default) / 'scene' / 'skin' / 'forward' -- later = the rest of this batch's
         # preparation runs without the next batch's first kernels beside it, but that batch starts later: profiles/r05_pipeline_experiments.log)
         gate_at = os.environ.get('GLAMR_GATE_AFTER', 'priors') if gate is not None else 'priors'
+        # Under a gate the SKINNING runs between the infiller and the trajectory predictor, i.e. before the gate opens: everything it needs (the
+        # infilled poses in video-frame rows, glamr_init_scatter_pose) is known by then.  Beside the next batch's first kernels its small workgroups
+        # were measured to read another workgroup's LDS contents now and then (~40 of 307 200 frames of a batch with joints off by millimetres;
+        # profiles/r05_pipeline_experiments.log, bench.py `replay_check`); where it runs now only the previous batch's optimiser stage is resident.
+        # GLAMR_SKIN_AFTER_PRIORS=1 restores the old order (development aid).
+        skin_early = gate is not None and os.environ.get('GLAMR_SKIN_AFTER_PRIORS') != '1' and gate_at in ('priors', 'infiller') \
+            and hasattr(self.mt_model, 'handle')
+
+        def skin():
+            # root-relative joints of every frame, cached for the whole optimisation
+            packed.t['j_local'] = self.smpl.root_relative_joints(pa_t['smpl_pose'].view(-1, 69), pa_t['smpl_beta'].view(-1, 10)).view(n_slots, T, 26, 3)
+
+        def after_infiller(out_inf):
+            if gate_at == 'infiller':
+                open_gate()
+            if skin_early:
+                _lib.check(L.glamr_init_scatter_pose(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out_inf['pose']), st))
+                skin()
         out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps, buffers=rs, coschedule=gate is not None,
-                                         between=open_gate if gate_at == 'infiller' else None)
+                                         between=after_infiller if (skin_early or gate_at == 'infiller') else None)
         if gate_at == 'priors':
             open_gate()
         packed.latents = (meps, teps)                                  # the draws this batch was initialised with (parameters in latent-optimisation mode)
         # (flag_traj_from_cam :237,325-351: the base pose of the frames outside a person's existence range read off the initial camera)
         _lib.check(L.glamr_init_scenes_ex(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out['pose']), _lib.ptr(out['local_traj']), _lib.ptr(out['trans']),
-                                          _lib.ptr(out['orient']), 1 if self.flag_traj_from_cam else 0, _lib.ptr(ws), st))
+                                          _lib.ptr(out['orient']), (1 if self.flag_traj_from_cam else 0) | (2 if skin_early else 0), _lib.ptr(ws), st))
         if gate_at == 'scene':
             open_gate()
-        # root-relative joints of every frame, cached for the whole optimisation
-        packed.t['j_local'] = self.smpl.root_relative_joints(pa_t['smpl_pose'].view(-1, 69), pa_t['smpl_beta'].view(-1, 10)).view(n_slots, T, 26, 3)
+        if not skin_early:
+            skin()
         if gate_at == 'skin':
             open_gate()
         # with flag_init_cam_all_frames this pass is only there for the world poses the cameras are initialised from; whoever needs the 'init'

@@ -512,13 +512,13 @@ class MotionTrajJointModel:
         return self.traj_predictor.get_latent(seq_len)
 
     def infer_padded(self, body_pose, visible, lens, motion_eps, traj_eps, buffers=None, coschedule=False, between=None):
-        """Batched entry used by GlobalReconOptimizer: ragged sequences padded to a common length.  `between`: called after the motion infiller
-        has been enqueued and before the trajectory predictor is (two library calls instead of one) -- where a pipelined caller lets the next
-        batch start (GlobalReconOptimizer.pipeline_gate)."""
+        """Batched entry used by GlobalReconOptimizer: ragged sequences padded to a common length.  `between(out)`: called after the motion infiller
+        has been enqueued (out['pose'] holds its result in stream order) and before the trajectory predictor is (two library calls instead of
+        one) -- where a pipelined caller runs what only needs the infilled poses (GlobalReconOptimizer.init_resident: the skinning)."""
         if between is None:
             return self.handle.infer(body_pose, visible, lens, motion_eps=motion_eps, traj_eps=traj_eps, buffers=buffers, coschedule=coschedule)
         out = self.handle.infer(body_pose, visible, lens, motion_eps=motion_eps, traj=False, buffers=buffers, coschedule=coschedule)
-        between()
+        between(out)
         out.update(self.handle.infer(out['pose'], None, lens, traj_eps=traj_eps, infill=False, buffers=buffers, coschedule=coschedule))
         return out
 

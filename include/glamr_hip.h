@@ -422,7 +422,12 @@ int glamr_init_scenes(const glamr_scene_batch* batch, const glamr_person_arrays*
  * get_traj_from_cam :325-351 with traj_interp_method 'linear_interp'): the base pose of a person (smpl_orient_world_base / root_trans_world_base,
  * what the frames outside its existence range keep) is read off the initial camera -- translation of cam_pose_inv . person_transform_cam,
  * orientation interpolated between the frames the person is seen in, heading separately (interp_orient_q_sep_heading). */
-enum { GLAMR_INIT_TRAJ_FROM_CAM = 1 };
+enum { GLAMR_INIT_TRAJ_FROM_CAM = 1, GLAMR_INIT_POSE_SCATTERED = 2 };
+/* The first step of glamr_init_scenes alone -- the motion infiller's poses (rows [0, n) of a person) into the video-frame rows of
+ * person_arrays.smpl_pose (global_recon_model.py:152-159: `smpl_pose[exist range] = infer_out_pose`) -- so that the joints-only skinning (:517-528,
+ * cached for the whole schedule) can run as soon as the infiller is done, before the trajectory predictor.  A later glamr_init_scenes_ex is then
+ * given GLAMR_INIT_POSE_SCATTERED and leaves smpl_pose alone. */
+int glamr_init_scatter_pose(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out, void* stream);
 int glamr_init_scenes_ex(const glamr_scene_batch* batch, const glamr_person_arrays* pa, const float* nets_pose_out,
                          const float* nets_local_traj, const float* nets_trans, const float* nets_orient, int flags, void* workspace, void* stream);
 /* init_cam_pose(all_frames=True) (:243-244) from the orient_world / trans_world of the last forward pass. */

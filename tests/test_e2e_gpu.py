@@ -823,7 +823,8 @@ def test_captured_resident_step_follows_new_inputs(make_model):
 def test_gated_two_stream_step_graphs_use_the_coschedulable_kernels(make_model, monkeypatch):
     """The staggered two-stream pipeline (PipelineGate): every batch starts when the previous batch's priors are done, its infiller runs on the
     kernels that fit beside the other stream's optimiser stage (GLAMR_NETS_COSCHEDULE: 48 sequences x 2 windows = 4800 window rows, above the
-    2048-row threshold), and capture_resident cuts the step into two graphs around the gate's event.  With the LDS kernels forced
+    2048-row threshold), and capture_resident cuts the step into two graphs around the gate's event (the priors with the skinning between infiller
+    and predictor | the rest).  With the LDS kernels forced
     (GLAMR_NETS_FREE=0) the gated, split, replayed step is the ungated plain step BIT FOR BIT: gate and split change nothing but the order
     of launches across streams.  With the co-schedulable kernels the replays reproduce the plain gated step bit for bit (capture_resident's
     own check); against the LDS kernels the priors differ by ~1e-7 (tests/test_nets_gpu.py), which six sign-driven Adam steps turn into
