@@ -115,9 +115,36 @@ __global__ __launch_bounds__(64, MAXW) void gemm_free_kernel(GemmArgs a) {
   // epilogue: register q of tile j = output column n0 + 32 j + 8 (q >> 2) + 4 kg + (q & 3) of row m0 + c
   if (row >= a.M) return;
   const int rbrow = a.rowbias ? (a.rows_per_group > 0 ? row / a.rows_per_group : row % (-a.rows_per_group)) : 0;
-  // (Round 5 measured a straight-line copy of this epilogue per combination of the uniform options -- 183 branches and ~1 400 of the kernel's
-  // 2 270 instructions are epilogue: the infiller got faster and the STEP SLOWER, 36.6 -> 36.8 - 37.3 ms: a faster infiller takes more of the
-  // issue slots of the resident stage, and the stage's chain is the pipeline's critical one.  profiles/r05_pipeline_experiments.log.)
+  // Column tiles that lie whole inside N (or any tile of a fragment-major output, whose rows are padded) leave through STRAIGHT-LINE code, one
+  // copy per combination of the uniform options (bias, per-row bias, ReLU, residual, output layout) chosen once: the general loop below decides
+  // them per group of four columns -- 183 branches, ~1 400 of the kernel's 2 270 instructions.  (Measured twice in round 5: while the optimiser
+  // stage's chain was the pipeline's critical one a faster infiller made the step SLOWER -- it takes more from the stage beside it -- and this
+  // was not kept; since the skinning moved ahead of the predictor the infiller's chain is the critical one by 2.6 ms:
+  // profiles/r05_pipeline_experiments.log.)
+  if (n0 + 32 * C <= a.N || a.y_frag) {
+    auto emit = [&](auto has_b, auto has_rb, auto relu, auto has_r, auto frag) {
+#pragma unroll
+      for (int j = 0; j < C; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = n0 + 32 * j + 8 * i + 4 * kg;
+          if (n >= a.N) continue;                      // (fragment-major outputs only: N is a multiple of 4 there)
+          f32x4 v = {acc[j][4 * i], acc[j][4 * i + 1], acc[j][4 * i + 2], acc[j][4 * i + 3]};
+          if (decltype(has_b)::value) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+          if (decltype(has_rb)::value) v += *reinterpret_cast<const f32x4*>(a.rowbias + (size_t)rbrow * a.ldrb + n);
+          if (decltype(relu)::value) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          if (decltype(has_r)::value) v += *reinterpret_cast<const f32x4*>(a.R + (decltype(frag)::value ? x32_off(row, n, a.ldr) : (size_t)row * a.ldr + n));
+          *reinterpret_cast<f32x4*>(a.Y + (decltype(frag)::value ? x32_off(row, n, a.ldy) : (size_t)row * a.ldy + n)) = v;
+        }
+    };
+    using T = std::true_type; using F = std::false_type;
+    auto pick_frag = [&](auto has_b, auto has_rb, auto relu, auto has_r) { if (a.y_frag) emit(has_b, has_rb, relu, has_r, T{}); else emit(has_b, has_rb, relu, has_r, F{}); };
+    auto pick_r = [&](auto has_b, auto has_rb, auto relu) { if (a.R) pick_frag(has_b, has_rb, relu, T{}); else pick_frag(has_b, has_rb, relu, F{}); };
+    auto pick_relu = [&](auto has_b, auto has_rb) { if (a.act == ACT_RELU) pick_r(has_b, has_rb, T{}); else pick_r(has_b, has_rb, F{}); };
+    auto pick_rb = [&](auto has_b) { if (a.rowbias) pick_relu(has_b, T{}); else pick_relu(has_b, F{}); };
+    if (a.bias) pick_rb(T{}); else pick_rb(F{});
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < C; ++j)
 #pragma unroll
