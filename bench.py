@@ -777,10 +777,11 @@ def run(argv=None):
             'replay_check': replay_check,
             'pipeline': None if not coschedule else {
                 'coscheduled_streams': True, 'stage_launch_ms_alone': k_avg, 'stage_launch_ms_beside_the_priors': beside,
-                'critical_cycle': 'round 5: period T = max(S, prep + I - R) + P + R with S the stage launch beside the next batch\'s infiller (27 ms; 22.1 alone), I that infiller '
-                                  'beside the stage (29 ms), P the trajectory predictor (4.2 ms: LDS kernels, after the stage has retired), R scene assembly + skinning + forward-only '
-                                  'launch (3.5 ms), prep 1 ms: both sides of the max within a millisecond, only P enters undivided (profiles/r05_chain_trace.log, r05_gap_trace.log).  '
-                                  'Measured and without effect: stage priority 0 / 1 / 3, a third stream, the gate opened after the infiller, more waves per SIMD for the LDS-free GEMM '
+                'critical_cycle': 'round 5: per batch and stream -- preparation (ahead of the gate in the three-graph cut), infiller I beside the other batch\'s stage '
+                                  '(28 ms), then, when that stage has retired, skinning (1.4 ms, alone on the GPU: beside the next batch\'s first kernels it was measured to '
+                                  'read other workgroups\' LDS, see replay_check) and trajectory predictor P (4.3 ms, LDS kernels), gate, scene assembly + forward-only '
+                                  'launch (0.5 ms), stage S (27 ms beside the next infiller; 22.1 alone).  Period = I + skinning + P + gaps: the infiller\'s last kernel '
+                                  'ends 2.6 ms after the other batch\'s stage (profiles/r05_gap_trace.log), so the stage has slack and a faster infiller is a faster step '
                                   '(profiles/r05_pipeline_experiments.log)',
                 'note': 'two streams, batches staggered by GlobalReconOptimizer.pipeline_gate: a batch starts when the previous one\'s priors are done, so its '
                         'motion infiller -- LDS-free one-wave kernels on fragment-major activations (csrc/nn_free.hpp) -- runs in the SIMD issue slots and '
