@@ -9,6 +9,7 @@
 #include "grecon_algo.hpp"
 #include "block_rt.hpp"
 #include <map>
+#include <memory>
 #include <set>
 #include <mutex>
 #include <tuple>
@@ -22,6 +23,7 @@ namespace GLAMR_GRECON_NS {
 #define GLAMR_GRECON_MAX_THREADS 512
 #endif
 constexpr int MAX_THREADS = GLAMR_GRECON_MAX_THREADS;
+static_assert(MAX_THREADS <= 512, "DeviceRT::scan_multi / scan_regs fetch the wave totals of a workgroup as two float4 reads: at most 8 waves (block_rt.hpp)");
 #ifndef GLAMR_GRECON_WAVES_PER_EU
 #define GLAMR_GRECON_WAVES_PER_EU 2
 #endif
@@ -109,10 +111,18 @@ namespace {
 #ifndef GLAMR_GRECON_WIDE
 // completion event of the last stage launch per workspace: glamr_grecon_last_launch_ns waits for THAT launch only, not for the device
 std::mutex g_ws_mu;
-std::map<const void*, hipEvent_t> g_ws_event;      // (an EVENT, not the stream handle: the caller may destroy its stream; an event outlives it)
-void forget_workspaces_locked() {
-  for (auto& kv : g_ws_event) (void)hipEventDestroy(kv.second);
-  g_ws_event.clear();
+// (an EVENT, not the stream handle: the caller may destroy its stream; an event outlives it.  Shared ownership: a thread that waits for a launch
+// holds a reference, NOT the table's mutex -- launches on other workspaces, streams and threads go on while it waits)
+struct LaunchEvent {
+  hipEvent_t ev = nullptr;
+  ~LaunchEvent() { if (ev) (void)hipEventDestroy(ev); }
+};
+std::map<const void*, std::shared_ptr<LaunchEvent>> g_ws_event;
+void forget_workspaces_locked() { g_ws_event.clear(); }
+std::shared_ptr<LaunchEvent> new_launch_event() {
+  auto e = std::make_shared<LaunchEvent>();
+  if (hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e->ev = nullptr; return nullptr; }
+  return e;
 }
 void record_launch(const void* workspace, hipStream_t stream);
 #endif
@@ -306,15 +316,14 @@ void record_launch(const void* workspace, hipStream_t stream) {
     if (cap == hipStreamCaptureStatusNone) {
       if (g_ws_event.size() > 4096) forget_workspaces_locked();      // callers that never ask for the stamps
       auto it = g_ws_event.find(workspace);
+      // an event somebody is waiting on keeps standing for the launch it was recorded after: this launch gets a new one
+      if (it != g_ws_event.end() && it->second.use_count() > 1) { g_ws_event.erase(it); it = g_ws_event.end(); }
       if (it == g_ws_event.end()) {
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) it = g_ws_event.emplace(workspace, ev).first;
-        else (void)hipGetLastError();
+        if (auto e = new_launch_event()) it = g_ws_event.emplace(workspace, std::move(e)).first;
       }
-      if (it != g_ws_event.end() && hipEventRecord(it->second, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(it->second); g_ws_event.erase(it); }
+      if (it != g_ws_event.end() && hipEventRecord(it->second->ev, stream) != hipSuccess) { (void)hipGetLastError(); g_ws_event.erase(it); }
     } else {
-      auto it = g_ws_event.find(workspace);
-      if (it != g_ws_event.end()) { (void)hipEventDestroy(it->second); g_ws_event.erase(it); }
+      g_ws_event.erase(workspace);
     }
   }
 }
@@ -385,14 +394,18 @@ extern "C" int glamr_grecon_last_launch_ns(const void* workspace, double* ns) {
   unsigned long long st[2];
   // the stamps are read on the stream the launch ran on: this waits for the work of THAT stream, not for the device (a pipelined caller
   // keeps its other streams running).  A workspace this library has not seen a launch on falls back to a device-wide wait.
-  // The launch's own completion event: waits for that launch, not for the device.  The table's mutex is HELD across the wait: another thread's
-  // launch on the same workspace (record_launch) or the table's clean-up may destroy the event otherwise, while this thread still waits on it.
-  // (Launches on other workspaces queue behind the mutex for the duration of the wait; the stamps are asked for by measuring code.)
+  // The launch's own completion event: waits for that launch, not for the device.  The table's mutex only covers the look-up; the wait holds a
+  // reference to the event, so another thread's launch on the same workspace (record_launch) or the table's clean-up cannot destroy it under this
+  // thread, and launches on any workspace proceed while it waits.
   bool waited = false;
   {
-    std::lock_guard<std::mutex> lock(g_ws_mu);
-    auto it = g_ws_event.find(workspace);
-    if (it != g_ws_event.end()) waited = hipEventSynchronize(it->second) == hipSuccess;
+    std::shared_ptr<LaunchEvent> e;
+    {
+      std::lock_guard<std::mutex> lock(g_ws_mu);
+      auto it = g_ws_event.find(workspace);
+      if (it != g_ws_event.end()) e = it->second;
+    }
+    if (e) waited = hipEventSynchronize(e->ev) == hipSuccess;
   }
   if (!waited) {
     (void)hipGetLastError();

@@ -38,6 +38,17 @@ __host__ __device__ inline size_t x32_off(int row, int col, int ld) {
 // 16 at compile time (0: run time); PD: operands that many k steps ahead.  MAXW: waves per SIMD the register allocation aims at.
 // (Measured and dropped: 2- and 3-wave workgroups marching through the same weight fragments with a barrier per k step, for L1 hits --
 // no change; 64 x 64 / 64 x 128 tiles -- faster alone, slower beside the stage, where one 230-register wave per SIMD hides nothing.)
+// The value of lane ^ 32 (the other half of the wave): v_permlane32_swap_b32, a register-file exchange.  NOT __shfl_xor(x, 32): that is
+// ds_bpermute_b32, which goes through the CU's LDS pipeline -- and the kernels of this file run, by design, beside another kernel's workgroups
+// that are in the middle of LDS traffic.  See DESIGN.md 5 ("the pipeline corruption"): a ds_bpermute issued by a wave of a workgroup WITHOUT an
+// LDS allocation, while a neighbouring workgroup's ds_read_b128 is in flight on the same CU, was measured to leave the upper lanes of that read
+// with stale register contents.
+__device__ __forceinline__ float lane_xor32(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 template <int KS, int C, int PD, int MAXW>
 __global__ __launch_bounds__(64, MAXW) void gemm_free_kernel(GemmArgs a) {
   const int lane = threadIdx.x, c = lane & 31, kg = lane >> 5;
@@ -176,6 +187,14 @@ template <int C, int PD, int MAXW>
 inline int launch_gemm_free_t(hipStream_t st, const GemmArgs& a) {
   const int ncb = (a.N + 32 * C - 1) / (32 * C), nrb = (a.M + 31) / 32;
   const dim3 grid((unsigned)((nrb + 7) / 8 * 8 * ncb)), block(64);
+#ifdef GLAMR_RACE_PROBE
+  if (std::getenv("GLAMR_NETS_PROBE_LOG"))
+    std::fprintf(stderr, "gemm_free: X %p W %p bias %p rowbias %p R %p Y %p M %d N %d K %d ldx %d ldy %d ldr %d rpg %d ldrb %d act %d Ws %p ws_plane %zu x_frag %d y_frag %d grid %u\n", (const void*)a.X, (const void*)a.W,
+                 (const void*)a.bias, (const void*)a.rowbias, (const void*)a.R, (void*)a.Y, a.M, a.N, a.K, a.ldx, a.ldy, a.ldr, a.rows_per_group, a.ldrb, a.act, (const void*)a.Ws, a.ws_plane, a.x_frag, a.y_frag, grid.x);
+#endif
+#ifdef GLAMR_RACE_PROBE      // probe builds: GLAMR_NETS_PROBE_GENERIC_K=<k steps> sends that depth to the run-time-depth instance (another register allocation)
+  if (const char* e = std::getenv("GLAMR_NETS_PROBE_GENERIC_K")) if (std::atoi(e) == a.K / 16) { hipLaunchKernelGGL((gemm_free_kernel<0, C, PD, MAXW>), grid, block, 0, st, a); return GLAMR_OK; }
+#endif
   switch (a.K / 16) {
     case 2: hipLaunchKernelGGL((gemm_free_kernel<2, C, PD, MAXW>), grid, block, 0, st, a); break;
     case 6: hipLaunchKernelGGL((gemm_free_kernel<6, C, PD, MAXW>), grid, block, 0, st, a); break;
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void ln_free_kernel(const float* X, const fl
     load(s, u, w);
     sum += ((u[0] + u[1]) + (u[2] + u[3])) + ((w[0] + w[1]) + (w[2] + w[3]));
   }
-  sum += __shfl_xor(sum, 32);
+  sum += lane_xor32(sum);
   const float mean = sum * (1.0f / 256.0f);
   float sq = 0.f;
 #pragma unroll 4
@@ -222,7 +241,7 @@ __global__ __launch_bounds__(64, 4) void ln_free_kernel(const float* X, const fl
     u -= mean; w -= mean;
     sq += ((u[0] * u[0] + u[1] * u[1]) + (u[2] * u[2] + u[3] * u[3])) + ((w[0] * w[0] + w[1] * w[1]) + (w[2] * w[2] + w[3] * w[3]));
   }
-  sq += __shfl_xor(sq, 32);
+  sq += lane_xor32(sq);
   const float rstd = 1.0f / sqrtf(sq * (1.0f / 256.0f) + 1e-5f);
   if ((int)blockIdx.x * 32 + (lane & 31) >= rows) return;
 #pragma unroll 4
@@ -240,6 +259,9 @@ __global__ __launch_bounds__(64, 4) void ln_free_kernel(const float* X, const fl
 // attention_mfma_kernel without LDS: the value rows are gathered from global memory in the key order the probabilities sit in, the key
 // mask is one ballot.  Same arithmetic in the same order.  K, V, O fragment-major; Q too unless q_shared (the prior's two token queries:
 // one row-major table for every sequence).
+#ifndef GLAMR_ATTN_ABLATE      // probe builds (tools/race_mini.py): which part of this kernel disturbs a neighbouring workgroup -- wrong results by design
+#define GLAMR_ATTN_ABLATE 0
+#endif
 __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
                                                                float* O, int ldo, int Lq, int Lk, int q_shared) {
   const int b = blockIdx.x >> 3, h = blockIdx.x & 7, lane = threadIdx.x, c = lane & 31, kg = lane >> 5;
@@ -275,7 +297,10 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
       sc[kt][qt] = (f32x16){0};
       if ((kt == 0 || two_k) && (qt == 0 || two_q)) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) sc[kt][qt] = mfma3(kh_[kt][s], kl_[kt][s], qh_[qt][s], ql_[qt][s], sc[kt][qt]);
+        for (int s = 0; s < 2; ++s) {
+          if (GLAMR_ATTN_ABLATE & 8) { for (int e = 0; e < 16; ++e) sc[kt][qt][e] += (float)kh_[kt][s][e & 7] * (float)qh_[qt][s][e & 7] + (float)kl_[kt][s][e & 7] + (float)ql_[qt][s][e & 7]; }
+          else sc[kt][qt] = mfma3(kh_[kt][s], kl_[kt][s], qh_[qt][s], ql_[qt][s], sc[kt][qt]);
+        }
       }
     }
   float inv[2];
@@ -295,19 +320,19 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
         mx = fmaxf(mx, v);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = fmaxf(mx, lane_xor32(mx));
     float den = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       if (kt == 1 && !two_k) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = (mx > -INFINITY) ? __expf(sc[kt][qt][r] - mx) : 0.f;
+        const float p = (mx > -INFINITY) ? ((GLAMR_ATTN_ABLATE & 1) ? 1.0f + 0.001f * (sc[kt][qt][r] - mx) : __expf(sc[kt][qt][r] - mx)) : 0.f;
         sc[kt][qt][r] = p;
         den += p;
       }
     }
-    den += __shfl_xor(den, 32);
+    den += lane_xor32(den);
     inv[qt] = den > 0.f ? 1.0f / den : 0.f;
   }
   f32x16 oc[2] = {(f32x16){0}, (f32x16){0}};
@@ -320,7 +345,7 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int key = 32 * kt + 16 * u + (j & 3) + 8 * (j >> 2) + 4 * kg;
-        vx[j] = key < Lk ? V[x32_off(b * Lk + key, h * 32 + c, ldk)] : 0.f;
+        vx[j] = (GLAMR_ATTN_ABLATE & 4) ? (float)key : (key < Lk ? V[x32_off(b * Lk + key, h * 32 + c, ldk)] : 0.f);
       }
       f16x8 vh, vl;
       split8(vx, vh, vl);
@@ -332,7 +357,8 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
         for (int j = 0; j < 8; ++j) px[j] = sc[kt][qt][8 * u + j];
         f16x8 ph, pl;
         split8(px, ph, pl);
-        oc[qt] = mfma3(vh, vl, ph, pl, oc[qt]);
+        if (GLAMR_ATTN_ABLATE & 2) { for (int e = 0; e < 16; ++e) oc[qt][e] += (float)vh[e & 7] * (float)ph[e & 7] + (float)vl[e & 7] + (float)pl[e & 7]; }
+        else oc[qt] = mfma3(vh, vl, ph, pl, oc[qt]);
       }
     }
   }

@@ -244,15 +244,8 @@ class SMPL(nn.Module):
         h, L = self._handle(dev), _lib.lib()
         joints = torch.empty((B, self.n_out, 3), device=dev, dtype=torch.float32)
         ws = torch.empty(L.glamr_smpl_workspace_bytes(h, B), device=dev, dtype=torch.uint8)
-        pose_before = body_pose.clone() if os.environ.get('GLAMR_DEBUG_KEEP_SKIN_WS') else None
         _lib.check(L.glamr_smpl_forward(h, B, _lib.ptr(body_pose), _lib.ptr(betas), _lib.ptr(z), None, None, _lib.ptr(joints), 2, _lib.ptr(ws),
                                         _lib.current_stream()))
-        if os.environ.get('GLAMR_DEBUG_KEEP_SKIN_WS'):      # development aid (tools/gate_race_probe.py): the chain joints of the workspace, snapshot in stream order
-            bpad = (B + 31) // 32 * 32
-            off = bpad * 4 * (224 + 224 + 288 + 384)
-            snap = ws[off:off + bpad * 72 * 4].clone().view(torch.float32).view(bpad, 24, 3)
-            self.__dict__.setdefault('_dbg_chain', {})[(bool(torch.cuda.is_current_stream_capturing()), torch.cuda.current_stream(dev).cuda_stream)] = \
-                (snap, body_pose.clone(), betas.clone(), pose_before)
         return joints
 
     def get_joints(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, root_trans=None, root_scale=None,

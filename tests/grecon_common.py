@@ -181,8 +181,9 @@ KSTEP_TOL = {   # achieved (MI355X / CPU runtime):           kp px            ro
     # With the suffix sum of the planar-position gradient in the Hillis-Steele order (ds_bpermute shuffles, rounds 1-3) or sequential (CPU
     # runtime) that sign comes out as the reference's: 0.002 px; in the DPP row-shift order (round 4: another order of the same
     # exact-on-integers sums, tests/test_scan_gpu.py) it did not: 0.20 px, and round 4 widened this bound to 0.6.  Round 5: the instances that
-    # derive the camera from the person keep the Hillis-Steele order for that ONE scan (grecon_algo.hpp `gxy_shuffle`; the other instances
-    # and the other three scans stay on DPP), and the bound is back where it was.
+    # derive the camera from the person keep the Hillis-Steele order for ALL FOUR scans of the iteration (grecon_algo.hpp `scan_shuffle =
+    # cam_from_person`; with that order on the planar-gradient scan alone it was still 0.20 px -- the forward sums feed the same sign); the
+    # other instances stay on DPP, and the bound is back where it was.
     ('glamr_3dpw', 120, 1): (0.01, 1e-6, 1e-6),               # 0.002 / 0.002    (the person's world pose is not compared)
     ('glamr_h36m', 100, 2): (0.55, 2e-5, 9e-4),               # 0.074 / 0.177    2.4e-6 / 5.0e-6   2.8e-4 / 2.6e-4
     ('glamr_static_multi', 300, 4): (0.05, 6e-5, 1.1e-3),     # 0.012 / 0.015    1.2e-5 / 1.9e-5   3.5e-4 / 3.3e-4

@@ -12,7 +12,7 @@ if [ -n "$GLAMR_VARIANT_ALGO" ]; then
   cp "$GLAMR_VARIANT_ALGO" /tmp/variant_$name/glamr_amd/csrc/grecon_algo.hpp
   SRC=/tmp/variant_$name/glamr_amd/csrc
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" -c $SRC/grecon.hip -o /tmp/grecon_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${GLAMR_VARIANT_PACKED:--Xclang -target-feature -Xclang -packed-fp32-ops} -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" -c $SRC/grecon.hip -o /tmp/grecon_$name.o
 objs=$(ls $B/*.o | grep -v "/grecon.hip.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/grecon_$name.o -o tools/_lib_$name.so
 echo built tools/_lib_$name.so

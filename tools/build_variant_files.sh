@@ -13,7 +13,7 @@ for f in $files; do
     grecon.hip|grecon_wide.hip) extra="-fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize";;
     init.hip) extra="-ffp-contract=off";;
   esac
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra "$@" -c glamr_amd/csrc/$f -o /tmp/${f}_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${GLAMR_VARIANT_PACKED:--Xclang -target-feature -Xclang -packed-fp32-ops} $extra "$@" -c glamr_amd/csrc/$f -o /tmp/${f}_$name.o
   objs="$objs /tmp/${f}_$name.o"
   skip="$skip|/$f.o"
 done
