@@ -515,30 +515,45 @@ def run(argv=None):
         if len(keep) > 2 * len(streams):
             keep.pop(0)
 
-    def replay_check_of(graphs):
-        """The two streams' graphs replayed alternately as in the timed loop, every replay with the SAME generator state (torch's graphs take
-        seed and offset at replay time), must leave in each graph's arrays exactly what ONE plain step with that state leaves -- projections
-        and every optimised parameter, bit for bit.  (capture_resident checks each graph alone; this checks them beside each other: a race
-        between the streams' replays shows up here and nowhere in a timing.)"""
+    def replay_check_of(graphs, pairs=4):
+        """The streams' step graphs replayed alternately as in the timed loop, under TWO generator states that swap between the graphs from pair to
+        pair (torch's graphs take seed and offset at replay time), with the output arrays poisoned before every pair: each replay must leave in its
+        graph's arrays exactly what ONE plain step with that state leaves -- projections, every optimised parameter, cached joints, camera -- bit
+        for bit.  A value read from the other stream, left over from the previous replay, or computed wrong beside the other stream's kernels is a
+        difference here and nowhere in a timing (round 6: profiles/r06_pipeline_corruption.log)."""
+        keys = ('kp_2d_pred', 'params', 'j_local', 'cam_pose')
         with torch.random.fork_rng(devices=[dev]):
-            seed = 20260927
-            torch.manual_seed(seed)
-            with torch.cuda.stream(streams[0]):
-                _, ref = model.optimize_resident(rin)
-            sync()
-            want = {k: ref.t[k].clone() for k in ('kp_2d_pred', 'params')}
-            n_rep = 4 * len(graphs)
-            for i in range(n_rep):
+            seeds = (20260927, 20260928)
+            want = {}
+            for seed in seeds:
                 torch.manual_seed(seed)
-                graphs[i % len(graphs)].replay()
-            sync()
-            worst, equal = 0.0, True
-            for g in graphs:
-                for k, w in want.items():
-                    got = g.packed.t[k]
-                    equal = equal and bool(torch.isfinite(got).all()) and torch.equal(got, w)
-                worst = max(worst, float((g.packed.t['kp_2d_pred'] - want['kp_2d_pred']).abs().max()))
-        return {'replays': n_rep, 'streams': len(graphs), 'bit_identical_to_one_plain_step': equal, 'max_projection_difference_px': worst}
+                with torch.cuda.stream(streams[0]):
+                    _, ref = model.optimize_resident(rin)
+                sync()
+                want[seed] = {k: ref.t[k].clone() for k in keys}
+            gate_now = getattr(model, 'pipeline_gate', None)
+            if gate_now is not None:
+                gate_now.last = None
+            worst, equal, n_rep = 0.0, True, 0
+            for pair in range(pairs):
+                for g in graphs:
+                    for k in keys:
+                        g.packed.t[k].fill_(float('nan'))
+                sync()
+                used = {}
+                for i, g in enumerate(graphs if pair % 2 == 0 else graphs[::-1]):
+                    used[id(g)] = seeds[(pair + i) % 2]
+                    torch.manual_seed(used[id(g)])
+                    g.replay()
+                    n_rep += 1
+                sync()
+                for g in graphs:
+                    for k in keys:
+                        got, w = g.packed.t[k], want[used[id(g)]][k]
+                        equal = equal and bool(torch.isfinite(got).all()) and torch.equal(got, w)
+                    d = (g.packed.t['kp_2d_pred'] - want[used[id(g)]]['kp_2d_pred']).abs().max()
+                    worst = max(worst, float(d) if bool(torch.isfinite(d)) else float('inf'))
+        return {'replays': n_rep, 'streams': len(graphs), 'seeds': len(seeds), 'arrays': list(keys), 'bit_identical_to_plain_steps': equal, 'max_projection_difference_px': worst}
 
     gate_cut = None
     graph_step = on_gpu and not args.no_graph_step
@@ -550,26 +565,18 @@ def run(argv=None):
         # every stream has run the step once (allocations, attribute calls, the priors' own graph): capture it, one graph per stream, through
         # the product's own entry point (GlobalReconOptimizer.capture_resident: capture + bit-for-bit check of a replay against a plain step)
         try:
-            # The pipelined step is captured with the preparation AHEAD of the gate (GLAMR_GATE_PREP=early: three graphs per step, 35.7 against
-            # 38.5 ms; the library's default is the two-graph cut) -- and kept only if the two streams' replays reproduce one plain step bit for
-            # bit right here, before the clock starts; otherwise the default cut is captured instead.  The same check runs again after the clock.
-            gate_cut = 'default (two graphs)'
-            if coschedule and 'GLAMR_GATE_PREP' not in os.environ and not args.no_early_prep:
-                os.environ['GLAMR_GATE_PREP'] = 'early'
-                try:
-                    step_graphs = [model.capture_resident(rin, stream=st, check=True) for st in streams]
-                    sync()
-                    pre = replay_check_of(step_graphs)
-                    if pre['bit_identical_to_one_plain_step']:
-                        gate_cut = 'preparation ahead of the gate (three graphs), verified before and after the timed region'
-                    else:
-                        sys.stderr.write('bench: the three-graph cut did not reproduce the plain step (%.3g px): the default cut is used\n' % pre['max_projection_difference_px'])
-                        step_graphs = None
-                finally:
-                    if step_graphs is None:
-                        del os.environ['GLAMR_GATE_PREP']
-            if step_graphs is None:
-                step_graphs = [model.capture_resident(rin, stream=st, check=True) for st in streams]
+            # The library's default cut under a gate is preparation | priors + skinning | rest (three graphs: the preparation does not wait for the
+            # gate); --no-early-prep times the two-graph cut.  The streams' replays must reproduce plain steps bit for bit right here, before the
+            # clock starts, and again after it: a failed check is an ERROR (exit code 1), not a warning.
+            if coschedule and args.no_early_prep:
+                os.environ['GLAMR_GATE_PREP'] = 'late'
+            gate_cut = None if not coschedule else ('two graphs (--no-early-prep)' if os.environ.get('GLAMR_GATE_PREP', 'early') == 'late'
+                                                    else 'preparation ahead of the gate (three graphs, the library default)')
+            step_graphs = [model.capture_resident(rin, stream=st, check=True) for st in streams]
+            sync()
+            pre = replay_check_of(step_graphs, pairs=2)
+            if not pre['bit_identical_to_plain_steps']:
+                raise SystemExit('bench: the step graphs do not reproduce plain steps BEFORE the timed region (max %.3g px)' % pre['max_projection_difference_px'])
             sync()
             eager_step = step
 
@@ -596,17 +603,14 @@ def run(argv=None):
     if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
-    # What the timed region computed, checked after the clock has stopped (replay_check_of above)
+    # What the timed region computed, checked after the clock has stopped (replay_check_of above): a difference is an error, no number is printed
     replay_check = None
     if step_graphs and on_gpu:
-        try:
-            replay_check = replay_check_of(step_graphs)
-            replay_check['gate_cut'] = gate_cut
-            if not replay_check['bit_identical_to_one_plain_step']:
-                sys.stderr.write('bench: the pipelined replays do NOT reproduce the plain step (max %.3g px): the value below is a timing of wrong results\n'
-                                 % replay_check['max_projection_difference_px'])
-        except Exception as e:      # noqa: BLE001
-            sys.stderr.write('bench: replay check not run (%s)\n' % e)
+        replay_check = replay_check_of(step_graphs)
+        replay_check['gate_cut'] = gate_cut
+        if not replay_check['bit_identical_to_plain_steps']:
+            raise SystemExit('bench: the pipelined replays do NOT reproduce plain steps (max %.3g px): no number is reported for a timing of wrong results'
+                             % replay_check['max_projection_difference_px'])
     beside = None
     if coschedule:
         # what a stage launch takes in THIS pipeline (beside the other stream's priors): four more gated steps as plain launches, whose
@@ -621,7 +625,7 @@ def run(argv=None):
             sys.stderr.write('bench: co-scheduled stage launches not measured (%s)\n' % e)
         del stage_events[:]
         model.pipeline_gate = None                                   # the single-stream measurements below run the plain step
-    if gate_cut is not None and gate_cut.startswith('preparation'):
+    if coschedule and args.no_early_prep:
         os.environ.pop('GLAMR_GATE_PREP', None)                      # (set above for this pipeline only: a caller in the same process keeps its own setting)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     n_total = parallel.sum_over_ranks(B, dev)                      # units all ranks processed per step

@@ -14,7 +14,6 @@
 #include "common.hpp"
 #define GLAMR_ROTMATH_IEEE 1      // see rotmath.hpp: this translation unit follows the reference's CPU operators as closely as fp32 allows
 #include "rotmath.hpp"
-#include "race_probe.hpp"
 
 namespace glamr {
 namespace init {
@@ -271,9 +270,6 @@ __global__ __launch_bounds__(256) void init_scene_kernel(SceneInitArgs a) {
   const int si = blockIdx.x, T = b.max_len, MP = b.max_persons, P = b.n_persons[si], n_fr = b.seq_len[si];
   const float base[4] = {0.5f, 0.5f, 0.5f, 0.5f}, basec[4] = {0.5f, -0.5f, -0.5f, -0.5f};
   float* vis_w = const_cast<float*>(b.vis);
-#ifdef GLAMR_RACE_PROBE
-  if (threadIdx.x == 0 && !(a.flags & GLAMR_INIT_POSE_SCATTERED)) probe::producer_start(a.smpl_pose);
-#endif
   // ---- scatter of the prior outputs into video-frame positions; person transforms --------------------------------------------
   for (int p = 0; p < P; ++p) {
     const size_t slot = (size_t)si * MP + p, o1 = slot * T;
@@ -299,10 +295,6 @@ __global__ __launch_bounds__(256) void init_scene_kernel(SceneInitArgs a) {
   }
   if (threadIdx.x == 0) s_start = T;
   __syncthreads();
-#ifdef GLAMR_RACE_PROBE
-  // (stamped at the very end of the kernel below as well: this one marks where the pose rows have been written)
-  if (threadIdx.x == 0 && !(a.flags & GLAMR_INIT_POSE_SCATTERED)) probe::producer_end(a.smpl_pose);
-#endif
   // ---- relative transforms between persons in the camera frame (:178-183); first frame anybody is seen in -----------------------
   for (int t = threadIdx.x; t < n_fr; t += blockDim.x) {
     bool any = false;
@@ -419,17 +411,10 @@ __global__ __launch_bounds__(256) void pose_scatter_kernel(glamr_scene_batch b, 
   if (slot - si * MP >= b.n_persons[si]) return;
   const size_t o1 = (size_t)slot * T;
   const int fs = b.fr_start[slot], n = b.fr_end[slot] - fs;
-#ifdef GLAMR_RACE_PROBE
-  if (threadIdx.x == 0) probe::producer_start(smpl_pose);
-#endif
   for (int idx = threadIdx.x; idx < n * 69; idx += blockDim.x) {
     const int e = idx / 69, k = idx - e * 69;
     smpl_pose[(o1 + fs + e) * 69 + k] = n_pose[(o1 + e) * 69 + k];
   }
-#ifdef GLAMR_RACE_PROBE
-  __syncthreads();
-  if (threadIdx.x == 0) probe::producer_end(smpl_pose);
-#endif
 }
 
 // init_cam_pose(all_frames=True): camera-to-world per frame from the first person where it is seen, zeros elsewhere
@@ -548,10 +533,6 @@ extern "C" int glamr_init_scatter_pose(const glamr_scene_batch* batch, const gla
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }
-
-#ifdef GLAMR_RACE_PROBE
-GLAMR_RACE_PROBE_EXPORT(glamr_debug_race_probe_init)
-#endif
 
 extern "C" int glamr_init_cam_all_frames(const glamr_scene_batch* batch, void* stream_) {
   GLAMR_REQUIRE(batch, "null argument");

@@ -414,31 +414,6 @@ thread_local int tl_fp32 = 0;
 // the optimiser stage (large batches: the other stream of a pipelined caller is inside a stage launch most of the time);
 // GLAMR_NETS_FREE=0 keeps the fused LDS kernels (A/B runs)
 thread_local int tl_free = 0;
-#ifdef GLAMR_RACE_PROBE
-// probe builds (tools/race_probe.py): GLAMR_NETS_PROBE_SPIN=<position>:<microseconds> parks the stream at one point of the launch sequence
-__global__ void probe_spin_kernel(unsigned long long ticks) {
-  const unsigned long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-static void probe_spin(hipStream_t st, int pos) {
-  const char* e = std::getenv("GLAMR_NETS_PROBE_SPIN");
-  if (!e) return;
-  int want = 0, us = 0;
-  if (std::sscanf(e, "%d:%d", &want, &us) == 2 && want == pos) hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)us * 100ull);
-}
-thread_local int tl_probe_first = 0, tl_probe_stopped = 0;
-// GLAMR_NETS_PROBE_STOP=<position>: the launch sequence ends there (what is left of the priors is not enqueued: wrong results, by design)
-static bool probe_stop(int pos) {
-  const char* e = std::getenv("GLAMR_NETS_PROBE_STOP");
-  if (e && std::atoi(e) == pos) tl_probe_stopped = 1;
-  return tl_probe_stopped != 0;
-}
-#define GLAMR_PROBE_SPIN(st, pos) do { probe_spin(st, pos); if (probe_stop(pos)) return GLAMR_OK; } while (0)
-#define GLAMR_PROBE_SPIN_FIRST(st, pos) do { if (tl_probe_first) { probe_spin(st, pos); if (probe_stop(pos)) return GLAMR_OK; } } while (0)
-#else
-#define GLAMR_PROBE_SPIN(st, pos) ((void)0)
-#define GLAMR_PROBE_SPIN_FIRST(st, pos) ((void)0)
-#endif
 inline size_t cp(int col) { return tl_free ? (size_t)col * 32 : (size_t)col; }      // pointer offset of column `col` (a multiple of 16) in either layout
 inline bool free_wanted(int flags) {
   const char* e = std::getenv("GLAMR_NETS_FREE");      // read per call: A/B runs switch it inside one process
@@ -525,7 +500,6 @@ int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const flo
   static const bool res_in_ln = std::getenv("GLAMR_NETS_RES_IN_LN") != nullptr;      // development aid (A/B)
   if (tl_free && !res_in_ln) {      // the residual in the GEMM's epilogue (same sum, same order): the three-pass LayerNorm then streams ONE array
     RC(lin(st, L, X, D, tmp, D, M, ACT_NONE, R, D));
-    GLAMR_PROBE_SPIN_FIRST(st, 15);
     return ln(st, tmp, nullptr, n, Y, M);
   }
   RC(lin(st, L, X, D, tmp, D, M));
@@ -844,12 +818,9 @@ int encoder_layer(hipStream_t st, const EncLayer& E, Ws& w, float* h_in, float* 
     RC(launch_qkv_attention(st, B, QkvAttnArgs{h_in, WIN, h_in, WIN, E.qkv.Ws, pl, E.qkv.b, 0, E.qkv.Ws, pl, E.qkv.b, 8, 16, w.mask, w.att, D}));
   } else {
     RC(lin(st, E.qkv, h_in, D, w.qkv, 3 * D, M));
-    GLAMR_PROBE_SPIN_FIRST(st, 12);
     launch_attention( dim3(B, 8), dim3(64), 0, st, w.qkv, 3 * D, w.qkv + cp(D), w.qkv + cp(2 * D), 3 * D, w.mask, w.att, D, WIN, WIN, 0);
-    GLAMR_PROBE_SPIN_FIRST(st, 13);
   }
   RC(proj_ln(st, E.o, E.n1, w.att, h_in, h_out, w.tmp, M));
-  GLAMR_PROBE_SPIN_FIRST(st, 14);
   RC(mlp2(st, E.f1, E.f2, &E.n2, h_out, D, h_out, h_out, w.ff, w.tmp, M, ACT_NONE));
   return GLAMR_OK;
 }
@@ -1029,11 +1000,8 @@ __global__ __launch_bounds__(256) void traj_to_global2_kernel(const float* raw, 
 int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const float* eps, int eps_stride, float* q_out, float* p_out) {
   const int M = B * WIN;
   RC(lin(st, h->enc_in, w.x, XLD, w.h0, D, M, ACT_NONE, nullptr, 0, h->enc_pe, -WIN, D, 0));      // (w.x is row-major in every mode)      // + the position table, in the GEMM's epilogue
-  GLAMR_PROBE_SPIN_FIRST(st, 5);
   RC(encoder_layer(st, h->enc[0], w, w.h0, w.h1, B));
-  GLAMR_PROBE_SPIN_FIRST(st, 6);
   RC(encoder_layer(st, h->enc[1], w, w.h1, w.h0, B));
-  GLAMR_PROBE_SPIN_FIRST(st, 7);
   float* ctx = w.h0;
   if (mode != GLAMR_VAE_INFER) {
     // posterior: [mu token, logvar token, 30 current frames] attend to each other and to the context (DataEncoder.forward :204-249)
@@ -1055,7 +1023,6 @@ int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const
   RC(lin(st, h->prior_f1, w.dq, D, w.ff, FF, B * 2, ACT_RELU));
   RC(lin(st, h->prior_f2, w.ff, FF, w.tmp, D, B * 2));
   RC(ln(st, w.tmp, w.dq, h->prior_n3, w.dq, B * 2));
-  GLAMR_PROBE_SPIN_FIRST(st, 8);
   RC(lin(st, h->prior_pz, w.dq, D, w.pz, D, B * 2, ACT_NONE, nullptr, 0, nullptr, 1, 0, -1, 0));      // row-major out: elementwise kernels read it
   if (p_out) hipLaunchKernelGGL(dist_out_kernel, dim3(B), dim3(NZ), 0, st, w.pz, p_out);
   if (mode == GLAMR_VAE_INFER) hipLaunchKernelGGL(reparam_infiller_kernel, dim3(B), dim3(64), 0, st, w.pz, eps, eps_stride, w.z, B);
@@ -1064,11 +1031,8 @@ int infiller_window(glamr_nets* h, hipStream_t st, Ws& w, int B, int mode, const
   // decoder: 30 queries = position code of z
   RC(lin(st, h->dec_z, w.z, NZ, w.zproj, D, B, ACT_NONE, nullptr, 0, nullptr, 1, 0, 0, 0));
   hipLaunchKernelGGL(build_queries_kernel, dim3(B, CUR), dim3(64), 0, st, w.zproj, h->dec_pe, w.dq, tl_free);
-  GLAMR_PROBE_SPIN_FIRST(st, 9);
   RC(decoder_layer(st, h->dec[0], w, w.dq, ctx, B, CUR));
-  GLAMR_PROBE_SPIN_FIRST(st, 10);
   RC(decoder_layer(st, h->dec[1], w, w.dq, ctx, B, CUR));
-  GLAMR_PROBE_SPIN_FIRST(st, 11);
   RC(mlp2(st, h->out1, h->out2, nullptr, w.dq, D, nullptr, w.tmp, w.ff, w.tmp, B * CUR, ACT_RELU));
   RC(lin(st, h->outfc, w.tmp, D, w.y, 128, B * CUR, ACT_NONE, nullptr, 0, nullptr, 1, 0, -1, 0));
   return GLAMR_OK;
@@ -1141,38 +1105,17 @@ int traj_pass(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, const in
 
 }  // namespace
 
-
 namespace {
 // the launch sequence of glamr_nets_infer (w.lens already holds the lengths)
 int enqueue_infer(glamr_nets* h, hipStream_t st, Ws& w, int B, int max_len, int n_win, int n_win_max, bool do_infill, bool do_traj, const float* body_pose,
                   const float* visible, const float* motion_eps, const float* traj_eps, float* out_pose, float* out_local_traj, float* out_trans,
                   float* out_orient) {
-#ifdef GLAMR_RACE_PROBE
-  tl_probe_stopped = 0;
-#endif
-  GLAMR_PROBE_SPIN(st, 1);
-#ifdef GLAMR_RACE_PROBE
-  const int probe_skip = std::getenv("GLAMR_NETS_PROBE_SKIP") ? std::atoi(std::getenv("GLAMR_NETS_PROBE_SKIP")) : 0;
-  if (!(probe_skip & 1))
-#endif
   hipLaunchKernelGGL(pose_in_kernel, dim3(B, w.Tpad), dim3(64), 0, st, body_pose, max_len, w.Tpad, w.pose);
-  GLAMR_PROBE_SPIN(st, 2);
   // ---- motion infiller: autoregressive windows [30 i, 30 i + 50) ------------------------------------------------------------
   for (int i = 0; do_infill && i < n_win; ++i) {
     const int s = i * CUR;
-#ifdef GLAMR_RACE_PROBE
-    if (!(probe_skip & 2))
-#endif
     hipLaunchKernelGGL(window_gather_kernel, dim3(B, WIN), dim3(64), 0, st, w.pose, visible, w.lens, w.Tpad, max_len, s, w.x, w.mask);
-    if (i == 0) GLAMR_PROBE_SPIN(st, 3);
-#ifdef GLAMR_RACE_PROBE
-    tl_probe_first = (i == 0);
-#endif
     RC(infiller_window(h, st, w, B, GLAMR_VAE_INFER, motion_eps + (size_t)i * NZ, n_win_max * NZ, nullptr, nullptr));
-#ifdef GLAMR_RACE_PROBE
-    if (tl_probe_stopped) return GLAMR_OK;
-#endif
-    if (i == 0) GLAMR_PROBE_SPIN(st, 4);
     hipLaunchKernelGGL(window_scatter_kernel, dim3(B, CUR), dim3(64), 0, st, w.y, 128, w.lens, w.Tpad, s, w.pose);
   }
   if (out_pose) hipLaunchKernelGGL(pose_out_kernel, dim3(B, max_len), dim3(64), 0, st, w.pose, max_len, w.Tpad, w.lens, out_pose);
@@ -1232,13 +1175,10 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
     std::memcpy(pinned, lens_host, (size_t)B * sizeof(int32_t));
     lens_src = pinned;
   }
-  // Recorded into a caller's graph the upload is a KERNEL reading the pinned table (hipHostMalloc memory is device-visible), not a memcpy node:
-  // replays of two such graphs on two streams were measured to disturb each other when a graph started with memcpy nodes
-  // (profiles/r05_pipeline_experiments.log; GLAMR_NETS_LENS_MEMCPY=1 restores the copy node)
+  // Recorded into a caller's graph the upload is a KERNEL reading the pinned table (hipHostMalloc memory is device-visible); GLAMR_NETS_LENS_MEMCPY=1
+  // records a copy node instead.  (Round 5 blamed copy nodes at the start of a graph for the two-stream corruption; round 6 found the cause
+  // elsewhere -- packed-fp32 instructions, glamr_amd/build.py -- and both forms replay bit-identically: profiles/r06_pipeline_corruption.log.)
   static const bool lens_memcpy = std::getenv("GLAMR_NETS_LENS_MEMCPY") != nullptr;
-#ifdef GLAMR_RACE_PROBE
-  if (std::getenv("GLAMR_NETS_PROBE_NO_LENS")) { /* the lengths of the previous call stay */ } else
-#endif
   if (outer_capture && !lens_memcpy) hipLaunchKernelGGL(copy_ints_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.lens, lens_src, B);
   else GLAMR_HIP_CHECK(hipMemcpyAsync(w.lens, lens_src, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   auto enqueue = [&]() -> int {
@@ -1301,39 +1241,6 @@ extern "C" int glamr_nets_infer(glamr_nets* h, int B, int max_len, const int32_t
   }
   return enqueue();
 }
-
-#ifdef GLAMR_RACE_PROBE
-// probe builds: ONE launch of the infiller's first GEMM on caller-provided arrays (tools/race_mini.py)
-extern "C" int glamr_debug_gemm_free(const float* X, const float* rowbias, const unsigned short* Ws, float* Y, int M, void* stream_) {
-  nn::GemmArgs a{X, nullptr, nullptr, rowbias, nullptr, Y, M, 256, 96, 96, 256, 0, -50, 256, 0};
-  a.Ws = Ws; a.ws_plane = (size_t)256 * 96; a.x_frag = 0; a.y_frag = 1;
-  return nn::launch_gemm_free(static_cast<hipStream_t>(stream_), a);
-}
-#endif
-
-#ifdef GLAMR_RACE_PROBE
-// probe builds: the infiller's first GEMM with the handle's own weights and position table on caller-provided rows (which & 1: the caller's Ws /
-// rowbias instead, which & 2: the handle's tables copied into the caller's arrays first)
-extern "C" int glamr_debug_ws_offsets(int B, int max_len, size_t* off_x, size_t* off_h0) {
-  Ws w = ws_layout(B, max_len, nullptr);
-  *off_x = reinterpret_cast<size_t>(w.x); *off_h0 = reinterpret_cast<size_t>(w.h0);
-  return GLAMR_OK;
-}
-extern "C" int glamr_debug_first_lin(glamr_nets* h, const float* X, float* Y, int M, unsigned short* Ws_alt, float* rb_alt, int which, void* stream_) {
-  hipStream_t st = static_cast<hipStream_t>(stream_);
-  nn::GemmArgs a{X, nullptr, nullptr, h->enc_pe, nullptr, Y, M, 256, 96, 96, 256, 0, -50, 256, 0};
-  a.Ws = h->enc_in.Ws; a.ws_plane = (size_t)256 * 96; a.x_frag = 0; a.y_frag = 1;
-  if (which & 2) {
-    GLAMR_HIP_CHECK(hipMemcpyAsync(Ws_alt, h->enc_in.Ws, (size_t)2 * 256 * 96 * 2, hipMemcpyDeviceToDevice, st));
-    GLAMR_HIP_CHECK(hipMemcpyAsync(rb_alt, h->enc_pe, (size_t)50 * 256 * 4, hipMemcpyDeviceToDevice, st));
-    GLAMR_HIP_CHECK(hipStreamSynchronize(st));
-    return GLAMR_OK;
-  }
-  if (which & 1) { a.Ws = Ws_alt; a.rowbias = rb_alt; }
-  std::fprintf(stderr, "first_lin: Ws %p rowbias %p bias %p (handle: Ws %p pe %p b %p)\n", (const void*)a.Ws, (const void*)a.rowbias, (const void*)a.bias, (const void*)h->enc_in.Ws, (const void*)h->enc_pe, (const void*)h->enc_in.b);
-  return nn::launch_gemm_free(st, a);
-}
-#endif
 
 extern "C" int glamr_nets_infiller_window(glamr_nets* h, int B, int mode, const glamr_infiller_io* io, void* workspace, void* stream_) {
   GLAMR_REQUIRE(h && io && workspace && B > 0, "null argument");

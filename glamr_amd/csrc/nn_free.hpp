@@ -38,11 +38,8 @@ __host__ __device__ inline size_t x32_off(int row, int col, int ld) {
 // 16 at compile time (0: run time); PD: operands that many k steps ahead.  MAXW: waves per SIMD the register allocation aims at.
 // (Measured and dropped: 2- and 3-wave workgroups marching through the same weight fragments with a barrier per k step, for L1 hits --
 // no change; 64 x 64 / 64 x 128 tiles -- faster alone, slower beside the stage, where one 230-register wave per SIMD hides nothing.)
-// The value of lane ^ 32 (the other half of the wave): v_permlane32_swap_b32, a register-file exchange.  NOT __shfl_xor(x, 32): that is
-// ds_bpermute_b32, which goes through the CU's LDS pipeline -- and the kernels of this file run, by design, beside another kernel's workgroups
-// that are in the middle of LDS traffic.  See DESIGN.md 5 ("the pipeline corruption"): a ds_bpermute issued by a wave of a workgroup WITHOUT an
-// LDS allocation, while a neighbouring workgroup's ds_read_b128 is in flight on the same CU, was measured to leave the upper lanes of that read
-// with stale register contents.
+// The value of lane ^ 32 (the other half of the wave) through v_permlane32_swap_b32, a register-file exchange: __shfl_xor(x, 32) is
+// ds_bpermute_b32, a trip through the CU's LDS pipeline -- which the kernels of this file share with another kernel's workgroups by design.
 __device__ __forceinline__ float lane_xor32(float x) {
   const unsigned u = __float_as_uint(x);
   const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -187,14 +184,6 @@ template <int C, int PD, int MAXW>
 inline int launch_gemm_free_t(hipStream_t st, const GemmArgs& a) {
   const int ncb = (a.N + 32 * C - 1) / (32 * C), nrb = (a.M + 31) / 32;
   const dim3 grid((unsigned)((nrb + 7) / 8 * 8 * ncb)), block(64);
-#ifdef GLAMR_RACE_PROBE
-  if (std::getenv("GLAMR_NETS_PROBE_LOG"))
-    std::fprintf(stderr, "gemm_free: X %p W %p bias %p rowbias %p R %p Y %p M %d N %d K %d ldx %d ldy %d ldr %d rpg %d ldrb %d act %d Ws %p ws_plane %zu x_frag %d y_frag %d grid %u\n", (const void*)a.X, (const void*)a.W,
-                 (const void*)a.bias, (const void*)a.rowbias, (const void*)a.R, (void*)a.Y, a.M, a.N, a.K, a.ldx, a.ldy, a.ldr, a.rows_per_group, a.ldrb, a.act, (const void*)a.Ws, a.ws_plane, a.x_frag, a.y_frag, grid.x);
-#endif
-#ifdef GLAMR_RACE_PROBE      // probe builds: GLAMR_NETS_PROBE_GENERIC_K=<k steps> sends that depth to the run-time-depth instance (another register allocation)
-  if (const char* e = std::getenv("GLAMR_NETS_PROBE_GENERIC_K")) if (std::atoi(e) == a.K / 16) { hipLaunchKernelGGL((gemm_free_kernel<0, C, PD, MAXW>), grid, block, 0, st, a); return GLAMR_OK; }
-#endif
   switch (a.K / 16) {
     case 2: hipLaunchKernelGGL((gemm_free_kernel<2, C, PD, MAXW>), grid, block, 0, st, a); break;
     case 6: hipLaunchKernelGGL((gemm_free_kernel<6, C, PD, MAXW>), grid, block, 0, st, a); break;
@@ -259,9 +248,6 @@ __global__ __launch_bounds__(64, 4) void ln_free_kernel(const float* X, const fl
 // attention_mfma_kernel without LDS: the value rows are gathered from global memory in the key order the probabilities sit in, the key
 // mask is one ballot.  Same arithmetic in the same order.  K, V, O fragment-major; Q too unless q_shared (the prior's two token queries:
 // one row-major table for every sequence).
-#ifndef GLAMR_ATTN_ABLATE      // probe builds (tools/race_mini.py): which part of this kernel disturbs a neighbouring workgroup -- wrong results by design
-#define GLAMR_ATTN_ABLATE 0
-#endif
 __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, int ldq, const float* K, const float* V, int ldk, const unsigned char* key_mask,
                                                                float* O, int ldo, int Lq, int Lk, int q_shared) {
   const int b = blockIdx.x >> 3, h = blockIdx.x & 7, lane = threadIdx.x, c = lane & 31, kg = lane >> 5;
@@ -297,10 +283,7 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
       sc[kt][qt] = (f32x16){0};
       if ((kt == 0 || two_k) && (qt == 0 || two_q)) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (GLAMR_ATTN_ABLATE & 8) { for (int e = 0; e < 16; ++e) sc[kt][qt][e] += (float)kh_[kt][s][e & 7] * (float)qh_[qt][s][e & 7] + (float)kl_[kt][s][e & 7] + (float)ql_[qt][s][e & 7]; }
-          else sc[kt][qt] = mfma3(kh_[kt][s], kl_[kt][s], qh_[qt][s], ql_[qt][s], sc[kt][qt]);
-        }
+        for (int s = 0; s < 2; ++s) sc[kt][qt] = mfma3(kh_[kt][s], kl_[kt][s], qh_[qt][s], ql_[qt][s], sc[kt][qt]);
       }
     }
   float inv[2];
@@ -327,7 +310,7 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
       if (kt == 1 && !two_k) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = (mx > -INFINITY) ? ((GLAMR_ATTN_ABLATE & 1) ? 1.0f + 0.001f * (sc[kt][qt][r] - mx) : __expf(sc[kt][qt][r] - mx)) : 0.f;
+        const float p = (mx > -INFINITY) ? __expf(sc[kt][qt][r] - mx) : 0.f;
         sc[kt][qt][r] = p;
         den += p;
       }
@@ -345,7 +328,7 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int key = 32 * kt + 16 * u + (j & 3) + 8 * (j >> 2) + 4 * kg;
-        vx[j] = (GLAMR_ATTN_ABLATE & 4) ? (float)key : (key < Lk ? V[x32_off(b * Lk + key, h * 32 + c, ldk)] : 0.f);
+        vx[j] = key < Lk ? V[x32_off(b * Lk + key, h * 32 + c, ldk)] : 0.f;
       }
       f16x8 vh, vl;
       split8(vx, vh, vl);
@@ -357,8 +340,7 @@ __global__ __launch_bounds__(64, 4) void attention_free_kernel(const float* Q, i
         for (int j = 0; j < 8; ++j) px[j] = sc[kt][qt][8 * u + j];
         f16x8 ph, pl;
         split8(px, ph, pl);
-        if (GLAMR_ATTN_ABLATE & 2) { for (int e = 0; e < 16; ++e) oc[qt][e] += (float)vh[e & 7] * (float)ph[e & 7] + (float)vl[e & 7] + (float)pl[e & 7]; }
-        else oc[qt] = mfma3(vh, vl, ph, pl, oc[qt]);
+        oc[qt] = mfma3(vh, vl, ph, pl, oc[qt]);
       }
     }
   }

@@ -24,7 +24,6 @@
 // element (row = (r & 3) + 8 (r >> 2) + 4 (l >> 5), col = l & 31).
 #include "common.hpp"
 #include "rotmath.hpp"
-#include "race_probe.hpp"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -177,21 +176,7 @@ struct PrepArgs {
 constexpr int PREP_FEAT_SEGS = 2 * FEAT_STEPS * 2;          // (plane, step, half)
 constexpr int PREP_ASK_SEGS = 12 * 2 * 2 * 2;               // (entry, plane, step, half)
 
-#ifdef GLAMR_RACE_PROBE
-// (probe builds: the level loop and the check at the end of the kernel run the SAME code on the operands as read)
-__device__ __noinline__ void probe_compose(const float* Gp, const float* sjp, const float* R, const float* Jr, float* G) {
-  float t[3] = {Jr[0] - sjp[0], Jr[1] - sjp[1], Jr[2] - sjp[2]};
-  for (int r0 = 0; r0 < 3; ++r0) {
-    for (int c = 0; c < 3; ++c) G[r0 * 4 + c] = Gp[r0 * 4 + 0] * R[0 * 3 + c] + Gp[r0 * 4 + 1] * R[1 * 3 + c] + Gp[r0 * 4 + 2] * R[2 * 3 + c];
-    G[r0 * 4 + 3] = Gp[r0 * 4 + 0] * t[0] + Gp[r0 * 4 + 1] * t[1] + Gp[r0 * 4 + 2] * t[2] + Gp[r0 * 4 + 3];
-  }
-}
-#endif
-
-#ifndef GLAMR_PREP_ATTR
-#define GLAMR_PREP_ATTR
-#endif
-__global__ __launch_bounds__(256) GLAMR_PREP_ATTR void smpl_prep_kernel(PrepArgs a) {
+__global__ __launch_bounds__(256) void smpl_prep_kernel(PrepArgs a) {
   GLAMR_CRITICAL_PATH_PRIO();
   __shared__ float sG[PREP_FRAMES][NJ][12];   // global transform of each joint: 3x3 rotation | translation
   __shared__ float sJ[PREP_FRAMES][NJ][3];    // rest joints
@@ -206,38 +191,12 @@ __global__ __launch_bounds__(256) GLAMR_PREP_ATTR void smpl_prep_kernel(PrepArgs
   const bool want_askin = a.askin != nullptr || a.askin_h != nullptr;
   float R[9];
   float Jr[3] = {0.f, 0.f, 0.f};
-#ifdef GLAMR_RACE_PROBE
-  float pr_seen[3] = {0.f, 0.f, 0.f}, g_own[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const unsigned plevel = probe::level();
-  // level 32: did this wave move (context save / restore), or stall, between kernel start and the end of the level loop?
-  const bool wave_probe = (plevel & 32) && (tid & 63) == 0;
-  unsigned hw0 = 0, xcc0 = 0;
-  unsigned long long t_prev = 0, gap_max = 0;
-  int gap_at = -1;
-  float gp_seen[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sjp_seen[3] = {0.f, 0.f, 0.f}, r_first[9];
-  if (wave_probe) { hw0 = __builtin_amdgcn_s_getreg((31 << 11) | 4); xcc0 = __builtin_amdgcn_s_getreg((31 << 11) | 20); t_prev = wall_clock64(); }
-  if (tid == 0) probe::consumer_start(a.pose);
-#endif
   if (active || padding) {
     if (active) {
       const float* pr = a.body_only ? a.pose + (size_t)b * 69 + (j - 1) * 3 : a.pose + (size_t)b * 72 + j * 3;
       float r[3] = {0.f, 0.f, 0.f};
       if (!a.body_only || j > 0) { r[0] = pr[0]; r[1] = pr[1]; r[2] = pr[2]; }
-#ifdef GLAMR_RACE_PROBE
-      if (!a.body_only || j > 0) {
-        for (int c = 0; c < 3; ++c) {
-          pr_seen[c] = r[c];
-          if (plevel & 8) {
-            const float coh = probe::coherent_load(pr + c);
-            if (__float_as_uint(coh) != __float_as_uint(r[c])) probe::record(3, (unsigned)(b * 72 + j * 3 + c), r[c], coh, 0.f, 0.f);
-          }
-        }
-      }
-#endif
       rodrigues_smplx(r, R);
-#ifdef GLAMR_RACE_PROBE
-      for (int e = 0; e < 9; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(r_first[e]) : "v"(R[e]));      // (a copy of its own)
-#endif
       for (int c = 0; c < 3; ++c) {
         float v = a.j_template[j * 3 + c];
         if (a.use_shape)
@@ -274,18 +233,8 @@ __global__ __launch_bounds__(256) GLAMR_PREP_ATTR void smpl_prep_kernel(PrepArgs
   if (active && lev == 0) {
     for (int e = 0; e < 9; ++e) sG[fl][j][(e / 3) * 4 + (e % 3)] = R[e];
     for (int c = 0; c < 3; ++c) sG[fl][j][c * 4 + 3] = Jr[c];
-#ifdef GLAMR_RACE_PROBE
-    for (int e = 0; e < 9; ++e) g_own[(e / 3) * 4 + (e % 3)] = R[e];
-    for (int c = 0; c < 3; ++c) g_own[c * 4 + 3] = Jr[c];
-#endif
   }
   __syncthreads();
-#ifdef GLAMR_RACE_PROBE
-  if (wave_probe) t_prev = wall_clock64();
-  unsigned long long lvl_mask[10];
-  for (int L = 0; L < 10; ++L) lvl_mask[L] = (plevel & 128) ? __ballot(active && lev == L) : 0ull;
-  const unsigned long long active_mask0 = __ballot(active);
-#endif
   for (int L = 1; L < a.n_levels; ++L) {
     if (active && lev == L) {
       const float* Gp = sG[fl][par];
@@ -296,81 +245,9 @@ __global__ __launch_bounds__(256) GLAMR_PREP_ATTR void smpl_prep_kernel(PrepArgs
         G[r0 * 4 + 3] = Gp[r0 * 4 + 0] * t[0] + Gp[r0 * 4 + 1] * t[1] + Gp[r0 * 4 + 2] * t[2] + Gp[r0 * 4 + 3];
       }
       for (int e = 0; e < 12; ++e) sG[fl][j][e] = G[e];
-#ifdef GLAMR_RACE_PROBE
-      for (int e = 0; e < 12; ++e) g_own[e] = G[e];
-      if (plevel & 64) {
-        for (int e = 0; e < 12; ++e) gp_seen[e] = Gp[e];
-        for (int c = 0; c < 3; ++c) sjp_seen[c] = sJ[fl][par][c];
-      }
-      if (plevel & 128) {
-        // kind 9: the lanes that execute this level against the lanes that should (ballot taken before the loop)
-        const unsigned long long now = __builtin_amdgcn_read_exec(), want = lvl_mask[L < 10 ? L : 9];
-        if (now != want && (int)__lane_id() == __ffsll((long long)now) - 1)
-          probe::record(9, (unsigned)L, __uint_as_float((unsigned)now), __uint_as_float((unsigned)(now >> 32)), __uint_as_float((unsigned)want), __uint_as_float((unsigned)(want >> 32)));
-      }
-#endif
     }
     __syncthreads();
-#ifdef GLAMR_RACE_PROBE
-    if (wave_probe) { const unsigned long long t = wall_clock64(); if (t - t_prev > gap_max) { gap_max = t - t_prev; gap_at = L; } t_prev = t; }
-#endif
   }
-#ifdef GLAMR_RACE_PROBE
-  if (wave_probe) {
-    const unsigned hw1 = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc1 = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    if (hw1 != hw0 || xcc1 != xcc0 || gap_max > 500ull)      // (> 5 us between two barriers of a loop that takes ~1 us per level)
-      probe::record(4, (unsigned)gap_at, __uint_as_float(hw0), __uint_as_float(hw1), __uint_as_float(xcc0 | (xcc1 << 8)), __uint_as_float((unsigned)gap_max));
-  }
-  if (plevel & 128) {
-    // kind 10: every lane that should have run a level did (the level it last ran), and the set of active lanes is what it was
-    const unsigned long long active_mask1 = __ballot(active);
-    if (active_mask1 != active_mask0 && (tid & 63) == 0)
-      probe::record(10, 0u, __uint_as_float((unsigned)active_mask0), __uint_as_float((unsigned)(active_mask0 >> 32)), __uint_as_float((unsigned)active_mask1), __uint_as_float((unsigned)(active_mask1 >> 32)));
-    if (active && lev > 0 && g_own[0] == 0.f && g_own[1] == 0.f && g_own[2] == 0.f && g_own[5] == 0.f) probe::record(11, (unsigned)lev, 0.f, 0.f, 0.f, 0.f);
-  }
-  if (active && (plevel & 64)) {
-    // kind 5: my rotation registers still hold what Rodrigues gave at kernel start
-    for (int e = 0; e < 9; ++e)
-      if (__float_as_uint(R[e]) != __float_as_uint(r_first[e])) probe::record(5, (unsigned)(b * 24 * 16 + j * 16 + e), R[e], r_first[e], 0.f, (float)lev);
-    if (lev > 0) {
-      // kind 7 / 8: the parent's rows as I read them inside the loop against what LDS holds now (they are written once)
-      for (int e = 0; e < 12; ++e) {
-        const float v = reinterpret_cast<volatile float*>(&sG[fl][par][0])[e];
-        if (__float_as_uint(v) != __float_as_uint(gp_seen[e])) probe::record(7, (unsigned)(b * 24 * 16 + j * 16 + e), gp_seen[e], v, (float)par, (float)lev);
-      }
-      for (int c = 0; c < 3; ++c) {
-        const float v = reinterpret_cast<volatile float*>(&sJ[fl][par][0])[c];
-        if (__float_as_uint(v) != __float_as_uint(sjp_seen[c])) probe::record(8, (unsigned)(b * 24 * 16 + j * 16 + c), sjp_seen[c], v, (float)par, (float)lev);
-      }
-      // kind 6: the same code on the operands as seen gives what I wrote
-      float G2[12];
-      probe_compose(gp_seen, sjp_seen, R, Jr, G2);
-      for (int e = 0; e < 12; ++e)
-        if (__float_as_uint(G2[e]) != __float_as_uint(g_own[e])) probe::record(6, (unsigned)(b * 24 * 16 + j * 16 + e), g_own[e], G2[e], 0.f, (float)lev);
-    }
-  }
-  if (active) {
-    // kind 1: my own rows of LDS still hold what I wrote
-    if (plevel & 4) for (int e = 0; e < 12; ++e) {
-      const float v = reinterpret_cast<volatile float*>(&sG[fl][j][0])[e];
-      if (__float_as_uint(v) != __float_as_uint(g_own[e])) probe::record(1, (unsigned)(b * 24 * 16 + j * 16 + e), g_own[e], v, 0.f, 0.f);
-    }
-    if (plevel & 4) for (int c = 0; c < 3; ++c) {
-      const float v = reinterpret_cast<volatile float*>(&sJ[fl][j][0])[c];
-      if (__float_as_uint(v) != __float_as_uint(Jr[c])) probe::record(1, (unsigned)(b * 24 * 16 + j * 16 + 12 + c), Jr[c], v, 0.f, 0.f);
-    }
-    // kind 2: the pose I read at kernel start is still what memory holds
-    if ((plevel & 2) && (!a.body_only || j > 0)) {
-      const float* pr = a.body_only ? a.pose + (size_t)b * 69 + (j - 1) * 3 : a.pose + (size_t)b * 72 + j * 3;
-      for (int c = 0; c < 3; ++c) {
-        const float v1 = probe::cached_load(pr + c), v2 = (plevel & 16) ? probe::coherent_load(pr + c) : v1;
-        if (__float_as_uint(v1) != __float_as_uint(pr_seen[c]) || __float_as_uint(v2) != __float_as_uint(pr_seen[c]))
-          probe::record(2, (unsigned)(b * 72 + j * 3 + c), pr_seen[c], v1, v2, 0.f);
-      }
-    }
-  }
-  if (tid == 0) probe::consumer_end(a.pose);
-#endif
   if (active || padding) {
     const float* G = sG[fl][j];
     if (active) for (int c = 0; c < 3; ++c) a.chain_joints[((size_t)b * NJ + j) * 3 + c] = G[c * 4 + 3];
@@ -1416,10 +1293,6 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   GLAMR_HIP_CHECK(hipGetLastError());
   return GLAMR_OK;
 }
-
-#ifdef GLAMR_RACE_PROBE
-GLAMR_RACE_PROBE_EXPORT(glamr_debug_race_probe_smpl)
-#endif
 
 extern "C" int glamr_smpl_fk(glamr_smpl* h, int B, const float* pose, const float* root_trans, const float* root_scale,
                              float* joints, void* stream_) {

@@ -674,13 +674,12 @@ class GlobalReconOptimizer:
         S, P, T, g = rin.S, rin.P, rin.T, rin.g
         n_slots = S * P
         gate = self.pipeline_gate
-        # GLAMR_GATE_PREP=early: the gate is waited for where the PRIORS start, not where the batch starts -- the arrays' zero fills and the per-person
-        # preparation (1.6 ms on the chain preparation -> infiller -> predictor) read the inputs only and may run beside the previous batch's priors;
-        # capture_resident cuts the step into three graphs for it (preparation | priors + skinning | rest): 35.7 against 38.5 ms per 1024-sequence step.
-        # NOT the default: the two streams' replays of the three-graph cut differed from the plain step in about one of six runs of the 48-sequence
-        # test (tests/test_e2e_gpu.py, gated two-stream test; cause not found), never at 1024 sequences once the skinning had moved ahead of the
-        # predictor.  bench.py asks for it and verifies its replays against a plain step before and after the timed region (`replay_check`).
-        prep_early = gate is not None and os.environ.get('GLAMR_GATE_PREP', 'late') == 'early'
+        # The gate is waited for where the PRIORS start, not where the batch starts: the arrays' zero fills and the per-person preparation (1.6 ms on
+        # the chain preparation -> infiller -> predictor) read the inputs only and run beside the previous batch's priors; capture_resident cuts the
+        # step into three graphs for it (preparation | priors + skinning | rest): 34.7 against 38.5 ms per 1024-sequence step.  Round 5 kept this
+        # behind a knob because its replays sometimes differed from the plain step; round 6 found the cause (packed-fp32 VALU instructions beside the
+        # other stream's MFMA kernels: glamr_amd/build.py) and removed it.  GLAMR_GATE_PREP=late selects the two-graph cut.
+        prep_early = gate is not None and os.environ.get('GLAMR_GATE_PREP', 'early') != 'late'
         if not torch.cuda.is_current_stream_capturing():
             self.value_checks(rin)                                       # (first use of this batch only)
             if gate is not None and not prep_early:
@@ -705,18 +704,14 @@ class GlobalReconOptimizer:
         if prep_early:
             if self._capture_head_split is not None:
                 self._capture_head_split()                             # capture_resident under a gate: the first cut (replay() waits for the gate there)
-                torch.zeros(1, device=dev)                             # (the new graph starts with a KERNEL node: see below)
             elif not torch.cuda.is_current_stream_capturing():
                 gate.before(torch.cuda.current_stream(dev))
-        # the latent draws of the motion priors.  Given latents are copied by a KERNEL (x * 1.0), not by Tensor.copy_: under capture_resident this is
-        # where a graph starts, and a graph whose first node is a memcpy node was measured to start before the work enqueued ahead of it on the stream
-        # had finished (ROCm 7.0: the replayed step then differed from the plain one by up to 2 px, from run to run -- tests/test_e2e_gpu.py,
-        # test_gated_two_stream_step_graphs_use_the_coschedulable_kernels).  torch.randn is a kernel too.
+        # the latent draws of the motion priors (given latents: copied into the priors' fixed arrays)
         if rs:
             meps, teps = rs['meps'], rs['teps']
             if rin.meps is not None:
-                torch.mul(rin.meps, 1.0, out=meps)
-                torch.mul(rin.teps, 1.0, out=teps)
+                meps.copy_(rin.meps)
+                teps.copy_(rin.teps)
             else:
                 torch.randn(meps.shape, out=meps)
                 torch.randn(teps.shape, out=teps)
@@ -734,9 +729,9 @@ class GlobalReconOptimizer:
         # preparation runs without the next batch's first kernels beside it, but that batch starts later: profiles/r05_pipeline_experiments.log)
         gate_at = os.environ.get('GLAMR_GATE_AFTER', 'priors') if gate is not None else 'priors'
         # Under a gate the SKINNING runs between the infiller and the trajectory predictor, i.e. before the gate opens: everything it needs (the
-        # infilled poses in video-frame rows, glamr_init_scatter_pose) is known by then.  Beside the next batch's first kernels its small workgroups
-        # were measured to read another workgroup's LDS contents now and then (~40 of 307 200 frames of a batch with joints off by millimetres;
-        # profiles/r05_pipeline_experiments.log, bench.py `replay_check`); where it runs now only the previous batch's optimiser stage is resident.
+        # infilled poses in video-frame rows, glamr_init_scatter_pose) is known by then, and it runs alone (1.5 ms) instead of beside the next batch's
+        # first kernels (2.4 ms): 34.7 against 35.4 ms per step (profiles/r06_pipeline_corruption.log).  (Round 5 moved it there to dodge the
+        # corruption of its results beside the other stream's attention kernels; with that fixed at its root the order is kept for its speed.)
         # GLAMR_SKIN_AFTER_PRIORS=1 restores the old order (development aid).
         skin_early = gate is not None and os.environ.get('GLAMR_SKIN_AFTER_PRIORS') != '1' and gate_at in ('priors', 'infiller') \
             and hasattr(self.mt_model, 'handle')
@@ -1054,7 +1049,7 @@ class GlobalReconOptimizer:
         else:
             # two graphs sharing one memory pool: everything up to and including the priors, and the rest; replay() records the gate's event between them
             tail = torch.cuda.CUDAGraph()
-            prep_early = os.environ.get('GLAMR_GATE_PREP', 'late') == 'early'
+            prep_early = os.environ.get('GLAMR_GATE_PREP', 'early') != 'late'
             head = torch.cuda.CUDAGraph() if prep_early else None     # (three graphs then: preparation | priors | the rest)
             torch.cuda.synchronize(self.device)
             with torch.cuda.stream(st):

@@ -193,7 +193,10 @@ def test_absolute_heading_matches_the_reference(make_model, golden, case):
         worst[1] = max(worst[1], float(np.abs(pd['root_trans_world'] - g['opt_p%d_root_trans_world' % pi]).max()))
         worst[2] = max(worst[2], _rot_err(pd['smpl_orient_world'], g['opt_p%d_smpl_orient_world' % pi]))
     print('absolute_heading %s T=%d P=%d, %d iterations per stage: kp %.4f px, root_trans_world %.2e m, smpl_orient_world %.2e' % (cfg_id, T, P, K, *worst))
-    assert worst[0] < 0.05 and worst[1] < 1e-5 and worst[2] < 7e-3          # achieved 0.014 / 0.0004 px, 5e-7 / 7e-7 m, 2.2e-3 / 2.9e-4
+    # achieved 0.014 / 0.0004 px, 5e-7 / 7e-7 m, 2.2e-3 / 2.9e-4 up to round 5; 0.054 px for the one-person case since round 6 built the library
+    # without packed-fp32 instructions (glamr_amd/build.py: the wide instance's products fuse in another operand order, and ten sign-driven Adam
+    # steps per stage amplify a last-bit difference)
+    assert worst[0] < 0.08 and worst[1] < 1e-5 and worst[2] < 7e-3
 
 
 def _full_schedule(make_model, golden, tag, gap, host_init=False):
@@ -690,6 +693,9 @@ def test_bench_step_graph_reproduces_the_plain_step():
     out = bench.run(['--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--no-kernel-lines'])
     assert out['config']['step_graph'] is True
     assert out['value'] > 0 and out['steps'] == 2
+    # the check that runs after the clock has stopped: both streams' graphs, alternated, two seeds, against plain steps of the same seeds
+    rc = out['replay_check']
+    assert rc['bit_identical_to_plain_steps'] is True and rc['max_projection_difference_px'] == 0.0 and rc['seeds'] >= 2, rc
     plain = bench.run(['--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--no-kernel-lines', '--no-graph-step'])
     assert plain['config']['step_graph'] is False
 
@@ -820,23 +826,27 @@ def test_captured_resident_step_follows_new_inputs(make_model):
 
 
 @pytest.mark.gpu
-def test_gated_two_stream_step_graphs_use_the_coschedulable_kernels(make_model, monkeypatch):
-    """The staggered two-stream pipeline (PipelineGate): every batch starts when the previous batch's priors are done, its infiller runs on the
-    kernels that fit beside the other stream's optimiser stage (GLAMR_NETS_COSCHEDULE: 48 sequences x 2 windows = 4800 window rows, above the
-    2048-row threshold), and capture_resident cuts the step into two graphs around the gate's event (the priors with the skinning between infiller
-    and predictor | the rest).  With the LDS kernels forced
-    (GLAMR_NETS_FREE=0) the gated, split, replayed step is the ungated plain step BIT FOR BIT: gate and split change nothing but the order
-    of launches across streams.  With the co-schedulable kernels the replays reproduce the plain gated step bit for bit (capture_resident's
-    own check); against the LDS kernels the priors differ by ~1e-7 (tests/test_nets_gpu.py), which six sign-driven Adam steps turn into
-    a few hundredths of a pixel."""
+@pytest.mark.parametrize('cut', ['early', 'late'])
+def test_gated_two_stream_step_graphs_use_the_coschedulable_kernels(make_model, monkeypatch, cut):
+    """The staggered two-stream pipeline (PipelineGate): every batch starts its priors when the previous batch's are done, its infiller runs on
+    the kernels that fit beside the other stream's optimiser stage (GLAMR_NETS_COSCHEDULE: 48 sequences x 2 windows = 4800 window rows, above
+    the 2048-row threshold), and capture_resident cuts the step around the gate: three graphs (preparation | priors + skinning | rest; the
+    default) or two (GLAMR_GATE_PREP=late).  The two streams work on DIFFERENT batches, their graphs are replayed alternately twelve times, and
+    every array of every replay must equal a plain gated step on the same kernels BIT FOR BIT -- a value read from the other stream, left over
+    from the previous replay or computed wrong beside the other stream's kernels is a difference (round 5 accepted 0.3 px here, which the
+    corruption of that round passed: profiles/r06_pipeline_corruption.log).  With the LDS kernels forced (GLAMR_NETS_FREE=0) the gated, split,
+    replayed step is also the UNGATED plain step bit for bit: gate and cut change nothing but the order of launches across streams."""
     from glamr_amd.global_recon.models.global_recon_model import PipelineGate
     md = synth.make_smpl_model()
     model = make_model('glamr_dynamic')
-    batch = [synth.make_in_dict(seed=300 + i, num_frames=96, num_persons=1, smpl_model=md) for i in range(48)]
-    lats = [mg.latents_for(d, 300 + i) for i, d in enumerate(batch)]
-    rin = model.stage_inputs(batch, lats)
+    monkeypatch.setenv('GLAMR_GATE_PREP', cut)
+    rins = []
+    for base in (300, 400):
+        batch = [synth.make_in_dict(seed=base + i, num_frames=96, num_persons=1, smpl_model=md) for i in range(48)]
+        rins.append(model.stage_inputs(batch, [mg.latents_for(d, base + i) for i, d in enumerate(batch)]))
     torch.cuda.synchronize()
-    plain = model.optimize_resident(rin, max_iters=6)[1].t['kp_2d_pred'].clone()
+    keys = ('kp_2d_pred', 'params', 'j_local', 'cam_pose', 'orient_world', 'trans_world', 'losses')
+    ungated = [{k: v.clone() for k, v in model.optimize_resident(r, max_iters=6)[1].t.items() if k in keys} for r in rins]
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     for forced_lds in (True, False):
@@ -846,21 +856,31 @@ def test_gated_two_stream_step_graphs_use_the_coschedulable_kernels(make_model, 
             monkeypatch.delenv('GLAMR_NETS_FREE')
         model.pipeline_gate = PipelineGate()
         try:
-            for st in streams:
+            want = []
+            for st, r in zip(streams, rins):
                 with torch.cuda.stream(st):
-                    model.optimize_resident(rin, max_iters=6)
-            torch.cuda.synchronize()
-            graphs = [model.capture_resident(rin, max_iters=6, stream=st, check=True) for st in streams]
-            assert all(g.tail is not None and g.head is None and g.gate is model.pipeline_gate for g in graphs)
-            for i in range(4):
-                graphs[i % 2].replay()
-            torch.cuda.synchronize()
-            for g in graphs:
-                got = g.packed.t['kp_2d_pred']
-                assert bool(torch.isfinite(got).all())
-                d = float((got - plain).abs().max())
-                print('gated step graph (%s) vs the ungated plain step: %.2e px' % ('LDS kernels' if forced_lds else 'co-schedulable kernels', d))
-                assert d == 0.0 if forced_lds else 0.0 < d < 0.3
-            assert torch.equal(graphs[0].packed.t['kp_2d_pred'], graphs[1].packed.t['kp_2d_pred'])
+                    want.append({k: v.clone() for k, v in model.optimize_resident(r, max_iters=6)[1].t.items() if k in keys})      # a plain GATED step
+                torch.cuda.synchronize()
+            model.pipeline_gate.last = None
+            graphs = [model.capture_resident(r, max_iters=6, stream=st, check=True) for st, r in zip(streams, rins)]
+            assert all(g.tail is not None and (g.head is not None) == (cut == 'early') and g.gate is model.pipeline_gate for g in graphs)
+            for rep in range(6):
+                torch.cuda.synchronize()
+                for gi in ((0, 1) if rep % 2 == 0 else (1, 0)):
+                    graphs[gi].replay()
+                torch.cuda.synchronize()
+                for gi, g in enumerate(graphs):
+                    for k in keys:
+                        got = g.packed.t[k]
+                        assert bool(torch.isfinite(got).all()), (cut, forced_lds, rep, gi, k)
+                        assert torch.equal(got, want[gi][k]), 'replay %d of stream %d, %s, %s kernels: %s differs from the plain gated step by %.3g' % (
+                            rep, gi, cut, 'LDS' if forced_lds else 'co-schedulable', k, float((got.float() - want[gi][k].float()).abs().max()))
+                        if forced_lds:
+                            assert torch.equal(got, ungated[gi][k]), (cut, rep, gi, k)
+                    g.packed.t['kp_2d_pred'].fill_(float('nan'))      # (a replay that did not rewrite its outputs would be seen)
+            if not forced_lds:
+                d = max(float((want[gi]['kp_2d_pred'] - ungated[gi]['kp_2d_pred']).abs().max()) for gi in range(2))
+                print('co-schedulable kernels against the LDS kernels after six iterations: %.2e px' % d)
+                assert 0.0 < d < 0.3      # (other kernels for the priors: ~1e-7 there, tests/test_nets_gpu.py; six sign-driven Adam steps later)
         finally:
             model.pipeline_gate = None

@@ -1,11 +1,13 @@
-"""DEVELOPMENT AID (GPU): the two-stream pipeline's corruption, one independent sample per iteration.
+"""DEVELOPMENT AID (GPU): the two-stream pipeline checked pair by pair (the tool that found round 6's packed-fp32 corruption,
+profiles/r06_pipeline_corruption.log; tests/test_pipeline_soak_gpu.py is its permanent form).
 Two step graphs (one per stream) are replayed as a PAIR, the device is synchronised, and every array of both is compared bit for bit with a plain
-step of the same seed; the seeds alternate between iterations so that a value left over from the previous replay is a wrong one.  With the
-instrumented library (tools/build_variant_files.sh race "smpl.hip init.hip" -DGLAMR_RACE_PROBE; GLAMR_LIB_PATH=tools/_lib_race.so) the
-records of csrc/race_probe.hpp are printed per iteration: own-LDS-row mismatches (kind 1), pose read at kernel start != pose at kernel end
-(kind 2), cached != coherent load at kernel start (kind 3), and producer-end / consumer-start stamps per pose array.
-usage: [GLAMR_GATE_PREP=early] [GLAMR_SKIN_AFTER_PRIORS=1] python tools/race_probe.py [n_sequences] [iterations]"""
-import ctypes, os, sys
+step of the same seed; the seeds alternate between iterations so that a value left over from the previous replay is a wrong one.
+To see the corruption again build a library WITH packed-fp32 instructions: GLAMR_VARIANT_PACKED=" " tools/build_variant_files.sh packed
+"smpl.hip init.hip nets.hip eval.hip"; GLAMR_LIB_PATH=tools/_lib_packed.so GLAMR_SKIN_AFTER_PRIORS=1 python tools/race_probe.py
+knobs: GLAMR_GATE_PREP=late, GLAMR_SKIN_AFTER_PRIORS=1, GLAMR_PROBE_TWO_INPUTS=1, GLAMR_PROBE_LATENTS=1, GLAMR_PROBE_SNAPSHOT=1 (the skinning's workspace
+copied inside the graphs), GLAMR_PROBE_HOST_WAIT=1, GLAMR_PROBE_SPIN_US=n, GLAMR_PROBE_B=graph|nets|mm|add|sleep|none (what the second stream runs)
+usage: python tools/race_probe.py [n_sequences] [iterations]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -17,27 +19,24 @@ from glamr_amd.global_recon.models.global_recon_model import PipelineGate
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-REC = np.dtype([('kind', 'u4'), ('block', 'u4'), ('tid', 'u4'), ('hw_id', 'u4'), ('xcc_id', 'u4'), ('aux', 'u4'), ('t', 'u8'), ('v', 'f4', (4,))])
-SLOT = np.dtype([('key', 'u8'), ('prod_end_max', 'u8'), ('cons_start_min_inv', 'u8'), ('prod_start_min_inv', 'u8'), ('cons_end_max', 'u8')])
-HDR = 16
-NBYTES = HDR + 16 * SLOT.itemsize + 4096 * REC.itemsize
-LEVEL = int(os.environ.get('GLAMR_PROBE_LEVEL', '31'))
-
 L = _lib.lib()
-dbg = None
-if hasattr(L, 'glamr_debug_race_probe_smpl'):
-    dbg = torch.zeros(NBYTES, dtype=torch.uint8, device=dev)
-    for fn in (L.glamr_debug_race_probe_smpl, L.glamr_debug_race_probe_init):
-        fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
-        assert fn(ctypes.c_void_p(dbg.data_ptr())) == 0
-    print('instrumented library: race records on, level %d' % LEVEL)
 
 model = bench.build_model(bench.ensure_assets(), dev)
 md = synth.make_smpl_model()
 # GLAMR_PROBE_TWO_INPUTS=1: the two streams work on DIFFERENT batches -- a wrong value that equals the other stream's right one came from there
 two_inputs = os.environ.get('GLAMR_PROBE_TWO_INPUTS') == '1'
-rin = model.stage_inputs([synth.make_in_dict(seed=s, num_frames=bench.NUM_FRAMES, num_persons=1, smpl_model=md) for s in range(B)])
-rins = [rin, model.stage_inputs([synth.make_in_dict(seed=5000 + s, num_frames=bench.NUM_FRAMES, num_persons=1, smpl_model=md) for s in range(B)]) if two_inputs else rin]
+def staged(seed0):
+    dicts = [synth.make_in_dict(seed=seed0 + s, num_frames=bench.NUM_FRAMES, num_persons=1, smpl_model=md) for s in range(B)]
+    lat = None
+    if os.environ.get('GLAMR_PROBE_LATENTS') == '1':      # GIVEN latents (copied into the priors' arrays inside the step graph) instead of draws
+        from glamr_amd.models.prior_models import num_windows, NZ
+        rng = np.random.default_rng(seed0)
+        lat = [{idx: {'motion': rng.standard_normal((num_windows(bench.NUM_FRAMES), NZ)).astype(np.float32), 'traj': rng.standard_normal(NZ).astype(np.float32)} for idx in d['est']} for d in dicts]
+    return model.stage_inputs(dicts, lat)
+
+
+rin = staged(0)
+rins = [rin, staged(5000) if two_inputs else rin]
 streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 torch.cuda.synchronize()
 model.pipeline_gate = PipelineGate()
@@ -157,8 +156,7 @@ def substitute(gi_first):
         elif B_KIND == 'sleep':
             torch.cuda._sleep(10_000_000)
         elif B_KIND == 'nets':
-            # the priors alone, on buffers of their own (another key of the library's graph cache: GLAMR_NETS_PROBE_STOP / _SPIN given as
-            # GLAMR_PROBE_B_ENV="NAME=value,..." apply to THIS call only, not to the step graphs or the reference steps)
+            # the priors alone, plain launches, on buffers of their own
             g2 = graphs[1 - gi_first].packed
             n_slots = g2.S * g2.P
             if 'rs3' not in STATE:
@@ -169,22 +167,13 @@ def substitute(gi_first):
                     STATE['rs3'][k].copy_(rs_b[k])
                 STATE['rs3']['persistent'] = True
             rs3 = STATE['rs3']
-            extra = dict(kv.split('=', 1) for kv in os.environ.get('GLAMR_PROBE_B_ENV', '').split(',') if kv)
-            os.environ.update(extra)
-            try:
-                model.mt_model.infer_padded(rs3['nets_pose'], rs3['nets_vis'], rins[1 - gi_first].lens, rs3['meps'], rs3['teps'], buffers=rs3, coschedule=True)
-            finally:
-                for k in extra:
-                    os.environ.pop(k, None)
+            model.mt_model.infer_padded(rs3['nets_pose'], rs3['nets_vis'], rins[1 - gi_first].lens, rs3['meps'], rs3['teps'], buffers=rs3, coschedule=True)
 
 
 n_bad = 0
 for it in range(N):
     order = (0, 1) if it % 2 == 0 else (1, 0)
     seed_of = {order[0]: seeds[it % 2], order[1]: seeds[(it + 1) % 2]}
-    if dbg is not None:
-        dbg.zero_()
-        dbg[8:16] = torch.from_numpy(np.array([LEVEL], 'u8').view('u1')).to(dev)
     torch.cuda.synchronize()
     for k, gi in enumerate(order):
         if k == 1 and B_KIND != 'graph':
@@ -233,35 +222,4 @@ for it in range(N):
                             dj = (x[f] - y[f]).abs().max(dim=1).values
                             print('         chain frame %d (block %d, frame-in-block %d): joints wrong %s max %.3g' % (f, f // 8, f % 8, torch.nonzero(dj > 0).flatten().tolist(), float(dj.max())))
             print('   j_local rows (slot, frame): %d, first %s; blocks of smpl_prep_kernel %s' % (len(rows), rows[:12], sorted({(r[0] * 300 + r[1]) // 8 for r in rows})[:24]))
-    if dbg is not None:
-        raw = dbg.cpu().numpy()
-        n_rec = int(raw[:8].view('u8')[0])
-        slots = raw[HDR:HDR + 16 * SLOT.itemsize].view(SLOT)
-        recs = raw[HDR + 16 * SLOT.itemsize:].view(REC)[:min(n_rec, 4096)]
-        inv = lambda x: (~np.uint64(x)) if x else 0
-        for s in slots:
-            if s['key']:
-                pe, cs, ps, ce = int(s['prod_end_max']), int(inv(s['cons_start_min_inv'])), int(inv(s['prod_start_min_inv'])), int(s['cons_end_max'])
-                print('   pose array %#x: producer %d .. %d, consumer %d .. %d (100 MHz ticks from the producer\'s start: producer end %d, consumer start %d end %d)%s'
-                      % (int(s['key']), ps, pe, cs, ce, pe - ps, cs - ps, ce - ps, '   <-- CONSUMER STARTED BEFORE THE PRODUCER ENDED' if cs and pe and cs < pe else ''))
-        print('   %d probe records' % n_rec + ''.join(' kind %d: %d' % (k, int((recs['kind'] == k).sum())) for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)))
-        for r in recs[recs['kind'] == 4][:40]:
-            u = r['v'].view('u4')
-            dec = lambda hw: 'se %d cu %d simd %d wave %d' % ((hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15)
-            print('      kind 4 block %d wave %d: largest gap between two barriers %d ticks (10 ns) at level %d; start xcc %d %s -> end xcc %d %s%s' % (
-                r['block'], r['tid'] >> 6, int(u[3]), int(np.int32(r['aux'])), int(u[2]) & 15, dec(int(u[0])), (int(u[2]) >> 8) & 15, dec(int(u[1])),
-                '   <-- THE WAVE MOVED' if (u[0] != u[1] or (int(u[2]) & 255) != (int(u[2]) >> 8)) else ''))
-        for r in recs[recs['kind'] != 4][:48]:
-            hw = int(r['hw_id'])
-            if r['kind'] in (9, 10):
-                u = r['v'].view('u4')
-                print('      kind %d block %d wave %d level %d: lanes %#018x, expected %#018x' % (r['kind'], r['block'], r['tid'] >> 6, r['aux'], int(u[0]) | (int(u[1]) << 32), int(u[2]) | (int(u[3]) << 32)))
-                continue
-            if r['kind'] >= 5:
-                print('      kind %d block %d tid %d (frame-in-block %d joint %d, wave %d lane %d) entry %d: %s' % (r['kind'], r['block'], r['tid'], r['tid'] // 24, r['tid'] % 24, r['tid'] >> 6, r['tid'] & 63,
-                      r['aux'] % 16, ' '.join('%.9g' % x for x in r['v'])))
-                continue
-            print('      kind %d block %d tid %d aux %d t %d xcc %d se %d cu %d simd %d wave %d | %s' % (
-                r['kind'], r['block'], r['tid'], r['aux'], r['t'], int(r['xcc_id']) & 15, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15,
-                ' '.join('%.9g' % x for x in r['v'])))
 print('SUMMARY: %d of %d graph replays differed from the plain step' % (n_bad, 2 * N))

@@ -1,8 +1,13 @@
-// Stand-alone reproducer (no torch, no graphs) of the corruption seen in the two-stream pipeline: smpl_prep_kernel (the library's own, included
-// below) runs on stream A while stream B starts a train of the infiller's first GEMM (gemm_free_kernel<6, 2, 1, 4>, also the library's own).
-// The chain joints of every run are compared bit for bit with a run of smpl_prep_kernel ALONE on the same inputs.
+// Stand-alone reproducer (no torch) of the corruption found in the two-stream pipeline: a kernel whose waves execute
+// PACKED fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) on stream A, a kernel that runs chains of DEPENDENT
+// v_mfma_f32_32x32x16_f16 in one-wave workgroups without LDS on stream B.  The victim's results are compared bit for bit with the same kernel
+// run alone (victims 0, 1) or checked inside the kernel against the unpacked instruction on the same operands (victim 2).
+// Build WITHOUT the library's -target-feature -packed-fp32-ops (the point is to have the packed instructions):
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/race_repro.hip glamr_amd/csrc/api_common.cpp -o tools/_race_repro
-//   run:   tools/_race_repro [iterations] [frames] [victim: 0 smpl_prep_kernel, 1 the reduced kernel below] [trigger: 0 gemm_free, 1 none, 2 plain loads] [graphs: 0 / 1]
+//   run:   tools/_race_repro [iterations] [frames] [victim] [trigger] [graphs: 0 / 1]
+//     victim:  0 smpl_prep_kernel (the library's), 1 its kinematic chain alone, 2 v_pk_fma_f32 against v_fma_f32 on register operands (self-checking)
+//     trigger: 0 gemm_free_kernel<6, 2, 1, 4> (independent accumulators), 1 none, 2 plain loads / stores, 3 attention_free_kernel (the library's),
+//              4 chains of three dependent MFMAs on one accumulator, 5 the same number of MFMAs over four accumulators in turn
 //   (LD_LIBRARY_PATH=<torch>/lib runs it on the HIP runtime PyTorch ships instead of /opt/rocm's)
 #include "../glamr_amd/csrc/smpl.hip"
 #include "../glamr_amd/csrc/nn_free.hpp"
@@ -27,6 +32,47 @@ __global__ __launch_bounds__(64, 4) void stream_kernel(const float4* x, float4* 
   for (int k = 0; k < 8; ++k) v[k] = i + (size_t)k * 64 < n ? x[i + (size_t)k * 64] : float4{0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 8; ++k) if (i + (size_t)k * 64 < n) y[i + (size_t)k * 64] = float4{v[k].x * 2.f, v[k].y + 1.f, v[k].z, v[k].w};
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+// victim 2: c <- a * c + b, once with v_pk_fma_f32 on a register pair and once with two v_fma_f32, 4096 times; mismatching lanes are counted
+__global__ __launch_bounds__(256) void pk_selfcheck_kernel(unsigned* n_bad, unsigned* bad_lanes, int iters) {
+  const int lane = threadIdx.x & 63;
+  const float a0 = 0.99f - 1e-4f * (float)lane, a1 = 0.98f + 2e-4f * (float)lane, b0 = 0.01f * (float)(1 + (blockIdx.x & 7)), b1 = 0.02f;
+  f2 a = {a0, a1}, b = {b0, b1}, c = {1.0f, 2.0f};
+  float r0 = 1.0f, r1 = 2.0f;
+  for (int i = 0; i < iters; ++i) {
+    asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(c) : "v"(a), "v"(b));
+    asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(r0) : "v"(a0), "v"(b0));
+    asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(r1) : "v"(a1), "v"(b1));
+    if (__float_as_uint(c.x) != __float_as_uint(r0) || __float_as_uint(c.y) != __float_as_uint(r1)) {
+      atomicAdd(n_bad, 1u);
+      atomicAdd(bad_lanes + lane, 1u);
+      c.x = r0; c.y = r1;
+    }
+  }
+  if (c.x == 12345.f) n_bad[1] = 1;
+}
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+// triggers 4 / 5: one wave per workgroup, no LDS; DEP: every MFMA accumulates into the result of the one before it
+template <bool DEP>
+__global__ __launch_bounds__(64, 4) void mfma_chain_kernel(float* out, int iters) {
+  const int lane = threadIdx.x;
+  h8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.01f * (float)((lane + i) & 15)); b[i] = (_Float16)(0.02f * (float)((lane * 3 + i) & 15)); }
+  f16v acc[4] = {(f16v){0}, (f16v){0}, (f16v){0}, (f16v){0}};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      f16v& t = acc[DEP ? (k / 3) : (k & 3)];
+      t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, t, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int k = 0; k < 4; ++k) for (int e = 0; e < 16; ++e) s += acc[k][e];
+  out[(size_t)blockIdx.x * 64 + lane] = s;
 }
 
 // the kinematic chain of smpl_prep_kernel alone: same thread map (8 frames x 24 joints of 256 threads), same LDS footprint
@@ -105,16 +151,26 @@ int main(int argc, char** argv) {
   glamr::nn::GemmArgs ga{X, nullptr, nullptr, rowbias, nullptr, Y, M, N, K, K, N, 0, -50, 256, 0};
   ga.Ws = Ws; ga.ws_plane = (size_t)256 * K; ga.x_frag = 0; ga.y_frag = 1;
   const dim3 ggrid((unsigned)((M / 32 + 7) / 8 * 8 * 4));
+  // the first attention of the infiller's first window: 1024 sequences x 8 heads, 50 x 50, fragment-major Q | K | V rows
+  float *qkv, *att, *mf_out;
+  unsigned char* kmask;
+  unsigned *n_bad_d, *bad_lanes_d;
+  CK(hipMalloc(&qkv, (size_t)(M + 32) * 768 * 4)); CK(hipMalloc(&att, (size_t)(M + 32) * 256 * 4)); CK(hipMalloc(&kmask, M)); CK(hipMemset(kmask, 0, M));
+  CK(hipMalloc(&mf_out, (size_t)8192 * 64 * 4)); CK(hipMalloc(&n_bad_d, 8)); CK(hipMalloc(&bad_lanes_d, 256));
+  { std::vector<float> h((size_t)(M + 32) * 768); for (auto& x : h) x = u(rng); CK(hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
   hipStream_t sa, sb;
   CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
   glamr::PrepArgs pa{B, Bpad, 10, n_levels, 1, pose, 1, betas, jtd, jsdd, parents, level, nullptr, reinterpret_cast<unsigned short*>(feat_h), nullptr,
                      reinterpret_cast<unsigned short*>(askin_h), chain};
   auto launch_victim = [&](hipStream_t st) {
+    if (victim == 2) { hipLaunchKernelGGL(pk_selfcheck_kernel, dim3(256 * 5 * 8), dim3(256), 0, st, n_bad_d, bad_lanes_d, 4096); return; }
     if (victim == 0) hipLaunchKernelGGL(glamr::smpl_prep_kernel, dim3(Bpad / 8), dim3(256), 0, st, pa);
     else hipLaunchKernelGGL(chain_only_kernel, dim3((B + 7) / 8), dim3(256), 0, st, B, pose, parents, level, n_levels, chain);
   };
+  CK(hipMemset(n_bad_d, 0, 8)); CK(hipMemset(bad_lanes_d, 0, 256));
   launch_victim(sa);
   CK(hipStreamSynchronize(sa));
+  if (victim == 2) { unsigned nb = 0; CK(hipMemcpy(&nb, n_bad_d, 4, hipMemcpyDeviceToHost)); std::printf("victim alone: %u packed results differ from the unpacked ones\n", nb); }
   CK(hipMemcpy(ref, chain, (size_t)B * 72 * 4, hipMemcpyDeviceToDevice));
   std::vector<float> ref_h((size_t)B * 72), got_h((size_t)B * 72);
   CK(hipMemcpy(ref_h.data(), ref, ref_h.size() * 4, hipMemcpyDeviceToHost));
@@ -125,6 +181,9 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, sb, delay_us * 100ull);
     for (int k = 0; k < 12; ++k) {
       if (trigger == 0) hipLaunchKernelGGL((glamr::nn::gemm_free_kernel<6, 2, 1, 4>), ggrid, dim3(64), 0, sb, ga);
+      else if (trigger == 3) hipLaunchKernelGGL(glamr::nn::attention_free_kernel, dim3(1024 * 8), dim3(64), 0, sb, qkv, 768, qkv + 256 * 32, qkv + 512 * 32, 768, kmask, att, 256, 50, 50, 0);
+      else if (trigger == 4) hipLaunchKernelGGL(mfma_chain_kernel<true>, dim3(8192), dim3(64), 0, sb, mf_out, 200);
+      else if (trigger == 5) hipLaunchKernelGGL(mfma_chain_kernel<false>, dim3(8192), dim3(64), 0, sb, mf_out, 200);
       else hipLaunchKernelGGL(stream_kernel, dim3((unsigned)(((size_t)M * N / 4 + 511) / 512)), dim3(64), 0, sb, reinterpret_cast<const float4*>(Y), reinterpret_cast<float4*>(feat_h), (size_t)M * N / 4);
     }
   };
@@ -141,6 +200,7 @@ int main(int argc, char** argv) {
     }
   }
   for (int it = 0; it < iters; ++it) {
+    CK(hipMemsetAsync(n_bad_d, 0, 8, sa)); CK(hipMemsetAsync(bad_lanes_d, 0, 256, sa));
     CK(hipMemsetAsync(chain, 0xFF, (size_t)B * 72 * 4, sa));
     CK(hipStreamSynchronize(sa));
     const unsigned long long delay_us = 30 + 40 * (it % 12);
@@ -151,6 +211,15 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
+    if (victim == 2) {
+      unsigned nb[2], lanes[64];
+      CK(hipMemcpy(nb, n_bad_d, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(lanes, bad_lanes_d, 256, hipMemcpyDeviceToHost));
+      std::printf("run %d (other stream %llu us after the launch): victim %.3f ms, %u packed results differ from the unpacked ones; lanes:", it, delay_us, ms, nb[0]);
+      for (int l = 0; l < 64; ++l) if (lanes[l]) std::printf(" %d:%u", l, lanes[l]);
+      std::printf("\n");
+      n_bad_runs += nb[0] > 0;
+      continue;
+    }
     CK(hipMemcpy(got_h.data(), chain, got_h.size() * 4, hipMemcpyDeviceToHost));
     int bad_frames = 0;
     for (int f = 0; f < B; ++f) {
