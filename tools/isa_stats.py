@@ -5,7 +5,7 @@ import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = os.environ.get('GLAMR_ISA_KERNEL', '_ZN5glamr6grecon19grecon_stage_kernelILi1ELb1ELi1ELi304EEEvNS0_10KernelArgsE')
 out = os.path.join(tempfile.gettempdir(), 'grecon_isa.s')
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize',
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize', '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops',
        '--cuda-device-only', '-S', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'glamr_amd/csrc/grecon.hip'), '-o', out] + sys.argv[1:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
