@@ -233,6 +233,11 @@ GLAMR_HD void adam(float& p, float& m, float& v, float g, const AdamCoef& c) {
 // reciprocal) has N - 1 independent ones between itself and its consumer.  Measured on the MI355X (profiles/r05_stage_ab.log): 11.15 against
 // 10.8 us per iteration for the plain loop -- the scheduling barriers also pin the loads and stores around the updates, which costs more than
 // the shorter chains give.  Operation for operation what adam() does either way: same bits (tests/test_adam_exact.py, tools/stage_bits.py).
+#if defined(GLAMR_ADAM_INTERLEAVE) && GLAMR_ADAM_INTERLEAVE == 2      // the staged form WITHOUT scheduling barriers between the stages
+#define GLAMR_ADAM_STAGE_FENCE() ((void)0)
+#else
+#define GLAMR_ADAM_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int N>
 GLAMR_HD void adam_n(float (&P)[N], float (&M)[N], float (&V)[N], const float (&g)[N], const AdamCoef& c) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GLAMR_ADAM_INTERLEAVE)
@@ -244,7 +249,7 @@ GLAMR_HD void adam_n(float (&P)[N], float (&M)[N], float (&V)[N], const float (&
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) s[k] = rm::hw_sqrt_(V[k]);
-  __builtin_amdgcn_sched_barrier(0);
+  GLAMR_ADAM_STAGE_FENCE();
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const float a = rm::sqrt_rn_fix_(V[k], s[k]);
@@ -252,10 +257,10 @@ GLAMR_HD void adam_n(float (&P)[N], float (&M)[N], float (&V)[N], const float (&
     den[k] = rm::fma_(rm::fma_(-c.bc2_sqrt, q, a), c.inv_bc2_sqrt, q) + 1e-8f;
     num[k] = c.neg_step * M[k];
   }
-  __builtin_amdgcn_sched_barrier(0);
+  GLAMR_ADAM_STAGE_FENCE();
 #pragma unroll
   for (int k = 0; k < N; ++k) y[k] = rm::hw_rcp_(den[k]);
-  __builtin_amdgcn_sched_barrier(0);
+  GLAMR_ADAM_STAGE_FENCE();
 #pragma unroll
   for (int k = 0; k < N; ++k) P[k] = P[k] + rm::div_fix_(num[k], den[k], y[k]);
 #else

@@ -687,6 +687,44 @@ __global__ __launch_bounds__(256) void smpl_finish_kernel(FinishArgs a) {
   if (lane < 3 && a.pivot) a.pivot[(size_t)b * 3 + lane] = sPivot[wave][lane];
 }
 
+// The same for calls whose regression partials come from at most four tiles (the joints tileset: 3): one THREAD per (frame, output joint), eight
+// frames per workgroup, the few partials of a regressed joint added in the order the wave reduction above adds them -- (t0 + t2) + (t1 + t3).
+// A wave per frame was 307 200 waves of three working lanes and six shuffles for a 1024 x 300 batch: 0.38 ms for 0.28 GB.
+__global__ __launch_bounds__(256) void smpl_finish_small_kernel(FinishArgs a) {
+  GLAMR_CRITICAL_PATH_PRIO();
+  __shared__ float sPivot[8][3];
+  const int fl = threadIdx.x >> 5, j = threadIdx.x & 31;
+  const int b = blockIdx.x * 8 + fl;
+  const int n_out = a.orig_joints ? NJ : a.n_out;
+  const bool ok = b < a.B && j < n_out;
+  float val[3] = {0.f, 0.f, 0.f};
+  if (ok) {
+    const int src = a.orig_joints ? j : a.joint_map[j];
+    if (src < NJ) {
+      for (int c = 0; c < 3; ++c) val[c] = a.chain_joints[((size_t)b * NJ + src) * 3 + c];
+    } else if (src < NJ + a.n_picked) {
+      for (int c = 0; c < 3; ++c) val[c] = a.picked[((size_t)b * a.n_picked + (src - NJ)) * 3 + c];
+    } else {
+      const int slot = a.extra_slot[src - NJ - a.n_picked], nred = a.n_extra_used * 3;
+      for (int c = 0; c < 3; ++c) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; ++k) if (k < a.n_tiles) t[k] = 0.f + a.partial[((size_t)k * a.Bpad + b) * nred + slot * 3 + c];
+        val[c] = (t[0] + t[2]) + (t[1] + t[3]);
+      }
+    }
+    if (j == 0) for (int c = 0; c < 3; ++c) sPivot[fl][c] = val[c];
+  }
+  __syncthreads();
+  if (!ok) return;
+  const float pv[3] = {sPivot[fl][0], sPivot[fl][1], sPivot[fl][2]};
+  if (a.root_trans) {
+    const float sc = a.root_scale ? a.root_scale[b] : 1.0f;
+    for (int c = 0; c < 3; ++c) val[c] = (val[c] - pv[c]) * sc + a.root_trans[(size_t)b * 3 + c];
+  }
+  for (int c = 0; c < 3; ++c) a.joints[((size_t)b * n_out + j) * 3 + c] = val[c];
+  if (j < 3 && a.pivot) a.pivot[(size_t)b * 3 + j] = pv[j];
+}
+
 __global__ __launch_bounds__(256) void smpl_anchor_kernel(int B, int V, const float* pivot, const float* root_trans,
                                                           const float* root_scale, float* verts) {
   const int b = blockIdx.y;
@@ -1283,7 +1321,8 @@ extern "C" int glamr_smpl_forward(glamr_smpl* h, int B, const float* pose, const
   if (need_tiles && (rc = lbs_pass(jts, h->n_extra_used, two_pass ? nullptr : verts, nullptr, false))) return rc;
   FinishArgs fa{B, w.Bpad, (need_tiles && !orig) ? jts.n_tiles : 0, h->n_extra_used, h->n_picked, h->n_out, orig ? 1 : 0,
                 w.chain, w.picked, w.partial, h->joint_map, h->extra_slot, root_trans, root_scale, joints, w.pivot};
-  hipLaunchKernelGGL(smpl_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, fa);
+  if (fa.n_tiles <= 4 && fa.n_out <= 32) hipLaunchKernelGGL(smpl_finish_small_kernel, dim3((B + 7) / 8), dim3(256), 0, stream, fa);
+  else hipLaunchKernelGGL(smpl_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, fa);
   if (two_pass) {
     // the full mesh: no regression, no picks, vertices re-anchored on the pivot the finish kernel just wrote
     if ((rc = lbs_pass(h->full, 0, verts, root_trans ? w.pivot : nullptr, true))) return rc;

@@ -621,8 +621,14 @@ class GlobalReconOptimizer:
             if getattr(rin, 'verdict', None) is None:
                 return
         from glamr_amd.utils import wire
-        rin.verdict_ready.synchronize()                                 # computed on the stream that consumed the batch
-        v = rin.verdict.cpu().numpy()
+        hv = getattr(rin, 'verdict_host', None)
+        if hv is not None:                                              # (copied with the batch's results: _fetch_async)
+            hv[1].synchronize()
+            v = hv[0].numpy()
+            rin.verdict_host = None
+        else:
+            rin.verdict_ready.synchronize()                             # computed on the stream that consumed the batch
+            v = rin.verdict.cpu().numpy()
         rin.verdict = None
         for kind, msg in ((0, 'smpl_pose_quat_wroot does not hold rotation matrices (|R R^T - I| > 1e-2); the field is named after quaternions but '
                               'carries 24 x 3 x 3 matrices regrouped by 4 (demo.py:320)'), (1, 'an input array contains non-finite values')):
@@ -733,7 +739,7 @@ class GlobalReconOptimizer:
         # first kernels (2.4 ms): 34.7 against 35.4 ms per step (profiles/r06_pipeline_corruption.log).  (Round 5 moved it there to dodge the
         # corruption of its results beside the other stream's attention kernels; with that fixed at its root the order is kept for its speed.)
         # GLAMR_SKIN_AFTER_PRIORS=1 restores the old order (development aid).
-        skin_early = gate is not None and os.environ.get('GLAMR_SKIN_AFTER_PRIORS') != '1' and gate_at in ('priors', 'infiller') \
+        skin_early = gate is not None and os.environ.get('GLAMR_SKIN_AFTER_PRIORS') != '1' and gate_at in ('priors', 'infiller', 'skin') \
             and hasattr(self.mt_model, 'handle')
 
         def skin():
@@ -746,6 +752,8 @@ class GlobalReconOptimizer:
             if skin_early:
                 _lib.check(L.glamr_init_scatter_pose(ctypes.byref(sb), ctypes.byref(pa), _lib.ptr(out_inf['pose']), st))
                 skin()
+                if gate_at == 'skin':
+                    open_gate()                                         # (the next batch's infiller beside this batch's trajectory predictor)
         out = self.mt_model.infer_padded(pa_t['nets_pose'], pa_t['nets_vis'], rin.lens, meps, teps, buffers=rs, coschedule=gate is not None,
                                          between=after_infiller if (skin_early or gate_at == 'infiller') else None)
         if gate_at == 'priors':
@@ -758,7 +766,7 @@ class GlobalReconOptimizer:
             open_gate()
         if not skin_early:
             skin()
-        if gate_at == 'skin':
+        if gate_at == 'skin' and not skin_early:
             open_gate()
         # with flag_init_cam_all_frames this pass is only there for the world poses the cameras are initialised from; whoever needs the 'init'
         # outputs gets them from the second pass (init_forward), or from the first stage's last evaluation
@@ -797,13 +805,22 @@ class GlobalReconOptimizer:
             src['rel'] = packed.t['rel_transform_cam']
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         host = {}
+        rin = packed.keepalive[0] if getattr(packed, 'keepalive', None) else None
         with ctx:
             for k, v in src.items():
                 hbuf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)      # (one pinned slab per batch was measured slower: 3 ms per allocation)
                 hbuf.copy_(v, non_blocking=True)
                 host[k] = hbuf
+            hv = None
+            if rin is not None and getattr(rin, 'verdict', None) is not None:
+                # the wire-format verdict rides along (a blocking .cpu() of its own was 7 ms of host stall per batch: tools/host_profile.py)
+                torch.cuda.current_stream(self.device).wait_event(rin.verdict_ready)
+                hv = torch.empty(rin.verdict.shape, dtype=rin.verdict.dtype, pin_memory=True)
+                hv.copy_(rin.verdict, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
+            if hv is not None:
+                rin.verdict_host = (hv, ev)
         return host, ev
 
     def _materialise(self, datas, packed, stage_vars, fetched=None):
