@@ -221,7 +221,12 @@ def kernel_lines(asset_root, model, dev):
         'workload': 'BASELINE configs[3]: 300-frame 4-person static-camera scenes (cfg glamr_static_multi: %s iterations), batch of %d scenes' % ('+'.join(map(str, iters)), B4),
         'scenes_per_sec': round(B4 / dt, 1), 'ms': round(dt * 1e3, 2), 'stage_launch_ms': [round(x, 2) for x in stage_ms],
         'us_per_scene_iteration': [round(x * 1e3 / n, 1) for x, n in zip(stage_ms, iters)],
-        'shared_camera_reduction': 'in-kernel block reduction of the 9 shared camera gradients (one workgroup per scene); see `collective_alternative`'}
+        'shared_camera_reduction': 'in-kernel block reduction of the 9 shared camera gradients (one workgroup per scene); see `collective_alternative`',
+        # the yardstick of `roofline` for this configuration: a workgroup walks its four persons one after the other (300 frames = 300 threads each),
+        # so the dependent-boundary floor of SURVEY 8(d) K5 (1.45 us per person and iteration) counts four times
+        'roofline': {'bound': 'latency/issue', 'unit': 'us per scene-iteration (lower is better; peak = 4 persons x the 1.45 us dependent-boundary floor)',
+                     'peak': 4 * DEPENDENT_BOUNDARY_US, 'achieved': [round(x * 1e3 / n, 1) for x, n in zip(stage_ms, iters)],
+                     'frac': [round(4 * DEPENDENT_BOUNDARY_US / (x * 1e3 / n), 4) for x, n in zip(stage_ms, iters)], 'traffic': None}}
     # latent-optimisation mode: the priors inside the Adam loop, one 300-frame sequence (what the mode is used on)
     from glamr_amd.global_recon.configs import get_config
     from glamr_amd.global_recon.models import model_dict
@@ -726,7 +731,7 @@ def run(argv=None):
         us_scene_iter = k_avg * 1e3 / iters / rounds
         algo_bytes = B * iters * ALGO_BYTES_PER_PERSON_ITER
         achieved = algo_bytes / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
-        traffic, traffic_src, issue_util, over_compulsory, bytes_si = None, 'no profiles/rNN_pmc_stage_kernel.json', None, None, None
+        traffic, traffic_src, issue_util, over_compulsory, bytes_si, valu_issue = None, 'no profiles/rNN_pmc_stage_kernel.json', None, None, None, None
         pf = pmc_file()
         if pf:
             pmc = json.load(open(pf))
@@ -739,6 +744,17 @@ def run(argv=None):
             if 'SQ_ACTIVE_INST_ANY' in sq and 'SQ_WAVE_CYCLES' in sq:
                 # five waves of a 300-frame scene on the four SIMDs of its CU: issue slots available = 4/5 of the summed wave cycles
                 issue_util = sq['SQ_ACTIVE_INST_ANY']['mean'] / (0.8 * sq['SQ_WAVE_CYCLES']['mean'])
+            inst = pmc.get('counters', {}).get('inst', {})
+            if 'SQ_INSTS_VALU' in inst:
+                # second yardstick: pure VALU issue time -- a wave64 VALU instruction occupies its SIMD for 2 cycles
+                # (MI355X_MICROARCH.md); one wave alone, and the SIMD that carries two of a 300-frame scene's five waves
+                waves = 5 * pmc.get('scenes', B)
+                valu_wave_iter = inst['SQ_INSTS_VALU']['mean'] / (waves * pmc.get('iterations', iters))
+                clock_hz = 2.4e9
+                valu_issue = {'valu_per_wave_iteration': valu_wave_iter, 'cycles_per_valu': 2, 'clock_ghz': clock_hz / 1e9,
+                              'one_wave_us': valu_wave_iter * 2 / clock_hz * 1e6, 'busiest_simd_us': 2 * valu_wave_iter * 2 / clock_hz * 1e6}
+                valu_issue['frac_of_one_wave'] = valu_issue['one_wave_us'] / us_scene_iter if us_scene_iter > 0 else None
+                valu_issue['frac_of_busiest_simd'] = valu_issue['busiest_simd_us'] / us_scene_iter if us_scene_iter > 0 else None
         out = {
             'metric': 'sequences/sec (300-frame, 1-person) end-to-end global_recon', 'value': n_total * args.steps / elapsed,
             'unit': 'sequences/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -763,7 +779,7 @@ def run(argv=None):
                          'frac': DEPENDENT_BOUNDARY_US / us_scene_iter if us_scene_iter > 0 else None,
                          'us_per_scene_iteration': us_scene_iter, 'dependent_boundary_floor_us': DEPENDENT_BOUNDARY_US,
                          'times_above_floor': us_scene_iter / DEPENDENT_BOUNDARY_US,
-                         'issue_slot_utilisation': issue_util, 'traffic_over_compulsory': over_compulsory, 'traffic_bytes_per_scene_iteration': bytes_si,
+                         'issue_slot_utilisation': issue_util, 'valu_issue_yardstick': valu_issue, 'traffic_over_compulsory': over_compulsory, 'traffic_bytes_per_scene_iteration': bytes_si,
                          'compulsory_bytes_per_scene_iteration': ALGO_BYTES_PER_PERSON_ITER / float(iters),
                          'contract_notional': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'contract_notional_frac': achieved / HBM_PEAK_GBS,
                                                'note': '%d B per person-iteration (SURVEY.md 8d K5 live state) x %d scenes x %d iterations / launch time: bytes the '
@@ -781,12 +797,12 @@ def run(argv=None):
             'replay_check': replay_check,
             'pipeline': None if not coschedule else {
                 'coscheduled_streams': True, 'stage_launch_ms_alone': k_avg, 'stage_launch_ms_beside_the_priors': beside,
-                'critical_cycle': 'round 5: per batch and stream -- preparation (ahead of the gate in the three-graph cut), infiller I beside the other batch\'s stage '
-                                  '(28 ms), then, when that stage has retired, skinning (1.4 ms, alone on the GPU: beside the next batch\'s first kernels it was measured to '
-                                  'read other workgroups\' LDS, see replay_check) and trajectory predictor P (4.3 ms, LDS kernels), gate, scene assembly + forward-only '
-                                  'launch (0.5 ms), stage S (27 ms beside the next infiller; 22.1 alone).  Period = I + skinning + P + gaps: the infiller\'s last kernel '
-                                  'ends 2.6 ms after the other batch\'s stage (profiles/r05_gap_trace.log), so the stage has slack and a faster infiller is a faster step '
-                                  '(profiles/r05_pipeline_experiments.log)',
+                'critical_cycle': 'per batch and stream -- preparation (ahead of the gate: three-graph cut), infiller I beside the other batch\'s stage (~27 ms), then, when '
+                                  'that stage has retired, skinning (1.4 ms) and trajectory predictor P (4.4 ms, LDS kernels), gate, scene assembly + forward-only launch '
+                                  '(0.3 ms), stage S (~27.7 ms beside the next infiller; 21.7 alone).  I and S end together; P + skinning + assembly (6.5 ms) are serial: '
+                                  'profiles/r06_gap_trace.log.  The skinning sits before the gate because it is faster alone (34.7 against 35.4 ms per step), not to avoid '
+                                  'anything: the corruption rounds 4 - 5 saw there was packed-fp32 arithmetic going wrong beside the other stream\'s MFMA kernels, removed at '
+                                  'its root in round 6 (profiles/r06_pipeline_corruption.log, glamr_amd/build.py)',
                 'note': 'two streams, batches staggered by GlobalReconOptimizer.pipeline_gate: a batch starts when the previous one\'s priors are done, so its '
                         'motion infiller -- LDS-free one-wave kernels on fragment-major activations (csrc/nn_free.hpp) -- runs in the SIMD issue slots and '
                         'matrix pipes a resident stage workgroup leaves idle.  The stage launch is slower beside them than alone; the step is shorter '
