@@ -363,6 +363,11 @@ def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8, group=
             'person_sharded_us_per_iteration': t_s / n_stage_iters * 1e6,
             'person_sharded_collective_host_us_per_iteration': sched.collective_seconds / n_stage_iters * 1e6,
             'launches_per_iteration': sched.launches / float(n_stage_iters),
+            # iterations 2 .. n - 1 of a stage are replays of ONE captured graph (forward-only launch, all-gather, gradient launch, all-reduce, Adam):
+            # their device time per iteration, without the two plain iterations and the capture a stage starts with (a real stage has 200 - 500)
+            'person_sharded_replayed_us_per_iteration': (sum(a.elapsed_time(b) for a, b, _ in sched.replay_events) * 1e3 / max(1, sum(k for _, _, k in sched.replay_events))
+                                                         if getattr(sched, 'replay_events', None) else None),
+            'iteration_graphs': getattr(sched, 'iteration_graphs', 0),
             'median_projection_difference_px': diff,
             'note': 'per iteration the sharded form pays 2 stage launches (forward-only + gradient), an all-gather of 4 x 300 x 6 floats, an all-reduce of the '
                     'shared camera gradient and the Adam launch; the default keeps the scene in one workgroup for all iterations of a stage'}

@@ -168,13 +168,13 @@ class PersonShardedSchedule:
     def _all_gather_poses(self, packed, own, block):
         """Own persons' (orient_world, trans_world) of every scene -> everybody; the others' land in the base arrays of their frozen slots."""
         import time
+        if not self.use_dist:
+            return
         S, P, T = packed.S, packed.P, packed.T
         ow, tw = packed.t['orient_world'].view(S, P, T, 3), packed.t['trans_world'].view(S, P, T, 3)
         mine = torch.zeros((block, S, T, 6), dtype=torch.float32, device=ow.device)
         for k, pi in enumerate(own):
             mine[k, :, :, :3], mine[k, :, :, 3:] = ow[:, pi], tw[:, pi]
-        if not self.use_dist:
-            return
         t0 = time.time()
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
@@ -213,7 +213,9 @@ class PersonShardedSchedule:
                 raise NotImplementedError('stage %r derives the camera from the persons: not covered by the person-sharded exchange' % stage)
             n = spec['opt_niters'] if max_iters is None else min(max_iters, spec['opt_niters'])
             m, v = torch.zeros_like(params), torch.zeros_like(params)
-            for it in range(n):
+            not_own = [pi for pi in range(P) if pi not in own]
+
+            def iteration(it, adam):
                 keep = packing.FLAG_KEEP_CAM_PARAMS if it > 0 else 0
                 fwd = packing.stage_desc(spec, model_specs, has_wd, niters=0)
                 fwd.flags |= keep | packing.FLAG_POSES_ONLY                         # (only the world poses are wanted: no residuals, no projections)
@@ -224,15 +226,20 @@ class PersonShardedSchedule:
                 gd.flags |= packing.FLAG_KEEP_CAM_PARAMS | (packing.FLAG_NO_CAMERA_TERMS if self.rank != 0 else 0)
                 grads = self.run_stage(packed, gd, True)                             # 3.
                 self.launches += 2
-                cam = grads[:, :l['person0']].contiguous()
-                self._all_reduce(cam)                                                # 4.
-                grads[:, :l['person0']] = cam
-                for pi in range(P):
-                    if pi not in own:
-                        grads[:, person_cols[pi]] = 0.0
+                if self.use_dist:
+                    cam = grads[:, :l['person0']].contiguous()
+                    self._all_reduce(cam)                                            # 4.
+                    grads[:, :l['person0']] = cam
+                for pi in not_own:
+                    grads[:, person_cols[pi]] = 0.0
                 if self.grad_hook is not None:
                     self.grad_hook(packed, stage, spec, grads)
-                self.adam_step(params.view(-1), m.view(-1), v.view(-1), grads.view(-1), spec['opt_lr'], it + 1)      # 5.
+                adam(grads)                                                          # 5.
+
+            graph = self._iteration_graph(packed, params, m, v, spec['opt_lr'], n, iteration) if n > 2 else None
+            if graph is None:
+                for it in range(n):
+                    iteration(it, lambda g, it=it: self.adam_step(params.view(-1), m.view(-1), v.view(-1), g.view(-1), spec['opt_lr'], it + 1))
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
@@ -243,6 +250,58 @@ class PersonShardedSchedule:
         packed.t['frozen'] = None
         packed.has_world_dheading = has_wd
         return packed
+
+    def _iteration_graph(self, packed, params, m, v, lr, n, iteration):
+        """Iterations 1 .. n - 1 of a stage as replays of ONE captured HIP graph (device entry points only): forward-only launch, all-gather, gradient
+        launch, all-reduce, Adam -- five launches and two collectives enqueued by a single graph launch, the Adam step number read from a device
+        counter (glamr_adam_step_indexed / glamr_counter_add).  Host-orchestrated the same sequence costs ~420 us per iteration against ~100 us of
+        kernel time (bench.py `configs3_person_sharded`): on an 8-GPU node that would measure launches, not links.  Iteration 0 runs plainly (it
+        initialises the camera parameters and every lazily built table; RCCL communicators must exist before a capture).  Returns True when the
+        whole stage has run; None = not applicable (injected run_stage / adam_step, CPU tensors, GLAMR_SHARDED_GRAPH=0) or the capture failed, in
+        which case nothing of the stage has run and the caller's plain loop takes over."""
+        import os
+        if self.run_stage is not _device_run_stage or self.adam_step is not _device_adam_step or not params.is_cuda or os.environ.get('GLAMR_SHARDED_GRAPH', '1') == '0':
+            return None
+        import ctypes
+        import numpy as np
+        from . import _lib
+        L = _lib.lib()
+        tab = np.zeros((n, 2), np.float32)
+        _lib.check(L.glamr_adam_coef_table(ctypes.c_double(float(lr)), int(n), _lib.ptr(tab)))
+        tab_d = torch.from_numpy(tab).to(params.device)
+        step = torch.zeros(1, dtype=torch.int32, device=params.device)
+
+        def adam_indexed(g):
+            st = _lib.current_stream()
+            _lib.check(L.glamr_adam_step_indexed(params.numel(), _lib.ptr(params), _lib.ptr(m), _lib.ptr(v), _lib.ptr(g), _lib.ptr(tab_d), _lib.ptr(step), st))
+            _lib.check(L.glamr_counter_add(_lib.ptr(step), 1, st))
+        snapshot = (params.clone(), m.clone(), v.clone(), self.launches)
+        try:
+            iteration(0, adam_indexed)
+            iteration(1, adam_indexed)                                              # (a plain iteration of the captured kind first: allocations, attribute calls)
+            torch.cuda.synchronize(params.device)
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=params.device)
+            side.wait_stream(torch.cuda.current_stream(params.device))
+            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                iteration(2, adam_indexed)                                          # (iteration number only selects KEEP_CAM_PARAMS: any it > 0 is the same graph)
+            self.launches -= 2                                                      # (capturing launched nothing)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(2, n):
+                g.replay()
+                self.launches += 2
+            ev1.record()
+            self.__dict__.setdefault('replay_events', []).append((ev0, ev1, n - 2))      # (device time of the replayed iterations: bench.py)
+            self.iteration_graphs = getattr(self, 'iteration_graphs', 0) + 1
+            return True
+        except Exception as e:      # noqa: BLE001 -- anything (a runtime without capturable collectives, ...): restore and let the plain loop run
+            import sys
+            sys.stderr.write('PersonShardedSchedule: iteration graph not used (%s)\n' % e)
+            torch.cuda.synchronize(params.device)
+            params.copy_(snapshot[0]); m.copy_(snapshot[1]); v.copy_(snapshot[2])
+            self.launches = snapshot[3]
+            return None
 
     def _reduce_losses(self, packed, own):
         """packed.t['losses'] after a sharded run: every rank's last evaluation reported ITS part -- the residuals of its own persons over the
