@@ -53,6 +53,12 @@ constexpr int NJ = 26;
 #ifndef GLAMR_KP_DEPTH
 #define GLAMR_KP_DEPTH 3      // keypoint rows requested ahead of the one being processed (grecon_algo.hpp phase E; GLAMR_KP_GROUP=0 builds only)
 #endif
+#ifndef GLAMR_KP_FOLD
+// 1 (default since round 6): a keypoint row costs 43 instead of 52 VALU instructions (joint_nb: fused chains started from q, the robust term's constant
+// factors folded into the table's weight column, out-of-range rows through a zero weight) -- stage launch 21.7 -> 20.9 ms (profiles/r06_stage_ab.log).
+// The kernel is issue-bound on the SIMD that carries two of a scene's five waves, so its time follows the instruction count.  0 = rounds 4-5's arithmetic.
+#define GLAMR_KP_FOLD 1
+#endif
 #ifndef GLAMR_KP_GROUP
 #define GLAMR_KP_GROUP 3      // workspace keypoint rows per group (requested a whole group ahead, processed without branches); 0 = the one-row ring
 #endif
@@ -846,6 +852,10 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   // launch of every iteration of the launch-by-launch schedules) stops after phase D: it needs neither the visibility tables nor the
   // normalisers nor the per-joint score sums -- 0.40 -> 0.2 ms of a launch that sits on the pipeline's critical chain (round 5).
   const bool poses_only = st.niters == 0 && (st.flags & GLAMR_FLAG_POSES_ONLY) && !cam_from_person;
+  // The keypoint row's arithmetic with folded constants (GLAMR_KP_FOLD, joint_nb) -- except where the camera rides on the person (cfg glamr_3dpw):
+  // there the first Adam steps are lr x the SIGN of gradients that are rounding noise, the reference's sign is reproduced by rounds 4-5's operation
+  // order (0.002 px after 15 steps against 0.20 px with any other: tests/grecon_common.py KSTEP_TOL), and that order is kept, as for the scans.
+  const bool kp_fold = GLAMR_KP_FOLD != 0 && !cam_from_person;
   if (!poses_only) setup_tables(rt, sc);
   // ---- stage setup: normalisers, Adam state, camera parameters from the current camera (get_parameter :596-606) ----------
   float n_vis_total = 0.f, n_exist = 0.f, n_exist_m1 = 0.f;
@@ -962,7 +972,9 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
         for (int k = 0; k < 3; ++k) o[k * sc.TM] = c.j_local[((size_t)t * NJ + j) * 3 + k];
         o[3 * sc.TM] = c.kp_2d[((size_t)t * NJ + j) * 2 + 0];
         o[4 * sc.TM] = c.kp_2d[((size_t)t * NJ + j) * 2 + 1];
-        o[5 * sc.TM] = w;
+        // kp_fold: the table's weight column carries the constant factor of the robust term's derivative as well, 2 sigma^4 = 2e8 (only
+        // iterations that are not the last read the table: the last evaluation, which reports the loss VALUE, walks the full arrays)
+        o[5 * sc.TM] = kp_fold ? w * 2e8f : w;
       }
     }
   }
@@ -1415,6 +1427,26 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
+                if (kp_fold) {
+                // 43 instead of 52 operations per joint: the homogeneous point as three fused chains started from q, the constant factor 2e8 in the
+                // table's weight column, rows outside the range through a zero WEIGHT (one select) instead of three selected products
+                const float wgt = (in_range ? cur[5] : 0.f) * w_kp;
+                const float hx = rm::fma_(H[2], cur[2], rm::fma_(H[1], cur[1], rm::fma_(H[0], cur[0], q[0])));
+                const float hy = rm::fma_(H[5], cur[2], rm::fma_(H[4], cur[1], rm::fma_(H[3], cur[0], q[1])));
+                const float hz = rm::fma_(H[8], cur[2], rm::fma_(H[7], cur[1], rm::fma_(H[6], cur[0], q[2]))) + 1e-8f;
+                const float ihz = rm::rcp_(hz);
+                const float u = hx * ihz, v = hy * ihz;
+                const float du = u - cur[3], dv = v - cur[4];
+                const float ru = rm::rcp_(rm::fma_(du, du, 1e4f)), rv = rm::rcp_(rm::fma_(dv, dv, 1e4f));
+                const float gu = ((du * ru) * ru) * wgt, gv = ((dv * rv) * rv) * wgt;
+                const float g2 = -rm::fma_(gu, u, gv * v);
+                const float gh[3] = {gu * ihz, gv * ihz, g2 * ihz};
+                for (int i = 0; i < 3; ++i) {
+                  for (int k = 0; k < 3; ++k) gH[i * 3 + k] = rm::fma_(gh[i], cur[k], gH[i * 3 + k]);
+                  gq[i] = gq[i] + gh[i];
+                }
+                return;
+                }
                 const float hx = rm::fma_(H[2], cur[2], rm::fma_(H[1], cur[1], H[0] * cur[0])) + q[0];
                 const float hy = rm::fma_(H[5], cur[2], rm::fma_(H[4], cur[1], H[3] * cur[0])) + q[1];
                 const float hz = (rm::fma_(H[8], cur[2], rm::fma_(H[7], cur[1], H[6] * cur[0])) + q[2]) + 1e-8f;
