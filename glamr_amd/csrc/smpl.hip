@@ -341,7 +341,11 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sDirs = smem;                                   // [3][32][KSTRIDE]
   float* sOut = smem + (F16 ? 3 * 2 * TILE_V * KSH / 2 : 3 * TILE_V * KSTRIDE);      // [4 waves][32 frames][OUT_STRIDE]  (only when verts != null)
-  const int tile = blockIdx.x;
+  // workgroup -> vertex tile: workgroups go to the 8 XCDs round robin by their linear id (x fastest; 216 tiles: the phase is the same in every y
+  // row), so tiles x and x + 1 wrote the two ends of a shared 128-byte line of every frame row from two different L2s.  XCD i takes a CONTIGUOUS
+  // range of tiles instead: neighbouring 384-byte runs of a frame row meet in one L2 (vertex pass at B = 19 200: 1.13 -> 1.06 ms, same bits).
+  const int xq = a.n_tiles >> 3, xr = a.n_tiles & 7, xi = blockIdx.x & 7;
+  const int tile = xi * xq + min(xi, xr) + (blockIdx.x >> 3);
   const int v0 = tile * TILE_V;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
@@ -465,6 +469,17 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
     // skinning: out_r = T_r0 px + T_r1 py + T_r2 pz + T_r3,  T_e[v, b] = sum_j W[v, j] A_e[b, j]
     const float* arow = a.askin + (size_t)b * 12 * NJ + half * 12;
     f32x16 out[3];
+    const bool frame_ok = b < a.B;
+    // the frame's re-anchoring constants (lane = frame) are requested HERE, a skinning phase ahead of their use: asked for where the vertices leave
+    // the accumulators, every frame tile waited a memory round trip for them (s_waitcnt vmcnt(0) between the last MFMA and the first subtraction).
+    // (a fused v * scale + (trans - pivot * scale) and a nested-fma form of the skinning sum were measured as well: 100 fewer VALU operations per frame
+    // tile, no faster -- the epilogue's arithmetic is not what the tile waits for -- and not kept: the results keep their bits)
+    float anc_pv[3] = {0.f, 0.f, 0.f}, anc_tr[3] = {0.f, 0.f, 0.f}, anc_sc = 1.0f;
+    if (a.pivot && frame_ok) {
+      anc_sc = a.root_scale ? a.root_scale[b] : 1.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { anc_pv[r] = a.pivot[(size_t)b * 3 + r]; anc_tr[r] = a.root_trans[(size_t)b * 3 + r]; }
+    }
     if (F16) {
       // joint transforms, fragment-major: entry e = 4 r + c, (plane, k step m) -> one contiguous 1 KB read per wave.  Twelve phases
       // (r, m, pair of c) of four fetches and six MFMAs each; the fetches of a phase are requested before the MFMAs of the one before it
@@ -516,15 +531,11 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
         out[r] = T[0] * px + T[1] * py + T[2] * pz + T[3];
       }
     }
-    const bool frame_ok = b < a.B;
     if (a.pivot && frame_ok) {      // re-anchor on output joint 0 (lane = frame: three pivots, three translations, one scale per lane)
-      const float sc = a.root_scale ? a.root_scale[b] : 1.0f;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float pv = a.pivot[(size_t)b * 3 + r], tr = a.root_trans[(size_t)b * 3 + r];
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[r][q] = (out[r][q] - pv) * sc + tr;
-      }
+        for (int q = 0; q < 16; ++q) out[r][q] = (out[r][q] - anc_pv[r]) * anc_sc + anc_tr[r];
     }
     // extra-joint regression partial sums: sum over this tile's 32 vertices (16 rows here + 16 in the other half)
     if (NE > 0) {
@@ -598,7 +609,8 @@ __global__ __launch_bounds__(F16 ? 512 : 256) void smpl_lbs_kernel(LbsArgs a) {
             for (int k = 0; k < 4; ++k) {
               float* d = dst + (size_t)(h + k) * fstride2;
               if (mine && bb0 + 2 * (h + k) < a.B) {
-                if (nhere >= 4) *reinterpret_cast<f32x4*>(d) = piece[k];
+                // (non-temporal: 1.6 GB of vertices per 19 200 frames stream through the L2s, nobody reads them back here -- 1.06 -> 0.97 ms)
+                if (nhere >= 4) __builtin_nontemporal_store(piece[k], reinterpret_cast<f32x4*>(d));
                 else { d[0] = piece[k][0]; if (nhere > 1) d[1] = piece[k][1]; if (nhere > 2) d[2] = piece[k][2]; }
               }
             }

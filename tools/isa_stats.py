@@ -60,3 +60,9 @@ for k, t in enumerate(lines):
 if best:
     c = collections.Counter(t.split()[0] for t in lines[best[0]:best[1]] if not t.startswith('.'))
     print('iteration loop: %d instructions, %d VALU (static; the joint loop inside runs ~14 times)' % (sum(c.values()), sum(n for o, n in c.items() if o.startswith('v_'))))
+    # opcode histogram of the loop (GLAMR_ISA_HIST=1): the kernel is issue-bound on the SIMD with two waves, so its time follows this count
+    if os.environ.get('GLAMR_ISA_HIST'):
+        for o, n in c.most_common(45):
+            print('   %-28s %5d' % (o, n))
+    if os.environ.get('GLAMR_ISA_DUMP'):
+        open(os.environ['GLAMR_ISA_DUMP'], 'w').write('\n'.join(lines[best[0]:best[1]]))
