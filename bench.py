@@ -373,6 +373,33 @@ def person_sharded_line(asset_root, dev, rank, world, iters=20, scenes=8, group=
                     'shared camera gradient and the Adam launch; the default keeps the scene in one workgroup for all iterations of a stage'}
 
 
+HARD_EXIT = []      # reasons why this rank must leave without tearing its process group down (see `guarded`)
+
+
+def guarded(fn, dev, seconds):
+    """fn() on a worker thread with a wall-clock limit: (result, None) or (None, reason).  After a time-out the thread may still sit in a collective:
+    the caller must not touch the process group again and leaves through os._exit."""
+    import threading
+    import torch
+    box = {}
+
+    def work():
+        try:
+            if dev.type == 'cuda':
+                torch.cuda.set_device(dev)
+            box['result'] = fn()
+        except BaseException as e:      # noqa: BLE001 -- reported by the caller; the headline must not depend on this line
+            box['error'] = '%s: %s' % (type(e).__name__, e)
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return None, 'no result after %.0f s' % seconds
+    if 'error' in box:
+        return None, box['error']
+    return box['result'], None
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: this file re-executed under torch.distributed.run (glamr_amd.parallel.self_launch); rank 0's
     JSON line is the only line on stdout."""
@@ -707,7 +734,15 @@ def run(argv=None):
             n_sh = min(world, 4)
             grp = dist.new_group(list(range(n_sh))) if world > n_sh else None
             if rank < n_sh:
-                sharded4 = person_sharded_line(asset_root, dev, rank, n_sh, group=grp)
+                # This is the ONE part of the run whose collectives sit on the data path, and no multi-GPU box was ever available to rehearse it:
+                # it runs under a wall-clock guard on every rank.  A rank whose guard expires (a peer failed and the collectives wait for it) or
+                # whose call raised gives up the line; rank 0 then prints the headline without it and every rank leaves through os._exit
+                # (a process group with a collective in flight cannot be torn down).
+                sharded4, abandoned = guarded(lambda: person_sharded_line(asset_root, dev, rank, n_sh, group=grp), dev,
+                                              float(os.environ.get('GLAMR_BENCH_SHARDED_TIMEOUT', '240')))
+                if abandoned:
+                    sys.stderr.write('bench: person-sharded line abandoned on rank %d (%s)\n' % (rank, abandoned))
+                    HARD_EXIT.append(abandoned)
         elif world == 1 and on_gpu:
             # a single-GPU run has no process group: one of ONE rank is created for this line alone, so that the RCCL calls of the
             # person-sharded schedule execute here too (nothing crosses a link: the figure is the launch + completion cost per iteration)
@@ -831,6 +866,10 @@ def run(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(asset_root)
         print(json.dumps(out))
+    if HARD_EXIT:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if use_dist:
         dist.destroy_process_group()
     return out

@@ -499,6 +499,9 @@ int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const flo
     return launch_rows(st, X, D, M, D, nullptr, 0, nullptr, nullptr, 1, 0, L.Ws, (size_t)D * L.K, L.K, L.b, ACT_NONE, R, D, n.g, n.b, Y, D);
   static const bool res_in_ln = std::getenv("GLAMR_NETS_RES_IN_LN") != nullptr;      // development aid (A/B)
   if (tl_free && !res_in_ln) {      // the residual in the GEMM's epilogue (same sum, same order): the three-pass LayerNorm then streams ONE array
+#ifdef GLAMR_LN_PROBE      // timing probe only (WRONG values): what the step would cost without the LayerNorm launches
+    return lin(st, L, X, D, Y, D, M, ACT_NONE, R, D);
+#endif
     RC(lin(st, L, X, D, tmp, D, M, ACT_NONE, R, D));
     return ln(st, tmp, nullptr, n, Y, M);
   }
@@ -515,6 +518,9 @@ int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float*
   if (!n) return lin(st, L2, hidden, FF, Y, D, M, act2, R, D);
   static const bool res_in_ln2 = std::getenv("GLAMR_NETS_RES_IN_LN") != nullptr;
   if (tl_free && !res_in_ln2) {
+#ifdef GLAMR_LN_PROBE
+    return lin(st, L2, hidden, FF, Y, D, M, act2, R, D);
+#endif
     RC(lin(st, L2, hidden, FF, tmp, D, M, act2, R, D));
     return ln(st, tmp, nullptr, *n, Y, M);
   }

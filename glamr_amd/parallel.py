@@ -260,7 +260,11 @@ class PersonShardedSchedule:
         whole stage has run; None = not applicable (injected run_stage / adam_step, CPU tensors, GLAMR_SHARDED_GRAPH=0) or the capture failed, in
         which case nothing of the stage has run and the caller's plain loop takes over."""
         import os
-        if self.run_stage is not _device_run_stage or self.adam_step is not _device_adam_step or not params.is_cuda or os.environ.get('GLAMR_SHARDED_GRAPH', '1') == '0':
+        # With more than one rank the captured iteration (collectives inside a HIP graph) is OPT-IN (GLAMR_SHARDED_GRAPH=1): it has only ever run
+        # on a process group of one rank -- no multi-GPU box was available to this project -- and a capture that fails on one rank alone would
+        # leave the ranks in different collective sequences (a hang, not an error).  The plain loop is what the world_size-2 tests cover.
+        knob = os.environ.get('GLAMR_SHARDED_GRAPH', '1' if self.world <= 1 else '0')
+        if self.run_stage is not _device_run_stage or self.adam_step is not _device_adam_step or not params.is_cuda or knob == '0':
             return None
         import ctypes
         import numpy as np
