@@ -85,6 +85,24 @@ int up_vec(float** dst, const std::vector<double>& v, size_t pad_to = 0) {
   for (size_t i = 0; i < v.size(); ++i) f[i] = (float)v[i];
   return upload_t(dst, f.data(), f.size());
 }
+// W [Np][K] (Np a multiple of 64, K of 32) as two fp16 planes in the fragment order the split-fp16 kernels fetch
+std::vector<unsigned short> split_planes(const std::vector<float>& f, int Np, int K) {
+  // fp32 ~ hi + lo in fp16 (round to nearest even; the remainder is exact in fp32), see nn_kernels.hpp
+  auto f16_bits = [](float x) -> unsigned short { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
+  auto f16_val = [](float x) -> float { return (float)(_Float16)x; };
+  // fragment order of v_mfma_f32_32x32x16_f16's B operand: [32-column block][16-deep k step][lane = column % 32 + 32 (k % 16 / 8)][k % 8]
+  std::vector<unsigned short> planes(2 * f.size());
+  const int ksteps = K / 16;
+  for (int n = 0; n < Np; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float x = f[(size_t)n * K + k];
+      const float r1 = x - f16_val(x);
+      const size_t dst = (((size_t)(n / 32) * ksteps + k / 16) * 64 + (n % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8;
+      planes[dst] = f16_bits(x); planes[f.size() + dst] = f16_bits(r1);
+    }
+  return planes;
+}
+
 // upload W [N][K] padded to [ceil64(N)][ceil32(K)]
 int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
   L.N = W.r;
@@ -102,19 +120,7 @@ int up_lin(Lin& L, const HostT& W, const std::vector<double>* bias) {
   int rc = upload_t(&L.W, f.data(), f.size());
   if (rc) return rc;
   {
-    // fp32 ~ hi + lo in fp16 (round to nearest even; the remainder is exact in fp32), see nn_kernels.hpp
-    auto f16_bits = [](float x) -> unsigned short { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
-    auto f16_val = [](float x) -> float { return (float)(_Float16)x; };
-    // fragment order of v_mfma_f32_32x32x16_f16's B operand: [32-column block][16-deep k step][lane = column % 32 + 32 (k % 16 / 8)][k % 8]
-    std::vector<unsigned short> planes(2 * f.size());
-    const int ksteps = L.K / 16;
-    for (int n = 0; n < Np; ++n)
-      for (int k = 0; k < L.K; ++k) {
-        const float x = f[(size_t)n * L.K + k];
-        const float r1 = x - f16_val(x);
-        const size_t dst = (((size_t)(n / 32) * ksteps + k / 16) * 64 + (n % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8;
-        planes[dst] = f16_bits(x); planes[f.size() + dst] = f16_bits(r1);
-      }
+    const std::vector<unsigned short> planes = split_planes(f, Np, L.K);
     if ((rc = upload_t(&L.Ws, planes.data(), planes.size()))) return rc;
   }
   if (bias) return up_vec(&L.b, *bias, Np);
@@ -477,8 +483,24 @@ int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const flo
 int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float* X, int ldx, const float* R, float* Y, float* hidden, float* tmp, int M,
          int act2, int xl = -1);
 
+// Few rows (a window of one sequence has 50: the latent-optimisation mode makes ~335 such products forward and ~335 backward per iteration):
+// gemm_kernel walks K with v_mfma_f32_32x32x2_f32 on ONE accumulator per wave -- a chain of K / 2 dependent 64-cycle instructions, 3.4 us at
+// K = 256 and 6.8 at 512 inside a 12 us kernel.  The one-wave split-fp16 kernel of nn_free.hpp (three v_mfma_f32_32x32x16_f16 per 16 k on two
+// column tiles, operands one step ahead, no LDS, no barrier) does the same product in 1.3 / 2.6 us of matrix time, on row-major rows as they are.
+// It takes the BACKWARD products (lin_bwd: gradient rows times transposed weights; 12.8 -> 11.2 ms per iteration of the mode).  The forward
+// products of few rows stay on the fp32 instruction: with them on the split kernel as well the mode runs at 10.5 ms, but the first gradient of
+// the motion latent moves by 3.8e-6 of its largest entry and, eight Adam steps later, the latent of one of the three reference fixtures is 9.5e-4
+// away instead of 1.4e-6 (Adam's first steps are sign-like: an entry whose gradient is ~0 takes a full step the other way) -- outside the 1e-4
+// tests/test_latent_gpu.py holds it to.  GLAMR_GEMM_SMALL_SPLIT_FWD=1 selects that variant, GLAMR_GEMM_SMALL_FP32=1 the fp32 kernel throughout.
+inline bool small_rows_split(const Lin& L, int M, int ldx, int ldy, int ldr, int ldrb, bool bwd) {
+  static const bool keep_fp32 = std::getenv("GLAMR_GEMM_SMALL_FP32") != nullptr || std::getenv("GLAMR_GEMM_FP32_MFMA") != nullptr;
+  static const bool fwd_too = std::getenv("GLAMR_GEMM_SMALL_SPLIT_FWD") != nullptr;
+  if (!bwd && !fwd_too) return false;
+  return !keep_fp32 && !tl_fp32 && L.Ws && M > 0 && M < 2048 && L.K % 32 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && ldrb % 4 == 0;
+}
+
 int lin(hipStream_t st, const Lin& L, const float* X, int ldx, float* Y, int ldy, int M, int act = ACT_NONE, const float* R = nullptr, int ldr = 0,
-        const float* rowbias = nullptr, int rpg = 1, int ldrb = 0, int xl = -1, int yl = -1) {
+        const float* rowbias = nullptr, int rpg = 1, int ldrb = 0, int xl = -1, int yl = -1, bool bwd = false) {
   // xl / yl (free mode only): layout of X, resp. Y and R -- 1 fragment-major (the default there), 0 row-major (what an LDS kernel or a small
   // elementwise kernel produced / will consume)
   if (tl_free && L.Ws && M > 0) {
@@ -490,6 +512,12 @@ int lin(hipStream_t st, const Lin& L, const float* X, int ldx, float* Y, int ldy
     a.y_frag = yl != 0;
     return launch_gemm_free(st, a);
   }
+  if (small_rows_split(L, M, ldx, ldy, R ? ldr : 4, rowbias ? ldrb : 4, bwd)) {
+    GemmArgs a{X, L.W, L.b, rowbias, R, Y, M, L.N, L.K, ldx, ldy, ldr, rpg, ldrb, act};
+    a.Ws = L.Ws;
+    a.ws_plane = (size_t)((L.N + 63) / 64 * 64) * L.K;
+    return launch_gemm_free(st, a);                       // (row-major X, Y and R: x_frag = y_frag = 0)
+  }
   return launch_gemm(st, X, ldx, L.W, L.b, Y, ldy, M, L.N, L.K, act, R, ldr, rowbias, rpg, ldrb, L.Ws);
 }
 
@@ -499,9 +527,6 @@ int proj_ln(hipStream_t st, const Lin& L, const LN& n, const float* X, const flo
     return launch_rows(st, X, D, M, D, nullptr, 0, nullptr, nullptr, 1, 0, L.Ws, (size_t)D * L.K, L.K, L.b, ACT_NONE, R, D, n.g, n.b, Y, D);
   static const bool res_in_ln = std::getenv("GLAMR_NETS_RES_IN_LN") != nullptr;      // development aid (A/B)
   if (tl_free && !res_in_ln) {      // the residual in the GEMM's epilogue (same sum, same order): the three-pass LayerNorm then streams ONE array
-#ifdef GLAMR_LN_PROBE      // timing probe only (WRONG values): what the step would cost without the LayerNorm launches
-    return lin(st, L, X, D, Y, D, M, ACT_NONE, R, D);
-#endif
     RC(lin(st, L, X, D, tmp, D, M, ACT_NONE, R, D));
     return ln(st, tmp, nullptr, n, Y, M);
   }
@@ -518,9 +543,6 @@ int mlp2(hipStream_t st, const Lin& L1, const Lin& L2, const LN* n, const float*
   if (!n) return lin(st, L2, hidden, FF, Y, D, M, act2, R, D);
   static const bool res_in_ln2 = std::getenv("GLAMR_NETS_RES_IN_LN") != nullptr;
   if (tl_free && !res_in_ln2) {
-#ifdef GLAMR_LN_PROBE
-    return lin(st, L2, hidden, FF, Y, D, M, act2, R, D);
-#endif
     RC(lin(st, L2, hidden, FF, tmp, D, M, act2, R, D));
     return ln(st, tmp, nullptr, *n, Y, M);
   }

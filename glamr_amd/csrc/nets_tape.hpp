@@ -238,6 +238,12 @@ const Lin* transposed(glamr_nets* h, const Lin& L) {
   if (hipMalloc(reinterpret_cast<void**>(&T.W), Wt.size() * sizeof(float)) != hipSuccess) return nullptr;
   if (hipMemcpy(T.W, Wt.data(), Wt.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   h->allocs.push_back(T.W);
+  if (L.Ws) {      // the layer is cleared for the split-fp16 kernels (range analysis of glamr_nets_create): so is its transpose, entry for entry
+    const std::vector<unsigned short> planes = split_planes(Wt, Tp, T.K);
+    if (hipMalloc(reinterpret_cast<void**>(&T.Ws), planes.size() * sizeof(unsigned short)) != hipSuccess) return nullptr;
+    if (hipMemcpy(T.Ws, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    h->allocs.push_back(T.Ws);
+  }
   return &h->lin_T.emplace(&L, T).first->second;
 }
 
@@ -252,7 +258,7 @@ int lin_bwd(const TapeCtx& c, const Lin& L, float* dY, int ldy, const float* Y, 
   const Lin* T = transposed(c.h, L);
   if (!T) return fail(GLAMR_E_HIP, "could not build the transposed weights of a layer");
   if (T->K > ldy) return fail(GLAMR_E_INVALID, "lin_bwd: gradient rows of %d floats, %d needed", ldy, T->K);
-  return launch_gemm(c.st, dY, ldy, T->W, nullptr, dX, ldx, M, T->N, T->K, ACT_NONE, dX, ldx);      // accumulates through the residual input
+  return lin(c.st, *T, dY, ldy, dX, ldx, M, ACT_NONE, dX, ldx, nullptr, 1, 0, -1, -1, true);      // accumulates through the residual input (few rows: the one-wave split-fp16 kernel)
 }
 int ln_bwd(const TapeCtx& c, const LN& n, const float* dY, const float* X, const float* R, float* dX, float* dR, int rows) {
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, c.st, dY, X, R, n.g, dX, dR, rows);
