@@ -288,11 +288,11 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   else if (ka.use_lds == 3 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<3, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<3, true, 2>, dyn) : launch(grecon_stage_kernel<3, true, 0>, dyn);
   else if (ka.use_lds == 1 || ka.use_lds == 3)      // several persons: the two full-arena modes are the same layout
-    rc = cam == 1 ? launch(grecon_stage_kernel<1, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, false, 2>, dyn) : launch(grecon_stage_kernel<1, false, 0>, dyn);
+    rc = cam == 1 ? launch(grecon_stage_kernel<1, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, false, 2>, dyn) : cam == 3 ? launch(grecon_stage_kernel<1, false, 3>, dyn) : launch(grecon_stage_kernel<1, false, 0>, dyn);
   else if (ka.use_lds == 2 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<2, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, true, 2>, dyn) : launch(grecon_stage_kernel<2, true, 0>, dyn);
   else if (ka.use_lds == 2)
-    rc = cam == 1 ? launch(grecon_stage_kernel<2, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, false, 2>, dyn) : launch(grecon_stage_kernel<2, false, 0>, dyn);
+    rc = cam == 1 ? launch(grecon_stage_kernel<2, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, false, 2>, dyn) : cam == 3 ? launch(grecon_stage_kernel<2, false, 3>, dyn) : launch(grecon_stage_kernel<2, false, 0>, dyn);
   else
     rc = launch(grecon_stage_kernel<0, false, 0>, 0);
 #endif

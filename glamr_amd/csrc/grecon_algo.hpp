@@ -774,8 +774,11 @@ GLAMR_HD float rel_transform_term(RT& rt, const Scene& sc, const SceneView& sh, 
 // CAM: how the stage treats the camera, when known at launch: 1 = optimised per frame, 2 = one optimised camera shared by all frames
 // (flag_fixed_cam), 0 = anything (constant, or derived from the persons).  Each value removes the other modes' code -- and their
 // registers -- from the instance: the general multi-person instance spills 214 VGPRs, its CAM = 1 version 58.
+// 3 = a CONSTANT camera: neither optimised nor derived from the persons -- the first stage of the multi-person configurations (variables
+// local_xy / local_heading only) and every forward-only pass; without the camera's gradient, its regularisers' reverse pass and the averaging over
+// the persons the several-person instances drop from 163 / 114 spilled registers (lite / full arena) to 0 / 3.
 inline int camera_mode(const glamr_stage_desc& st) {
-  if (!(st.var_mask & GLAMR_VAR_CAM)) return 0;
+  if (!(st.var_mask & GLAMR_VAR_CAM)) return (st.flags & GLAMR_FLAG_CAM_FROM_PERSON) ? 0 : 3;
   return (st.flags & GLAMR_FLAG_FIXED_CAM) ? 2 : 1;
 }
 
@@ -840,8 +843,8 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   // live across the whole body (two registers each, a few dozen arrays).
   const int fstep = ((FAST == 1 || FAST == 3) && RT::one_thread_per_frame) ? (1 << 20) : rt.nthreads();
   const int T = sc.T, P = SINGLE ? 1 : sc.P;
-  const bool var_cam = CAM != 0 ? true : (bool)(st.var_mask & GLAMR_VAR_CAM);
-  const bool fixed_cam = CAM == 2 ? true : (CAM == 1 ? false : (bool)(st.flags & GLAMR_FLAG_FIXED_CAM));
+  const bool var_cam = CAM == 3 ? false : (CAM != 0 ? true : (bool)(st.var_mask & GLAMR_VAR_CAM));
+  const bool fixed_cam = CAM == 2 ? true : ((CAM == 1 || CAM == 3) ? false : (bool)(st.flags & GLAMR_FLAG_FIXED_CAM));      // (only read where var_cam holds)
   const bool cam_from_person = CAM != 0 ? false : (!var_cam && (st.flags & GLAMR_FLAG_CAM_FROM_PERSON));
   const bool has_wd = (st.flags & GLAMR_FLAG_HAS_WORLD_DHEADING) || (st.var_mask & GLAMR_VAR_WORLD_DHEADING);
   auto on = [&](int id) { return (st.loss_mask >> id) & 1u; };

@@ -51,6 +51,7 @@ static void run_one(RT& rt, const glamr_scene_batch* b, const glamr_stage_desc* 
   switch (camera_mode(*st)) {
     case 1: if (single) run_scene<0, true, 1>(rt, sc, *st, l); else run_scene<0, false, 1>(rt, sc, *st, l); break;
     case 2: if (single) run_scene<0, true, 2>(rt, sc, *st, l); else run_scene<0, false, 2>(rt, sc, *st, l); break;
+    case 3: if (single) run_scene<0, true, 0>(rt, sc, *st, l); else run_scene<0, false, 3>(rt, sc, *st, l); break;      // (constant camera: its own instance for several persons, as on the device)
     default: if (single) run_scene<0, true, 0>(rt, sc, *st, l); else run_scene<0, false, 0>(rt, sc, *st, l); break;
   }
 }
