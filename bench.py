@@ -135,18 +135,21 @@ def cpu_baseline(asset_root, iters=40):
                       % (NUM_FRAMES, t_init, {k: round(v * 1e3, 1) for k, v in scan.items()}, iters, spec['opt_niters'], nt, per_iter * 1e3, total)}
 
 
-def _timed(fn, reps=3):
-    """Best-of-`reps` duration of fn() in seconds, measured with HIP events on the current stream (the library launches there)."""
+def _timed(fn, reps=3, calls=1):
+    """Best-of-`reps` duration of fn() in seconds, measured with HIP events on the current stream (the library launches there).  calls > 1: that many
+    calls back to back between the two events, per call -- for calls of a millisecond or less, whose few launches the host enqueues more slowly than an
+    idle GPU runs them (one call between two events then measures the interpreter: 1.15 against 0.95 ms for the skinning of 19 200 frames)."""
     import torch
     best = None
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
-        fn()
+        for _c in range(calls):
+            fn()
         b.record()
         torch.cuda.synchronize()
-        dt = a.elapsed_time(b) * 1e-3
+        dt = a.elapsed_time(b) * 1e-3 / calls
         best = dt if best is None else min(best, dt)
     return best
 
@@ -164,7 +167,7 @@ def kernel_lines(asset_root, model, dev):
         pose = (torch.randn(B, 72, generator=g) * 0.3).to(dev)
         betas, trans = torch.randn(B, 10, generator=g).to(dev), torch.randn(B, 3, generator=g).to(dev)
         for verts in (True, False):
-            dt = _timed(lambda: smpl(global_orient=pose[:, :3], body_pose=pose[:, 3:], betas=betas, root_trans=trans, return_verts=verts))
+            dt = _timed(lambda: smpl(global_orient=pose[:, :3], body_pose=pose[:, 3:], betas=betas, root_trans=trans, return_verts=verts), calls=20 if B > 1000 else 100)
             tf = SMPL_FLOP_PER_FRAME * B / dt / 1e12 if verts else None
             lines.append({'frames': B, 'vertices': verts, 'ms': round(dt * 1e3, 4),
                           'tflops_algorithmic': None if tf is None else round(tf, 2),
@@ -172,7 +175,7 @@ def kernel_lines(asset_root, model, dev):
                           'write_gbs': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9, 1) if verts else None,
                           'frac_of_hbm_peak': round(SMPL_BYTES_PER_FRAME_VERTS * B / dt / 1e9 / HBM_PEAK_GBS, 3) if verts else None})
     best = max((l['tflops_algorithmic'] or 0.0) for l in lines)
-    out['smpl_lbs'] = {'flop_per_frame': SMPL_FLOP_PER_FRAME, 'fp16x3_peak_tflops': round(FP16X3_PEAK_TFLOPS, 1),
+    out['smpl_lbs'] = {'timing': 'HIP events around 20 (19 200 frames) / 100 (300 frames) calls back to back, best of three, per call', 'flop_per_frame': SMPL_FLOP_PER_FRAME, 'fp16x3_peak_tflops': round(FP16X3_PEAK_TFLOPS, 1),
                        'frac_of_fp16x3_peak': round(best / FP16X3_PEAK_TFLOPS, 4), 'runs': lines}
     # the two priors on 1024 sequences of 300 frames (GEMM-dominated: the fp16-split MFMA kernels)
     md = synth.make_smpl_model()
@@ -250,7 +253,8 @@ def kernel_lines(asset_root, model, dev):
                                        'ms_per_iteration_round3_host_orchestrated': 20.3,
                                        'note': 'slope between a %d- and a %d-iteration run (init_data, the two plain iterations and the capture cancel): from the third iteration of '
                                                'a stage on the iteration -- taped infiller (10 windows), trajectory predictor, skinning, one gradient launch of the stage kernel, '
-                                               'SMPL backward, infiller backward, two Adam steps with their step numbers on the device: 1 271 kernels (profiles/r04_latent_kernel_stats.csv) -- is ONE replayed HIP graph' % (K1, K2)}
+                                               'SMPL backward, infiller backward, two Adam steps with their step numbers on the device: 1 271 kernels (profiles/r06_latent_kernel_stats.csv) -- is ONE replayed HIP graph; '
+                                               'round 6: the backward products of few rows on the one-wave split-fp16 kernel (12.8 -> 11.2 ms, profiles/r06_latent_ab.log)' % (K1, K2)}
     # ... and on a BATCH of sequences (round 5: the schedule takes S scenes; the reference runs the mode one sequence at a time)
     SB = 32
     many = [synth.make_in_dict(seed=s, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md) for s in range(SB)]
@@ -812,7 +816,8 @@ def run(argv=None):
                          'bound_note': 'one workgroup per scene, state on chip, 7 workgroup barriers per iteration; neither HBM nor the matrix pipes limit it.  Round 5 removed the exposed '
                                        'memory waits of the dependent chain (13.3 -> 10.6 us per scene-iteration, profiles/r05_stage_ab.log); what bounds it now is ISSUE on the SIMD that '
                                        'carries two of a 300-frame scene\'s five waves: the fifth wave leaves the keypoint phase 1.1 us after the other four, which wait for it at the '
-                                       'next barrier (profiles/r05_phase_times.log). '
+                                       'next barrier (profiles/r05_phase_times.log).  Round 6: 43 instead of 52 operations per scored joint (10.83 -> 10.5 us, profiles/r06_stage_ab.log); interleaved '
+                                       'joint chains (max-ILP scheduling), staged Adam chains and two scenes per CU measured without gain (profiles/r06_session2_probes.log). '
                                        'achieved / peak / frac are SURVEY 8(d) K5\'s yardstick: microseconds per scene-iteration against the 1.45 us dependent-boundary floor '
                                        "(frac = floor / achieved).  The contract's hbm line is kept under `contract_notional` and is NOTIONAL",
                          'achieved': us_scene_iter, 'peak': DEPENDENT_BOUNDARY_US, 'unit': 'us per scene-iteration (lower is better; peak = dependent-boundary floor)',
