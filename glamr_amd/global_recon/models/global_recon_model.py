@@ -1319,7 +1319,8 @@ class GlobalReconOptimizer:
         # (a caller that keeps a frozen set of its own -- gc.get_freeze_count() > 0 -- manages the collector itself: gc.unfreeze() would release ITS set too)
         frozen = gc.isenabled() and gc.get_freeze_count() == 0 and os.environ.get('GLAMR_STREAM_GC_FREEZE', '1') != '0'
         if frozen:
-            gc.collect()
+            # (no gc.collect() first: a full collection at this point walks every object alive -- 67 ms with torch imported, tools/stream_profile.py,
+            # at the head of every stream, before its first batch is even staged; whatever garbage is frozen along is collected after gc.unfreeze())
             gc.freeze()
         try:
             yield from self._stream_loop(it, lat, turn, computes, down, max_iters)
