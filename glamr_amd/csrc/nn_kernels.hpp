@@ -105,6 +105,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   }
 }
 
+// The same contract for FEW rows (M < 2048, what launch_gemm does not hand to the split-fp16 kernel: a 50-frame window of one sequence -- a lone sequence's priors, the taped forward of the
+// latent-optimisation mode: ~330 such products per pass).  gemm_kernel's wave walks K with one accumulator of v_mfma_f32_32x32x2_f32: K / 2 dependent
+// instructions of 64 cycles each, 3.4 us at K = 256 and 6.8 at 512, on 4 - 12 workgroups of a 256-CU chip.  Here a workgroup owns a 32 x 32 tile, each
+// wave a 16 x 16 accumulator walked with v_mfma_f32_16x16x4_f32 (K / 4 dependent instructions of ~40 cycles: 1.1 / 2.1 us) and four times as many
+// workgroups share the rows.  Products and sums stay fp32 (the split-fp16 kernels move a lone sequence's results out of the single-sequence parity bounds).
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
+  constexpr int TS = 32;
+  __shared__ __attribute__((aligned(16))) float sA[2][TS * GT_LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][TS * GT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  f32x4acc acc = {0.f, 0.f, 0.f, 0.f};
+  // staging map: 256 float4 per operand tile and chunk, one per thread
+  const int r0 = tid >> 3, c4 = (tid & 7) * 4;
+  constexpr int PF = 4;
+  const int nchunks = a.K / GT_K;
+  f32x4 va[PF], vb[PF];
+  const float* xa = a.X + (size_t)min(m0 + r0, a.M - 1) * a.ldx + c4;
+  const float* xb = a.W + (size_t)(n0 + r0) * a.K + c4;      // (W is padded to a multiple of 64 rows)
+  auto fetch = [&](int c, int slot) {
+    va[slot] = *reinterpret_cast<const f32x4*>(xa + c * GT_K);
+    vb[slot] = *reinterpret_cast<const f32x4*>(xb + c * GT_K);
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u) if (u < nchunks) fetch(u, u);
+  for (int c0 = 0; c0 < nchunks; c0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int c = c0 + u;
+      if (c >= nchunks) break;
+      float* bA = sA[c & 1];
+      float* bB = sB[c & 1];
+      *reinterpret_cast<f32x4*>(bA + r0 * GT_LD + c4) = va[u];
+      *reinterpret_cast<f32x4*>(bB + r0 * GT_LD + c4) = vb[u];
+      __syncthreads();
+      if (c + PF < nchunks) fetch(c + PF, u);
+      // lane group g consumes k = 8 g .. 8 g + 7 of the chunk, one value per instruction (the instruction's four k slots are the four groups)
+      const float* pa = bA + (wm * 16 + r16) * GT_LD + g * 8;
+      const float* pb = bB + (wn * 16 + r16) * GT_LD + g * 8;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(pa), x1 = *reinterpret_cast<const f32x4*>(pa + 4);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(pb), w1 = *reinterpret_cast<const f32x4*>(pb + 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[s], w0[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], w1[s], acc, 0, 0, 0);
+    }
+  }
+  // epilogue: lane owns column n0 + 16 wn + r16, rows 16 wm + 4 g + r
+  const int n = n0 + wn * 16 + r16;
+  if (n >= a.N) return;
+  const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + wm * 16 + 4 * g + r;
+    if (m >= a.M) continue;
+    float v = acc[r] + b;
+    if (a.rowbias) v += a.rowbias[(size_t)(a.rows_per_group > 0 ? m / a.rows_per_group : m % (-a.rows_per_group)) * a.ldrb + n];
+    if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+    if (a.R) v += a.R[(size_t)m * a.ldr + n];
+    a.Y[(size_t)m * a.ldy + n] = v;
+  }
+}
+
 // ---- fp32 GEMM on the 16-bit matrix cores ----------------------------------------------------------------------------------------
 // An fp32 number is, to 2^-22 of its size, the sum of two fp16 numbers (11 + 11 mantissa bits): x = hi + lo, hi = fp16(x), lo = fp16(x - hi)
 // (the remainder is exact in fp32).  The product of two such numbers, dropping lo*lo (2^-22 of it), is  hi*hi + hi*lo + lo*hi:  THREE
@@ -1088,6 +1154,11 @@ inline int launch_gemm(hipStream_t st, const float* X, int ldx, const float* W, 
   }
   // (measured and dropped, round 4: the K loop of a tile over two groups of four waves for grids of a handful of workgroups -- 13.3 against 12.4 us
   // per call at M = 50: these calls are launch + latency, not the chain of fp32 MFMAs)
+  static const bool no_small = [] { const char* e = std::getenv("GLAMR_GEMM_SMALL16"); return e && e[0] == '0'; }();      // development aid: gemm_kernel for few rows as well
+  if (!no_small) {      // (every product that is not on the split-fp16 kernels: a sequence alone and the same sequence inside a small batch then agree to the bit)
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, a);
+    return GLAMR_OK;
+  }
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M), dim3(256), 0, st, a);
   return GLAMR_OK;
 }
