@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* Q, int 
   // (rows of 36 floats: 16-byte aligned, so the channel loops below read four values per LDS instruction -- most of them broadcasts of one key row)
   __shared__ __attribute__((aligned(16))) float sQ[64][36], sK[64][36], sV[64][36], sdO[64][36];
   __shared__ float sP[64][65], sdS[64][65];
+  __shared__ float sPart[64][4];
   __shared__ unsigned char sM[64];
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, i = tid & 63, g = tid >> 6;
   const float scale = 0.17677669529663687f;      // 1 / sqrt(32)
@@ -95,17 +96,45 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* Q, int 
   } else {
     for (int j = g; j < 64; j += 4) { sP[i][j] = 0.f; sdS[i][j] = 0.f; }
   }
+  // softmax over the unmasked keys and dS = P o (dP - rowsum(dP o P)).  Round 3 - 5: one thread per row, four dependent loops over the keys with an LDS
+  // round trip (and an expf) per trip -- 8 of the kernel's 29 us, 70 calls per iteration of the latent-optimisation mode.  Round 6: what has no order
+  // (the row maximum) or no neighbour (the exponentials, the final products) is spread over the row's four threads by key, as the scores were; the two
+  // SUMS stay with one thread per row, added key by key in the order they always were -- every output bit as before.
+  if (i < Lq) {
+    float pm = -3.0e38f;
+    for (int j = g; j < Lk; j += 4) if (!sM[j]) pm = fmaxf(pm, sP[i][j]);      // (own writes of the loop above: no barrier needed)
+    sPart[i][g] = pm;
+  }
   __syncthreads();
-  // softmax over the unmasked keys and dS = P o (dP - rowsum(dP o P)): one thread per row
+  if (i < Lq) {
+    const float mx = fmaxf(fmaxf(sPart[i][0], sPart[i][1]), fmaxf(sPart[i][2], sPart[i][3]));
+    for (int j = g; j < Lk; j += 4) sP[i][j] = sM[j] ? 0.f : expf(sP[i][j] - mx);
+  }
+  __syncthreads();
   if (g == 0 && i < Lq) {
-    float mx = -3.0e38f;
-    for (int j = 0; j < Lk; ++j) if (!sM[j]) mx = fmaxf(mx, sP[i][j]);
+    // (four keys' values requested together, then added one after the other: the order of the sums is the keys' order)
     float sum = 0.f;
-    for (int j = 0; j < Lk; ++j) { const float e = sM[j] ? 0.f : expf(sP[i][j] - mx); sP[i][j] = e; sum += e; }
+    int j = 0;
+    for (; j + 4 <= Lk; j += 4) {
+      const float e0 = sP[i][j], e1 = sP[i][j + 1], e2 = sP[i][j + 2], e3 = sP[i][j + 3];
+      sum += e0; sum += e1; sum += e2; sum += e3;
+    }
+    for (; j < Lk; ++j) sum += sP[i][j];
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
     float dot = 0.f;
-    for (int j = 0; j < Lk; ++j) { const float p = sP[i][j] * inv; sP[i][j] = p; dot = fmaf(sdS[i][j], p, dot); }
-    for (int j = 0; j < Lk; ++j) sdS[i][j] = sP[i][j] * (sdS[i][j] - dot);
+    for (j = 0; j + 4 <= Lk; j += 4) {
+      const float e0 = sP[i][j], e1 = sP[i][j + 1], e2 = sP[i][j + 2], e3 = sP[i][j + 3];
+      const float d0_ = sdS[i][j], d1_ = sdS[i][j + 1], d2_ = sdS[i][j + 2], d3_ = sdS[i][j + 3];
+      dot = fmaf(d0_, e0 * inv, dot); dot = fmaf(d1_, e1 * inv, dot); dot = fmaf(d2_, e2 * inv, dot); dot = fmaf(d3_, e3 * inv, dot);
+    }
+    for (; j < Lk; ++j) dot = fmaf(sdS[i][j], sP[i][j] * inv, dot);
+    sPart[i][0] = inv;
+    sPart[i][1] = dot;
+  }
+  __syncthreads();
+  if (i < Lq) {
+    const float inv = sPart[i][0], dot = sPart[i][1];
+    for (int j = g; j < Lk; j += 4) { const float pr = sP[i][j] * inv; sP[i][j] = pr; sdS[i][j] = pr * (sdS[i][j] - dot); }
   }
   __syncthreads();
   const int d0 = g * 8;
