@@ -254,7 +254,7 @@ def kernel_lines(asset_root, model, dev):
                                        'note': 'slope between a %d- and a %d-iteration run (init_data, the two plain iterations and the capture cancel): from the third iteration of '
                                                'a stage on the iteration -- taped infiller (10 windows), trajectory predictor, skinning, one gradient launch of the stage kernel, '
                                                'SMPL backward, infiller backward, two Adam steps with their step numbers on the device: 1 271 kernels (profiles/r06_latent_kernel_stats.csv) -- is ONE replayed HIP graph; '
-                                               'round 6: the backward products of few rows on the one-wave split-fp16 kernel, the forward ones on gemm_small_kernel, the softmax of attention_bwd_kernel over four threads per row (12.8 -> 9.2 ms, profiles/r06_latent_ab.log)' % (K1, K2)}
+                                               'round 6: the backward products of few rows on the one-wave split-fp16 kernel, the forward ones on gemm_small_kernel, the softmax of attention_bwd_kernel over four threads per row (12.8 -> 8.6 ms, profiles/r06_latent_ab.log)' % (K1, K2)}
     # ... and on a BATCH of sequences (round 5: the schedule takes S scenes; the reference runs the mode one sequence at a time)
     SB = 32
     many = [synth.make_in_dict(seed=s, num_frames=NUM_FRAMES, num_persons=1, smpl_model=md) for s in range(SB)]

@@ -190,6 +190,7 @@ inline int launch_gemm_free_t(hipStream_t st, const GemmArgs& a) {
     case 8: hipLaunchKernelGGL((gemm_free_kernel<8, C, PD, MAXW>), grid, block, 0, st, a); break;
     case 16: hipLaunchKernelGGL((gemm_free_kernel<16, C, PD, MAXW>), grid, block, 0, st, a); break;
     case 32: hipLaunchKernelGGL((gemm_free_kernel<32, C, PD, MAXW>), grid, block, 0, st, a); break;
+    case 48: hipLaunchKernelGGL((gemm_free_kernel<48, C, PD, MAXW>), grid, block, 0, st, a); break;      // (K = 768: the backward of a QKV projection)
     default: hipLaunchKernelGGL((gemm_free_kernel<0, C, PD, MAXW>), grid, block, 0, st, a); break;
   }
   return GLAMR_OK;
@@ -200,6 +201,9 @@ inline int launch_gemm_free(hipStream_t st, const GemmArgs& a) {
 #ifndef GLAMR_FREE_GEMM_CFG
 #define GLAMR_FREE_GEMM_CFG 2, 1, 4      // development aid: column tiles per wave, k steps of operands ahead, waves per SIMD the allocation aims at
 #endif
+  // few rows (the backward products of the taped infiller: 50 rows on an otherwise idle chip): ONE column tile per wave -- twice the waves, half the
+  // chain of MFMAs in each (every output element is the same sum in the same order: bits unchanged)
+  if (a.M <= 128 && !a.x_frag && !a.y_frag) return launch_gemm_free_t<1, 1, 4>(st, a);
   return launch_gemm_free_t<GLAMR_FREE_GEMM_CFG>(st, a);
 }
 
