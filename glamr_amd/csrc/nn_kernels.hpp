@@ -1003,9 +1003,13 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
   __syncthreads();
   const float* Gb = a.G + (size_t)b * a.max_len * 1024 + dir * 512 + r;
   float* Hb = a.H + (size_t)b * a.max_len * 256 + dir * 128;
+  // (the gate pre-activation of the NEXT step is requested while this step runs: asked for at the top of its own step, every step began with a
+  // memory round trip -- 300 of them per launch, two launches per call of a lone sequence's trajectory predictor)
+  float gnext = n > 0 ? Gb[(size_t)(dir ? n - 1 : 0) * 1024] : 0.f;
   for (int s = 0; s < n; ++s) {
     const int t = dir ? (n - 1 - s) : s;
-    float acc = Gb[(size_t)t * 1024];
+    float acc = gnext;
+    if (s + 1 < n) gnext = Gb[(size_t)(dir ? n - 2 - s : s + 1) * 1024];
 #pragma unroll
     for (int k = 0; k < 128; k += 4) {
       const f32x4 hv = *reinterpret_cast<const f32x4*>(sh + k);
