@@ -728,16 +728,32 @@ GLAMR_HD float rel_transform_term(RT& rt, const Scene& sc, const SceneView& sh, 
     float gTi[12];
     for (int k = 0; k < 12; ++k) gTi[k] = 0.f;
     for (int o = 0; o < P; ++o) {
-      if (o == p || person_view<FAST>(rt, sc, o).vis[t] == 0.f) continue;
-      float To[12], Ro[9];
-      cols_to_R(person_view<FAST>(rt, sc, o).d6 + t * 6, Ro);
-      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = person_view<FAST>(rt, sc, o).tw[t * 3 + i]; }
-      float Toinv[12];
-      invert34(To, Toinv);
-      // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
+      if (o == p) continue;
+      // Everything the pair reads from memory is requested HERE, ahead of the per-lane visibility test: the other person's visibility, world
+      // rotation columns and translation, and both directions' 3 x 4 targets (constants of the launch that do not fit the arena: L2).  Asked for where
+      // they are used -- behind the test, then inside the direction loop -- every pair waited three memory round trips in a row: 25 of the 109 us of a
+      // 4-person iteration (tools/grecon_phases.py).  Same arithmetic, same order.
+      const PersonView vo = person_view<FAST>(rt, sc, o);
+      const float vis_o = vo.vis[t];
+      float d6o[6], two[3], tgt2[2][12];
+      for (int k = 0; k < 6; ++k) d6o[k] = vo.d6[t * 6 + k];
+      for (int k = 0; k < 3; ++k) two[k] = vo.tw[t * 3 + k];
       for (int dir = 0; dir < 2; ++dir) {
         const int a = dir == 0 ? p : o, b = dir == 0 ? o : p;
         const float* target = sh.rel_cam + (((size_t)a * sh.rel_stride_p + b) * sh.rel_stride_t + t) * 12;
+        for (int k = 0; k < 12; ++k) tgt2[dir][k] = target[k];
+      }
+      if (vis_o == 0.f) continue;
+      float To[12], Ro[9];
+      cols_to_R(d6o, Ro);
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) To[i * 4 + j] = Ro[i * 3 + j]; To[i * 4 + 3] = two[i]; }
+      float Toinv[12];
+      invert34(To, Toinv);
+      // pair (p, o): rel = inv(T_p) T_o ; pair (o, p): rel = inv(T_o) T_p.  This thread owns T_p's gradient of both.
+#pragma unroll
+      for (int dir = 0; dir < 2; ++dir) {
+        const int a = dir == 0 ? p : o, b = dir == 0 ? o : p;
+        const float* target = tgt2[dir];
         const float fw = (sh.pair_first[a * MAXP + b] == t) ? st.first_frame_weight[GLAMR_LOSS_REL_TRANSFORM] : 1.0f;
         float rel[12];
         if (dir == 0) mul34(Tiinv, To, rel); else mul34(Toinv, Ti, rel);
