@@ -248,11 +248,14 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   // 1 full arena + Adam state of single-person scenes, 3 full arena (both: single-pass instances, a thread per frame), 2 lite arena,
   // 0 everything in the workspace
   const bool per_frame = batch->max_len <= threads;
-  ka.use_lds = (full <= LDS_BUDGET && per_frame) ? 1 : ((full_arena <= LDS_BUDGET && per_frame) ? 3 : (lite <= LDS_BUDGET ? 2 : 0));
+  // (4 = mid, scenes of several persons only: BASELINE configs[3]'s 4 x 300 frames take 143 of the 153 KB; `GLAMR_GRECON_NO_MID_ARENA` keeps them on the lite arena)
+  const size_t mid = scene_fast_floats(batch->max_persons, batch->max_len, 4) * sizeof(float);
+  static const bool no_mid = std::getenv("GLAMR_GRECON_NO_MID_ARENA") != nullptr;      // development aid / A-B runs
+  ka.use_lds = (full <= LDS_BUDGET && per_frame) ? 1 : ((full_arena <= LDS_BUDGET && per_frame) ? 3 : ((mid <= LDS_BUDGET && batch->max_persons > 1 && !no_mid) ? 4 : (lite <= LDS_BUDGET ? 2 : 0)));
   // a launch that records the per-iteration loss history (glamr_scene_batch.loss_history) runs on the plain instance: the reporting evaluation
   // every iteration is a diagnostic mode, and the arena instances' loops stay free of it
   if (batch->loss_history && stage->niters > 0) ka.use_lds = 0;
-  const size_t base = ka.use_lds == 1 ? full : (ka.use_lds == 3 ? full_arena : lite);
+  const size_t base = ka.use_lds == 1 ? full : (ka.use_lds == 3 ? full_arena : (ka.use_lds == 4 ? mid : lite));
   const size_t want = base + (size_t)NJ * 6 * batch->max_persons * arena_len * sizeof(float);
   const size_t dyn = ka.use_lds ? (want < LDS_BUDGET ? want : LDS_BUDGET) : 0;
   ka.fast_floats = (unsigned)(dyn / sizeof(float));
@@ -271,7 +274,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   };
   int rc;
 #ifdef GLAMR_GRECON_WIDE
-  if (ka.use_lds == 1 || ka.use_lds == 3) {      // (the full arena of > 8 persons never fits; kept from being instantiated)
+  if (ka.use_lds == 1 || ka.use_lds == 3 || ka.use_lds == 4) {      // (the full arena of > 8 persons never fits; kept from being instantiated -- the mid arena likewise)
     ka.use_lds = lite <= LDS_BUDGET ? 2 : 0;
     const size_t want2 = lite + (size_t)NJ * 6 * batch->max_persons * arena_len * sizeof(float);
     ka.fast_floats = (unsigned)((ka.use_lds ? (want2 < LDS_BUDGET ? want2 : LDS_BUDGET) : 0) / sizeof(float));
@@ -291,6 +294,8 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
     rc = cam == 1 ? launch(grecon_stage_kernel<1, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<1, false, 2>, dyn) : cam == 3 ? launch(grecon_stage_kernel<1, false, 3>, dyn) : launch(grecon_stage_kernel<1, false, 0>, dyn);
   else if (ka.use_lds == 2 && single)
     rc = cam == 1 ? launch(grecon_stage_kernel<2, true, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, true, 2>, dyn) : launch(grecon_stage_kernel<2, true, 0>, dyn);
+  else if (ka.use_lds == 4)
+    rc = cam == 1 ? launch(grecon_stage_kernel<4, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<4, false, 2>, dyn) : cam == 3 ? launch(grecon_stage_kernel<4, false, 3>, dyn) : launch(grecon_stage_kernel<4, false, 0>, dyn);
   else if (ka.use_lds == 2)
     rc = cam == 1 ? launch(grecon_stage_kernel<2, false, 1>, dyn) : cam == 2 ? launch(grecon_stage_kernel<2, false, 2>, dyn) : cam == 3 ? launch(grecon_stage_kernel<2, false, 3>, dyn) : launch(grecon_stage_kernel<2, false, 0>, dyn);
   else

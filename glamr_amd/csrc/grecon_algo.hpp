@@ -164,12 +164,16 @@ template <int FAST, class T> __device__ __forceinline__ T* fastp(T* p) {
 }
 // arrays of the second group are on chip only with a full arena (FAST == 1 or 3); with the lite arena (FAST == 2) they are global
 template <int FAST, class T> __device__ __forceinline__ T* fastp2(T* p) { return (FAST == 1 || FAST == 3) ? fastp<1>(p) : glob(p); }
+// ... and the own-frame hand-over arrays between the residual phase and the reverse pass (world translation, the two adjoints) also with the MID
+// arena (FAST == 4: lite + those three, for scenes of several persons whose full arena does not fit)
+template <int FAST, class T> __device__ __forceinline__ T* fastp3(T* p) { return (FAST == 1 || FAST == 3 || FAST == 4) ? fastp<1>(p) : glob(p); }
 #else
 template <class T> inline T* uni(T* p) { return p; }
 inline int uni(int x) { return x; }
 template <class T> inline T* glob(T* p) { return p; }
 template <int FAST, class T> inline T* fastp(T* p) { return p; }
 template <int FAST, class T> inline T* fastp2(T* p) { return p; }
+template <int FAST, class T> inline T* fastp3(T* p) { return p; }
 #endif
 
 // Frame-loop condition.  The device build also tells the compiler that a frame index is a small non-negative number (the launcher
@@ -475,7 +479,9 @@ GLAMR_HD void param_layout(int max_persons, int max_len, glamr_param_layout& l) 
 // Where every per-scene array lives: float offsets into the on-chip arena (lds) or into the scene's workspace slice.  One function
 // for the binder (run time), the size queries, and -- with a frame count known at compile time -- the constant addresses of the
 // constant-layout instances.  `fast`: an arena exists; `fast_mode` 1 = full (+ parameters and Adam moments of single-person scenes),
-// 2 = lite, 3 = full with the Adam state in the workspace (a smaller arena: several workgroups of short sequences share a CU).
+// 2 = lite, 3 = full with the Adam state in the workspace (a smaller arena: several workgroups of short sequences share a CU),
+// 4 = mid: lite + world translation and the two adjoint hand-over arrays (26 instead of 14 floats per person-frame: what 3 - 4 persons x 300 frames
+// leave room for; round 6).
 struct ArrOff { unsigned off; bool lds; };
 struct PersonOff {
   ArrOff m_ws, v_ws, m, v, p, g_ws, theta, csn, xy, d6, tw, g_d6, g_tw, g_theta, g_xy, Lc, kpc_ws, vis_rank, kp_wsum, h_prior, oc6;
@@ -501,6 +507,8 @@ GLAMR_HD constexpr SceneOff scene_offsets(int max_persons, int max_len, bool fas
   auto lds = [&](unsigned n) { ArrOff r{f, true}; f += n; return r; };
   auto takef = [&](unsigned n) { return fast ? lds(n) : take(n); };
   auto takef2 = [&](unsigned n) { return full ? lds(n) : take(n); };
+  const bool mid = fast && fast_mode == 4;      // lite + the three hand-over arrays a frame's own thread reads back after a barrier (12 floats per person-frame)
+  auto takef3 = [&](unsigned n) { return (full || mid) ? lds(n) : take(n); };
   // the moments of the camera block use a COMPACT index: camera parameters i, camera residuals i - 9 T
   o.cm_ws = take(person0); o.cv_ws = take(person0);
   o.cm = af ? lds(9 * TM) : o.cm_ws; o.cv = af ? lds(9 * TM) : o.cv_ws;
@@ -516,7 +524,7 @@ GLAMR_HD constexpr SceneOff scene_offsets(int max_persons, int max_len, bool fas
     s.m = af ? lds(pstride) : s.m_ws; s.v = af ? lds(pstride) : s.v_ws;
     if (af) s.p = lds(pstride);
     s.g_ws = take(pstride);
-    s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef2(3 * TM); s.g_d6 = takef2(6 * TM); s.g_tw = takef2(3 * TM);
+    s.theta = takef(TM); s.csn = takef(2 * TM); s.xy = takef(2 * TM); s.d6 = takef(6 * TM); s.tw = takef3(3 * TM); s.g_d6 = takef3(6 * TM); s.g_tw = takef3(3 * TM);
     s.g_theta = takef(TM); s.g_xy = takef(2 * TM); s.Lc = takef2(12 * TM);
     s.kpc_ws = take(26 * 6 * TM);
     s.vis_rank = take(TM); s.kp_wsum = take(32); s.h_prior = take(TM); s.oc6 = take(6 * TM);
@@ -579,7 +587,7 @@ GLAMR_HD PersonView person_view(RT& rt, const Scene& sc, int p) {
     if (AF) { w.p = fastp<1>(s.p); w.m = fastp<1>(s.m); w.v = fastp<1>(s.v); } else { w.p = glob(s.p); w.m = glob(s.m); w.v = glob(s.v); }
     // first group (prefix sums, neighbour reads): on chip with either arena; second group (own-frame hand-over arrays): full arena only
     w.theta = fastp<FAST>(s.theta); w.csn = fastp<FAST>(s.csn); w.xy = fastp<FAST>(s.xy); w.d6 = fastp<FAST>(s.d6); w.g_theta = fastp<FAST>(s.g_theta); w.g_xy = fastp<FAST>(s.g_xy);
-    w.tw = fastp2<FAST>(s.tw); w.g_d6 = fastp2<FAST>(s.g_d6); w.g_tw = fastp2<FAST>(s.g_tw); w.Lc = fastp2<FAST>(s.Lc);
+    w.tw = fastp3<FAST>(s.tw); w.g_d6 = fastp3<FAST>(s.g_d6); w.g_tw = fastp3<FAST>(s.g_tw); w.Lc = fastp2<FAST>(s.Lc);
     w.kpc = fastp<FAST>(s.kpc); w.kpc_ws = glob(s.kpc_ws);      // kpc is only dereferenced for the njc_fast joints that are on chip
     return w;
   }
