@@ -250,7 +250,7 @@ extern "C" int glamr_grecon_run_stage(const glamr_scene_batch* batch, const glam
   const bool per_frame = batch->max_len <= threads;
   // (4 = mid, scenes of several persons only: BASELINE configs[3]'s 4 x 300 frames take 143 of the 153 KB; `GLAMR_GRECON_NO_MID_ARENA` keeps them on the lite arena)
   const size_t mid = scene_fast_floats(batch->max_persons, batch->max_len, 4) * sizeof(float);
-  static const bool no_mid = std::getenv("GLAMR_GRECON_NO_MID_ARENA") != nullptr;      // development aid / A-B runs
+  const bool no_mid = std::getenv("GLAMR_GRECON_NO_MID_ARENA") != nullptr;      // development aid / A-B tests (read per launch)
   ka.use_lds = (full <= LDS_BUDGET && per_frame) ? 1 : ((full_arena <= LDS_BUDGET && per_frame) ? 3 : ((mid <= LDS_BUDGET && batch->max_persons > 1 && !no_mid) ? 4 : (lite <= LDS_BUDGET ? 2 : 0)));
   // a launch that records the per-iteration loss history (glamr_scene_batch.loss_history) runs on the plain instance: the reporting evaluation
   // every iteration is a diagnostic mode, and the arena instances' loops stay free of it

@@ -594,6 +594,29 @@ def test_shared_cu_arena_gives_the_same_values(make_model, monkeypatch):
         assert np.array_equal(policy[i]['person_data'][0]['kp_2d_pred'], policy[i % 6]['person_data'][0]['kp_2d_pred'])
 
 
+def test_mid_arena_gives_the_same_values(make_model, monkeypatch):
+    """Scenes of several persons whose full arena does not fit a CU's LDS (BASELINE configs[3]: 4 persons x 300 frames; 3 persons likewise) run on
+    the MID arena since round 6 -- the lite arena's arrays plus world translation and the two adjoint hand-over arrays on chip (instances
+    grecon_stage_kernel<4, false, CAM>).  Where an array lives must not change a single bit: against the lite arena (GLAMR_GRECON_NO_MID_ARENA, read
+    per launch), both stages of cfg glamr_static_multi (constant camera, then the shared optimised one), 12 iterations each, ragged existence ranges."""
+    md = synth.make_smpl_model()
+    in_dicts = [_trim_person(synth.make_in_dict(seed=70, num_frames=300, num_persons=4, smpl_model=md), 2, 11, 280),
+                synth.make_in_dict(seed=71, num_frames=300, num_persons=3, smpl_model=md, gap=(120, 150))]
+    model = make_model('glamr_static_multi')
+    out = {}
+    for name, env in (('mid', None), ('lite', '1')):
+        if env is None:
+            monkeypatch.delenv('GLAMR_GRECON_NO_MID_ARENA', raising=False)
+        else:
+            monkeypatch.setenv('GLAMR_GRECON_NO_MID_ARENA', env)
+        out[name] = [model.optimize(d, latents=mg.latents_for(d, 70 + i), max_iters=12) for i, d in enumerate(in_dicts)]
+    for a, b in zip(out['mid'], out['lite']):
+        assert np.array_equal(a['cam_pose'], b['cam_pose'])
+        for pid in a['person_data']:
+            for key in ('kp_2d_pred', 'root_trans_world', 'smpl_orient_world', 'traj_local_rot', 'traj_local_dxy'):
+                assert np.array_equal(a['person_data'][pid][key], b['person_data'][pid][key]), (pid, key)
+
+
 def test_constant_layout_instance_gives_the_same_values(make_model, monkeypatch):
     """BASELINE configs[1]'s length selects the constant-layout instances of the stage kernel (arena, workspace and on-chip parameter
     blocks laid out for 304 frames, every address of the loop a compile-time constant, stage-constant inputs read from workspace
