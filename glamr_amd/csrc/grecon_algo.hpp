@@ -1942,14 +1942,34 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   auto keep_losses = [&](int it) {
     if (FAST == 0 && hist && rt.tid() == 0) for (int k = 0; k < GLAMR_NUM_LOSSES; ++k) glob(hist)[(size_t)it * GLAMR_NUM_LOSSES + k] = sh.losses[k];
   };
-  if (FAST == 0 && hist) {
-    for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::true_type{}); keep_losses(it); trace_hook(rt, it, sc, 0); }
+  // GLAMR_FLAG_NO_REPORT (launch-by-launch schedules: the gradient launch of every iteration but a stage's last): the final evaluation is an
+  // update-only one as well -- no outputs, no loss values, gradients (and grads_out) as always.  Same two instantiations, one call site each.
+  // (honoured by the instances for scenes of several persons with run-time layouts -- what the person-sharded schedule launches; compiled out of the
+  // single-person instances, whose loops keep the code they were tuned with: with it the constant-layout instance measured 10.67 instead of 10.50 us)
+  constexpr bool NR = !SINGLE && TMC == 0;
+  if constexpr (NR) {
+    const bool no_report = niters > 0 && (st.flags & GLAMR_FLAG_NO_REPORT) && !(FAST == 0 && hist);
+    const int n_plain = no_report ? n_eval : n_eval - 1;
+    if (FAST == 0 && hist) {
+      for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::true_type{}); keep_losses(it); trace_hook(rt, it, sc, 0); }
+    } else {
+      for (int it = 0; it < n_plain; ++it) { evaluate(std::false_type{}); trace_hook(rt, it, sc, 0); }
+    }
+    if (!no_report) {
+      evaluate(std::true_type{});
+      keep_losses(n_eval - 1);
+      trace_hook(rt, n_eval - 1, sc, 0);
+    }
   } else {
-    for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::false_type{}); trace_hook(rt, it, sc, 0); }
+    if (FAST == 0 && hist) {
+      for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::true_type{}); keep_losses(it); trace_hook(rt, it, sc, 0); }
+    } else {
+      for (int it = 0; it + 1 < n_eval; ++it) { evaluate(std::false_type{}); trace_hook(rt, it, sc, 0); }
+    }
+    evaluate(std::true_type{});
+    keep_losses(n_eval - 1);
+    trace_hook(rt, n_eval - 1, sc, 0);
   }
-  evaluate(std::true_type{});
-  keep_losses(n_eval - 1);
-  trace_hook(rt, n_eval - 1, sc, 0);
   rt.sync();
   if (AF) {      // the on-chip parameters go back to the batch array, once
     copy_person_block(rt, sc.ps[0].p_g, l, sc.ps[0].p, lo);

@@ -215,7 +215,9 @@ class PersonShardedSchedule:
             m, v = torch.zeros_like(params), torch.zeros_like(params)
             not_own = [pi for pi in range(P) if pi not in own]
 
-            def iteration(it, adam):
+            def iteration(it, adam, report=True):
+                # report=False (every iteration but the stage's last): the gradient launch skips the reporting part of its evaluation --
+                # all 26 joints, the outputs, the 13 loss reductions (GLAMR_FLAG_NO_REPORT); the stage's outputs are the last iteration's
                 keep = packing.FLAG_KEEP_CAM_PARAMS if it > 0 else 0
                 fwd = packing.stage_desc(spec, model_specs, has_wd, niters=0)
                 fwd.flags |= keep | packing.FLAG_POSES_ONLY                         # (only the world poses are wanted: no residuals, no projections)
@@ -223,7 +225,7 @@ class PersonShardedSchedule:
                 self._all_gather_poses(packed, own, block)                           # 2.
                 gd = packing.stage_desc(spec, model_specs, has_wd, niters=1)
                 gd.lr = 0.0                                                          # the update is made below, after the reduction
-                gd.flags |= packing.FLAG_KEEP_CAM_PARAMS | (packing.FLAG_NO_CAMERA_TERMS if self.rank != 0 else 0)
+                gd.flags |= packing.FLAG_KEEP_CAM_PARAMS | (packing.FLAG_NO_CAMERA_TERMS if self.rank != 0 else 0) | (0 if report else packing.FLAG_NO_REPORT)
                 grads = self.run_stage(packed, gd, True)                             # 3.
                 self.launches += 2
                 if self.use_dist:
@@ -236,10 +238,10 @@ class PersonShardedSchedule:
                     self.grad_hook(packed, stage, spec, grads)
                 adam(grads)                                                          # 5.
 
-            graph = self._iteration_graph(packed, params, m, v, spec['opt_lr'], n, iteration) if n > 2 else None
+            graph = self._iteration_graph(packed, params, m, v, spec['opt_lr'], n, iteration) if n > 3 else None
             if graph is None:
                 for it in range(n):
-                    iteration(it, lambda g, it=it: self.adam_step(params.view(-1), m.view(-1), v.view(-1), g.view(-1), spec['opt_lr'], it + 1))
+                    iteration(it, lambda g, it=it: self.adam_step(params.view(-1), m.view(-1), v.view(-1), g.view(-1), spec['opt_lr'], it + 1), report=(it == n - 1))
             has_wd = has_wd or 'world_dheading' in spec['opt_variables']
             if spec.get('reinitialize_cam', False):
                 packed.t['cam_pose'][:] = packed.t['cam_pose'][:, :1]
@@ -252,7 +254,8 @@ class PersonShardedSchedule:
         return packed
 
     def _iteration_graph(self, packed, params, m, v, lr, n, iteration):
-        """Iterations 1 .. n - 1 of a stage as replays of ONE captured HIP graph (device entry points only): forward-only launch, all-gather, gradient
+        """Iterations 2 .. n - 2 of a stage as replays of ONE captured HIP graph, iterations 0, 1 and n - 1 plainly (the last one reports: outputs and loss
+        values; the others carry GLAMR_FLAG_NO_REPORT) (device entry points only): forward-only launch, all-gather, gradient
         launch, all-reduce, Adam -- five launches and two collectives enqueued by a single graph launch, the Adam step number read from a device
         counter (glamr_adam_step_indexed / glamr_counter_add).  Host-orchestrated the same sequence costs ~420 us per iteration against ~100 us of
         kernel time (bench.py `configs3_person_sharded`): on an 8-GPU node that would measure launches, not links.  Iteration 0 runs plainly (it
@@ -281,22 +284,23 @@ class PersonShardedSchedule:
             _lib.check(L.glamr_counter_add(_lib.ptr(step), 1, st))
         snapshot = (params.clone(), m.clone(), v.clone(), self.launches)
         try:
-            iteration(0, adam_indexed)
-            iteration(1, adam_indexed)                                              # (a plain iteration of the captured kind first: allocations, attribute calls)
+            iteration(0, adam_indexed, report=False)
+            iteration(1, adam_indexed, report=False)                                # (a plain iteration of the captured kind first: allocations, attribute calls)
             torch.cuda.synchronize(params.device)
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream(device=params.device)
             side.wait_stream(torch.cuda.current_stream(params.device))
             with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                iteration(2, adam_indexed)                                          # (iteration number only selects KEEP_CAM_PARAMS: any it > 0 is the same graph)
+                iteration(2, adam_indexed, report=False)                            # (iteration number only selects KEEP_CAM_PARAMS: any it > 0 is the same graph)
             self.launches -= 2                                                      # (capturing launched nothing)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-            for _ in range(2, n):
+            for _ in range(2, n - 1):
                 g.replay()
                 self.launches += 2
             ev1.record()
-            self.__dict__.setdefault('replay_events', []).append((ev0, ev1, n - 2))      # (device time of the replayed iterations: bench.py)
+            self.__dict__.setdefault('replay_events', []).append((ev0, ev1, n - 3))      # (device time of the replayed iterations: bench.py)
+            iteration(n - 1, adam_indexed, report=True)                             # the stage's last iteration, plainly: its evaluation reports
             self.iteration_graphs = getattr(self, 'iteration_graphs', 0) + 1
             return True
         except Exception as e:      # noqa: BLE001 -- anything (a runtime without capturable collectives, ...): restore and let the plain loop run

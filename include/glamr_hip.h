@@ -235,6 +235,10 @@ int glamr_traj_local_to_global(int n_seq, int T, const float* local_traj, float*
 #define GLAMR_FLAG_ABSOLUTE_HEADING (1u << 6)      /* absolute_heading (global_recon_model.py:59,283,421; no shipped config): the heading entries of the local
                                                       trajectory are absolute, not increments.  Runs on the instances of csrc/grecon_wide.hip whatever the
                                                       number of persons (the instances with the on-chip arena are compiled without it) */
+#define GLAMR_FLAG_NO_REPORT (1u << 7)             /* niters > 0, launch-by-launch schedules (glamr_amd/parallel.py): the launch's LAST evaluation updates and
+                                                      records gradients like the others but writes no outputs and no loss values -- the gradient launch of
+                                                      every iteration except a stage's last one, whose outputs are the stage's (round 6).  Ignored (the launch reports as usual) by
+                                                      launches that record the per-iteration loss history and by scenes of one person */
 
 /* loss ids (loss_func_dict, loss_func.py:314-340) -- order of glamr_stage_desc.loss_weight[] */
 enum {
