@@ -883,7 +883,13 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
   // there the first Adam steps are lr x the SIGN of gradients that are rounding noise, the reference's sign is reproduced by rounds 4-5's operation
   // order (0.002 px after 15 steps against 0.20 px with any other: tests/grecon_common.py KSTEP_TOL), and that order is kept, as for the scans.
   const bool kp_fold = GLAMR_KP_FOLD != 0 && !cam_from_person;
-  if (!poses_only) setup_tables(rt, sc);
+  // GLAMR_FLAG_KEEP_TABLES (launch-by-launch schedules, every gradient launch of a stage but its first, on the SAME workspace): what the stage set-up
+  // leaves in the workspace and no iteration touches -- visibility tables, per-joint score sums, the orientation targets, the workspace rows of the
+  // keypoint table -- is still there.  Honoured by the several-person run-time-layout instances only (see NR below: the others keep their code).
+  constexpr bool KT = !SINGLE && TMC == 0;
+  bool keep_tables = false;
+  if constexpr (KT) keep_tables = !poses_only && st.niters > 0 && (st.flags & GLAMR_FLAG_KEEP_TABLES);
+  if constexpr (KT) { if (!poses_only && !keep_tables) setup_tables(rt, sc); } else { if (!poses_only) setup_tables(rt, sc); }
   // ---- stage setup: normalisers, Adam state, camera parameters from the current camera (get_parameter :596-606) ----------
   float n_vis_total = 0.f, n_exist = 0.f, n_exist_m1 = 0.f;
   for (int p = 0; p < P && !poses_only; ++p) {
@@ -942,7 +948,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int k = 0; k < 3; ++k) sc.cp[lo.cam_trans + t * 3 + k] = sc.cp_g[l.cam_trans + t * 3 + k];
     }
   }
-  for (int p = 0; p < P; ++p)
+  for (int p = 0; p < P && !(KT && keep_tables); ++p)
     for (int t = rt.tid(); frame_in(t, T); t += fstep) {
       const PersonConst& c = sc.pc[p];
       if (t < c.fr_end - c.fr_start) sc.ps[p].h_prior[t] = rm::atan2s(c.prior[(size_t)t * 11 + 10], c.prior[(size_t)t * 11 + 9]);
@@ -951,7 +957,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       for (int r = 0; r < 3; ++r) { sc.ps[p].oc6[t * 6 + r] = Rb[r * 3 + 0]; sc.ps[p].oc6[t * 6 + 3 + r] = Rb[r * 3 + 1]; }
     }
   // per-joint sum over visible frames of thresholded score^2 (first_frame_only broadcasting of kp_2d, loss_func.py:27-33)
-  for (int p = 0; p < P && !poses_only; ++p) {
+  for (int p = 0; p < P && !poses_only && !(KT && keep_tables); ++p) {
     float cj[NJ];
     for (int j = 0; j < NJ; ++j) cj[j] = 0.f;
     for (int t = rt.tid(); frame_in(t, T); t += fstep) {
@@ -989,6 +995,7 @@ GLAMR_HD void run_scene(RT& rt, Scene& sc, const glamr_stage_desc& st, const gla
       const bool kp_frame = c.vis[t] != 0.f && (!kp_first || c.vis_rank[t] == 0);
       const float rank_w = (c.vis_rank[t] >= 0 && c.vis_rank[t] < 10) ? st.first_frame_weight[GLAMR_LOSS_KP_2D] : 1.0f;
       for (int jj = 0; jj < s.njc; ++jj) {
+        if (KT && keep_tables && jj >= s.njc_fast) break;      // (the workspace rows are still there; the on-chip rows are rebuilt with the arena)
         const int j = s.jidx[jj];
         float w = 0.f;
         if (kp_frame) {

@@ -17,6 +17,7 @@ VAR_BITS = {'cam': 1, 'local_xy': 2, 'local_heading': 4, 'world_dheading': 8, 'l
 FLAG_FIXED_CAM, FLAG_CAM_FROM_PERSON, FLAG_HAS_WORLD_DHEADING = 1, 2, 4
 FLAG_KEEP_CAM_PARAMS, FLAG_NO_CAMERA_TERMS = 8, 16          # launch-by-launch stages (glamr_amd/parallel.py PersonShardedSchedule)
 FLAG_POSES_ONLY = 32                                       # a forward-only launch that stops after the world poses
+FLAG_KEEP_TABLES = 256                                     # launch-by-launch schedules: same stage, same workspace as the previous launch -- the set-up's tables are kept
 FLAG_NO_REPORT = 128                                       # launch-by-launch schedules: the launch's last evaluation writes no outputs / loss values
 FLAG_ABSOLUTE_HEADING = 64                                 # specs absolute_heading: per-frame headings are absolute (csrc/grecon_wide.hip instances)
 

@@ -100,14 +100,16 @@ def gather_results(local_results, dst=0):
 # Person-sharded scenes: the collective variant of BASELINE configs[3]
 # ------------------------------------------------------------------------------------------------------------------------------------
 
-def _device_run_stage(packed, sd, want_grads):
-    """glamr_grecon_run_stage on the packed batch (current stream); returns the gradient record (n_scenes, scene_stride) or None."""
+def _device_run_stage(packed, sd, want_grads, ws=None):
+    """glamr_grecon_run_stage on the packed batch (current stream); returns the gradient record (n_scenes, scene_stride) or None.  `ws`: a
+    workspace the caller keeps across launches (GLAMR_FLAG_KEEP_TABLES needs the previous launch's); a fresh one otherwise."""
     import ctypes
     from . import _lib
     L = _lib.lib()
     sb = packed.struct()
     grads = torch.zeros_like(packed.t['params']) if want_grads else None
-    ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=packed.device)
+    if ws is None:
+        ws = torch.empty(L.glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=packed.device)
     _lib.check(L.glamr_grecon_run_stage(ctypes.byref(sb), ctypes.byref(sd), _lib.ptr(grads), _lib.ptr(ws), _lib.current_stream()))
     packed.last_ws = ws
     return grads
@@ -214,6 +216,10 @@ class PersonShardedSchedule:
             n = spec['opt_niters'] if max_iters is None else min(max_iters, spec['opt_niters'])
             m, v = torch.zeros_like(params), torch.zeros_like(params)
             not_own = [pi for pi in range(P) if pi not in own]
+            grad_ws = None
+            if self.run_stage is _device_run_stage and params.is_cuda and os.environ.get('GLAMR_SHARDED_KEEP_TABLES', '1') != '0':
+                from . import _lib
+                grad_ws = torch.empty(_lib.lib().glamr_grecon_workspace_bytes(packed.S, packed.P, packed.T), dtype=torch.uint8, device=packed.device)
 
             def iteration(it, adam, report=True):
                 # report=False (every iteration but the stage's last): the gradient launch skips the reporting part of its evaluation --
@@ -226,7 +232,13 @@ class PersonShardedSchedule:
                 gd = packing.stage_desc(spec, model_specs, has_wd, niters=1)
                 gd.lr = 0.0                                                          # the update is made below, after the reduction
                 gd.flags |= packing.FLAG_KEEP_CAM_PARAMS | (packing.FLAG_NO_CAMERA_TERMS if self.rank != 0 else 0) | (0 if report else packing.FLAG_NO_REPORT)
-                grads = self.run_stage(packed, gd, True)                             # 3.
+                if grad_ws is not None:
+                    # the gradient launches of a stage share ONE workspace nothing else writes to: from the second on, the stage-constant tables of
+                    # the set-up are still in it (GLAMR_FLAG_KEEP_TABLES: ~100 us of a 250 us launch)
+                    gd.flags |= packing.FLAG_KEEP_TABLES if it > 0 else 0
+                    grads = self.run_stage(packed, gd, True, ws=grad_ws)                 # 3.
+                else:
+                    grads = self.run_stage(packed, gd, True)                         # 3.
                 self.launches += 2
                 if self.use_dist:
                     cam = grads[:, :l['person0']].contiguous()

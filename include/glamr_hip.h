@@ -235,6 +235,10 @@ int glamr_traj_local_to_global(int n_seq, int T, const float* local_traj, float*
 #define GLAMR_FLAG_ABSOLUTE_HEADING (1u << 6)      /* absolute_heading (global_recon_model.py:59,283,421; no shipped config): the heading entries of the local
                                                       trajectory are absolute, not increments.  Runs on the instances of csrc/grecon_wide.hip whatever the
                                                       number of persons (the instances with the on-chip arena are compiled without it) */
+#define GLAMR_FLAG_KEEP_TABLES (1u << 8)           /* niters > 0, launch-by-launch schedules: the caller runs this stage again on the SAME workspace (contents
+                                                      untouched since the previous launch of this stage on this batch): the stage-constant tables the set-up
+                                                      leaves there -- visibility ranks, pair tables, per-joint score sums, orientation targets, the workspace rows
+                                                      of the keypoint table -- are not rebuilt.  Scenes of several persons only; ignored otherwise (round 6) */
 #define GLAMR_FLAG_NO_REPORT (1u << 7)             /* niters > 0, launch-by-launch schedules (glamr_amd/parallel.py): the launch's LAST evaluation updates and
                                                       records gradients like the others but writes no outputs and no loss values -- the gradient launch of
                                                       every iteration except a stage's last one, whose outputs are the stage's (round 6).  Ignored (the launch reports as usual) by
