@@ -77,3 +77,38 @@ def test_person_sharded_schedule_under_an_rccl_group(monkeypatch):
     assert out['launches_per_iteration'] == 2.0 and out['persons_per_rank'] == 4
     assert out['median_projection_difference_px'] < 0.05
     assert out['person_sharded_us_per_iteration'] > out['in_kernel_reduction_us_per_iteration'] > 0
+
+
+def test_kept_tables_and_silent_gradient_launches_change_nothing(asset_root, monkeypatch):
+    """Round 6: the gradient launches of a sharded stage share ONE workspace and, from the second on, skip the stage-constant part of the set-up
+    (GLAMR_FLAG_KEEP_TABLES); every one but the stage's last skips the reporting part of its evaluation (GLAMR_FLAG_NO_REPORT); iterations 2 .. n - 2 are
+    replays of one captured graph.  None of it is arithmetic: against the schedule with a fresh workspace, a full set-up and plain launches every
+    iteration (GLAMR_SHARDED_KEEP_TABLES=0, GLAMR_SHARDED_GRAPH=0) parameters, projections and loss values must agree bit for bit -- both stages of
+    glamr_static_multi, 4 persons with ragged existence ranges, one rank without a process group."""
+    from glamr_amd import parallel
+    from glamr_amd.global_recon import packing
+    from glamr_amd.global_recon.configs import get_config
+    from glamr_amd.utils import synth
+    from oracle.port import build
+    cfg = get_config('glamr_static_multi')
+    T, P, K = 120, 4, 7
+    in_dict = synth.trim_person(synth.make_in_dict(seed=21, num_frames=T, num_persons=P, smpl_model=synth.make_smpl_model()), 1, 9, 101)
+    ora = build.load_optimizer(asset_root, cfg)
+    data = ora.init_data(in_dict, latents=mg.latents_for(in_dict, 21))
+    jl = gc.j_local_from_oracle(ora.smpl, data)
+    dev = torch.device('cuda:0')
+    out = {}
+    for name, env in (('kept', {}), ('plain', {'GLAMR_SHARDED_KEEP_TABLES': '0', 'GLAMR_SHARDED_GRAPH': '0'})):
+        for k in ('GLAMR_SHARDED_KEEP_TABLES', 'GLAMR_SHARDED_GRAPH'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        packed = packing.PackedScenes([data, data], [jl, jl], dev)
+        sched = parallel.PersonShardedSchedule(rank=0, world=1, use_dist=False)
+        sched.run(packed, cfg['opt_stage_specs'], cfg['grecon_model_specs'], max_iters=K)
+        torch.cuda.synchronize()
+        out[name] = {k: packed.t[k].clone() for k in ('params', 'kp_2d_pred', 'orient_world', 'trans_world', 'cam_pose', 'losses')}
+        if name == 'kept':
+            assert getattr(sched, 'iteration_graphs', 0) == len(cfg['opt_stage_specs'])          # the captured iterations were used
+    for k in out['kept']:
+        assert torch.equal(out['kept'][k], out['plain'][k]), k
